@@ -1,0 +1,179 @@
+/*
+ * xrl_abi.h -- C ABI of libxrl_amd.so, the MI355X-native XR-Linear inference library.
+ *
+ * Part 1 declares, with IDENTICAL names, argument order and meaning, the entry points the
+ * reference (amzn/pecos @ 2024-10-20) exports from pecos.core.libpecos_float32 for its
+ * XR-Linear inference path, so that the reference's ctypes binding
+ * (pecos/core/base.py:799-976 link_xlinear_methods, :1499-1534 link_sparse_operations) can bind
+ * this library for that path without change.  Every declaration cites the reference line it
+ * replaces.  Part 2 is ADDITIVE (prefix xrl_): error reporting, device selection and a
+ * device-resident variant of predict used for benchmarking and multi-GPU sharding.
+ *
+ * All pointers are plain host pointers unless a parameter is documented as a device pointer.
+ * No torch / C++ types appear in any signature.
+ */
+#ifndef XRL_ABI_H
+#define XRL_ABI_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Matrix views handed over by the caller (read-only, valid for the duration of the call).
+ * Layout-identical to pecos/core/utils/matrix.hpp:49-71 and the ctypes mirrors in
+ * pecos/core/base.py:172-354.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {            /* matrix.hpp:49-55  ScipyCsrF32 */
+    uint32_t rows, cols;
+    uint64_t* row_ptr;      /* [rows+1] */
+    uint32_t* col_idx;      /* [nnz], ascending inside a row (base.py:1073-1076) */
+    float* val;             /* [nnz] */
+} ScipyCsrF32;
+
+typedef struct {            /* matrix.hpp:56-62  ScipyCscF32 */
+    uint32_t rows, cols;
+    uint64_t* col_ptr;      /* [cols+1] */
+    uint32_t* row_idx;      /* [nnz], ascending inside a column */
+    float* val;             /* [nnz] */
+} ScipyCscF32;
+
+typedef struct {            /* matrix.hpp:63-67  ScipyDrmF32: dense row-major */
+    uint32_t rows, cols;
+    float* val;             /* [rows*cols] */
+} ScipyDrmF32;
+
+typedef struct {            /* matrix.hpp:68-72  ScipyDcmF32: dense column-major */
+    uint32_t rows, cols;
+    float* val;             /* [rows*cols] */
+} ScipyDcmF32;
+
+/* matrix.hpp:47.  The callee passes the ADDRESSES of its three result pointers; the caller
+ * allocates indices u32[nnz], indptr u64[rows+1 | cols+1], data f32[nnz] and writes their
+ * addresses back (pecos/core/base.py:431-464).  Invoked exactly once per predict call,
+ * synchronously on the calling thread, after all device work has completed. */
+typedef void (*py_sparse_allocator_t)(bool is_col_major, uint64_t rows, uint64_t cols,
+                                      uint64_t nnz, void* indices_pp, void* indptr_pp,
+                                      void* data_pp);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 1: reference-compatible entry points
+ * ---------------------------------------------------------------------------------------- */
+
+/* pecos/core/libpecos.cpp:116-119.  model_path = <model>/ranker (param.json + {d}.model/). */
+void* c_xlinear_load_model_from_disk(const char* model_path);
+
+/* libpecos.cpp:121-126.  weight_matrix_type in {0 CSC, 1 HASH_CHUNKED, 2 BINARY_SEARCH_CHUNKED}
+ * (pecos/core/base.py:49).  This library has ONE device layout; the value is remembered only so
+ * that c_xlinear_get_layer_type answers like the reference. */
+void* c_xlinear_load_model_from_disk_ext(const char* model_path, int weight_matrix_type);
+
+/* libpecos.cpp:140-143 */
+void c_xlinear_destruct_model(void* ptr);
+
+/* libpecos.cpp:147-150; attr in {depth, nr_features, nr_labels, nr_codes} (inference.hpp:2367-2379) */
+uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr);
+
+/* libpecos.cpp:152-156 */
+int c_xlinear_get_layer_type(void* ptr, int layer_depth);
+
+/* libpecos.cpp:158-175 (C_XLINEAR_PREDICT).  0 / NULL overrides mean "use the model's per-layer
+ * param.json value" (inference.hpp:2055-2058).  `threads` is accepted and ignored (the work runs
+ * on the GPU).  Result: CSR rows x nr_labels, rows score-sorted, at most only_topk per row. */
+void c_xlinear_predict_csr_f32(void* ptr, const ScipyCsrF32* input_x,
+                               const uint32_t overridden_beam_size,
+                               const char* overridden_post_processor_str,
+                               const uint32_t overridden_only_topk, const int threads,
+                               py_sparse_allocator_t pred_alloc);
+void c_xlinear_predict_drm_f32(void* ptr, const ScipyDrmF32* input_x,
+                               const uint32_t overridden_beam_size,
+                               const char* overridden_post_processor_str,
+                               const uint32_t overridden_only_topk, const int threads,
+                               py_sparse_allocator_t pred_alloc);
+
+/* libpecos.cpp:201-235 (C_XLINEAR_SINGLE_LAYER_PREDICT): one layer from caller-owned W / C,
+ * optional previous-layer predictions csr_codes (NULL => all-ones N x C.cols, no combine). */
+void c_xlinear_single_layer_predict_csr_f32(const ScipyCsrF32* input_x, const ScipyCsrF32* csr_codes,
+                                            ScipyCscF32* W, ScipyCscF32* C,
+                                            const char* post_processor_str, const uint32_t only_topk,
+                                            const int num_threads, const float bias,
+                                            py_sparse_allocator_t pred_alloc);
+void c_xlinear_single_layer_predict_drm_f32(const ScipyDrmF32* input_x, const ScipyCsrF32* csr_codes,
+                                            ScipyCscF32* W, ScipyCscF32* C,
+                                            const char* post_processor_str, const uint32_t only_topk,
+                                            const int num_threads, const float bias,
+                                            py_sparse_allocator_t pred_alloc);
+
+/* libpecos.cpp:337-355 (C_SPARSE_INNER_PRODUCTS): val[i] = <X[X_row_idx[i],:], W[:,W_col_idx[i]]>,
+ * `val` is caller-allocated f32[len] (pecos/core/utils/matrix.hpp:1049-1060). */
+void c_sparse_inner_products_csr2csc_f32(const ScipyCsrF32* pX, const ScipyCscF32* pW, uint64_t len,
+                                         uint32_t* X_row_idx, uint32_t* W_col_idx, float* val, int threads);
+void c_sparse_inner_products_drm2csc_f32(const ScipyDrmF32* pX, const ScipyCscF32* pW, uint64_t len,
+                                         uint32_t* X_row_idx, uint32_t* W_col_idx, float* val, int threads);
+void c_sparse_inner_products_csr2dcm_f32(const ScipyCsrF32* pX, const ScipyDcmF32* pW, uint64_t len,
+                                         uint32_t* X_row_idx, uint32_t* W_col_idx, float* val, int threads);
+void c_sparse_inner_products_drm2dcm_f32(const ScipyDrmF32* pX, const ScipyDcmF32* pW, uint64_t len,
+                                         uint32_t* X_row_idx, uint32_t* W_col_idx, float* val, int threads);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 2: additive entry points (no reference counterpart)
+ * ---------------------------------------------------------------------------------------- */
+
+/* The reference throws C++ exceptions through extern "C" (process abort).  This library catches
+ * everything; a failed call returns (NULL / 0 / without invoking the allocator) and leaves a
+ * message here.  Thread-local; NULL when the last call on this thread succeeded. */
+const char* xrl_last_error(void);
+void xrl_clear_error(void);
+
+const char* xrl_version(void);
+int xrl_device_count(void);            /* hipGetDeviceCount; 0 when no GPU is visible */
+int xrl_set_device(int device);        /* device used by subsequent loads on this thread; 0 = ok */
+
+/* Build a model from in-memory CSC layers (same semantics as loading the folder). */
+void* xrl_model_create(uint32_t depth, const ScipyCscF32* const* W, const ScipyCscF32* const* C,
+                       const float* bias, const uint32_t* only_topk,
+                       const char* const* post_processor);
+
+/* Device-resident queries: upload once, predict many times (bench / multi-GPU shards). */
+void* xrl_queries_upload_csr(void* model, const ScipyCsrF32* X);
+void* xrl_queries_upload_drm(void* model, const ScipyDrmF32* X);
+void xrl_queries_free(void* queries);
+
+/* Beam search with inputs already resident in HBM.  Writes fixed-stride results
+ *   d_out_idx u32[rows*out_stride], d_out_val f32[rows*out_stride], d_out_cnt u32[rows]
+ * into caller-provided DEVICE buffers (e.g. torch tensors) on `hip_stream` (a hipStream_t, NULL =
+ * the library's own stream) and returns without synchronising when `sync` == 0.
+ * out_stride must be >= the effective only_topk.  Returns 0 on success. */
+int xrl_predict_device(void* model, void* queries, uint32_t beam_size, const char* post_processor,
+                       uint32_t only_topk, uint32_t* d_out_idx, float* d_out_val,
+                       uint32_t* d_out_cnt, uint32_t out_stride, void* hip_stream, int sync);
+
+/* Effective only_topk of the last layer for the given override (0 = model default). */
+uint32_t xrl_effective_topk(void* model, uint32_t only_topk);
+
+/* Profiling: when enabled, every kernel launch of predict is bracketed by hipEvents on its stream.
+ * xrl_profile_get fills up to `cap` records; returns the number available. */
+typedef struct {
+    char name[32];          /* kernel family: "k0_prolongate", "k1_sparse", "k1_dense", "k2_topk", ... */
+    uint32_t layer;
+    uint32_t launches;
+    double ms;              /* accumulated GPU time of those launches */
+    double alg_bytes;       /* accumulated ALGORITHMIC bytes those launches processed */
+} xrl_profile_rec_t;
+void xrl_profile_enable(void* model, int enable);
+void xrl_profile_reset(void* model);
+uint32_t xrl_profile_get(void* model, xrl_profile_rec_t* out, uint32_t cap);
+
+/* Tuning knobs (benchmark / tests only): key in {"k1_group", "sort_items", "max_batch_rows"} */
+int xrl_set_option(void* model, const char* key, int64_t value);
+
+/* Bytes of HBM held by the compiled model. */
+uint64_t xrl_model_device_bytes(void* model);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRL_ABI_H */

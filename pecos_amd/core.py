@@ -1,0 +1,367 @@
+"""ctypes binding of ``libxrl_amd.so`` -- the MI355X counterpart of ``pecos.core.clib`` for the
+XR-Linear inference path.
+
+Mirrors, for that path only, the reference's binding layer (pecos/core/base.py):
+
+* struct views ``ScipyCsrF32 / ScipyCscF32 / ScipyDrmF32 / ScipyDcmF32``   base.py:172-354
+* ``ScipyCompressedSparseAllocator`` (python-side result allocator)        base.py:357-478
+* ``corelib`` methods ``xlinear_load_predict_only``, ``xlinear_destruct_model``,
+  ``xlinear_get_int_attr``, ``xlinear_get_layer_type``, ``xlinear_predict``,
+  ``xlinear_single_layer_predict``, ``sparse_inner_products``             base.py:978-1405, 1536-1589
+
+with the same names, argument order and meaning, so that code written against
+``pecos.core.clib`` reads the same against :data:`clib` here.  There is NO CPU fallback: every
+compute call needs a visible HIP device and raises ``RuntimeError`` otherwise.
+"""
+import ctypes
+import os
+from ctypes import (CFUNCTYPE, POINTER, byref, c_bool, c_char_p, c_double, c_float, c_int, c_int64,
+                    c_uint32, c_uint64, c_void_p, cast)
+
+import numpy as np
+import scipy.sparse as smat
+
+XLINEAR_INFERENCE_MODEL_TYPES = {"CSC": 0, "HASH_CHUNKED": 1, "BINARY_SEARCH_CHUNKED": 2}  # base.py:49
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libxrl_amd.so")
+
+
+class _MatView(ctypes.Structure):
+    """Common behaviour of the zero-copy matrix views (the buffers are kept alive in py_buf)."""
+
+    @classmethod
+    def init_from(cls, A):
+        if A is None:
+            return None
+        if isinstance(A, cls):
+            return A
+        return cls(A)
+
+    @property
+    def dtype(self):
+        return self.buf.dtype
+
+    @property
+    def shape(self):
+        return self.buf.shape
+
+
+class ScipyCscF32(_MatView):
+    _fields_ = [("rows", c_uint32), ("cols", c_uint32), ("col_ptr", POINTER(c_uint64)),
+                ("row_idx", POINTER(c_uint32)), ("val", POINTER(c_float))]
+
+    def __init__(self, A):
+        assert isinstance(A, smat.csc_matrix)
+        assert A.dtype == np.float32
+        self.py_buf = {"col_ptr": A.indptr.astype(np.uint64, copy=False),
+                       "row_idx": A.indices.astype(np.uint32, copy=False),
+                       "val": A.data.astype(np.float32, copy=False)}
+        self.rows, self.cols = A.shape
+        for name, typ in self._fields_[2:]:
+            setattr(self, name, self.py_buf[name].ctypes.data_as(typ))
+        self.buf = A
+
+
+class ScipyCsrF32(_MatView):
+    _fields_ = [("rows", c_uint32), ("cols", c_uint32), ("row_ptr", POINTER(c_uint64)),
+                ("col_idx", POINTER(c_uint32)), ("val", POINTER(c_float))]
+
+    def __init__(self, A):
+        assert isinstance(A, smat.csr_matrix)
+        assert A.dtype == np.float32
+        self.py_buf = {"row_ptr": A.indptr.astype(np.uint64, copy=False),
+                       "col_idx": A.indices.astype(np.uint32, copy=False),
+                       "val": A.data.astype(np.float32, copy=False)}
+        self.rows, self.cols = A.shape
+        for name, typ in self._fields_[2:]:
+            setattr(self, name, self.py_buf[name].ctypes.data_as(typ))
+        self.buf = A
+
+
+class ScipyDrmF32(_MatView):
+    _fields_ = [("rows", c_uint32), ("cols", c_uint32), ("val", POINTER(c_float))]
+
+    def __init__(self, A):
+        assert isinstance(A, np.ndarray)
+        assert A.dtype == np.float32
+        assert A.flags["C_CONTIGUOUS"] is True
+        self.py_buf = {"val": A}
+        self.rows, self.cols = A.shape
+        self.val = A.ctypes.data_as(POINTER(c_float))
+        self.buf = A
+
+
+class ScipyDcmF32(_MatView):
+    _fields_ = [("rows", c_uint32), ("cols", c_uint32), ("val", POINTER(c_float))]
+
+    def __init__(self, A):
+        assert isinstance(A, np.ndarray)
+        assert A.dtype == np.float32
+        assert A.flags["F_CONTIGUOUS"] is True
+        self.py_buf = {"val": A}
+        self.rows, self.cols = A.shape
+        self.val = A.ctypes.data_as(POINTER(c_float))
+        self.buf = A
+
+
+class ScipyCompressedSparseAllocator(object):
+    """Python-side allocator handed to the native predict call (base.py:357-478): the callee passes
+    the addresses of its three pointers, we allocate numpy arrays and write their addresses back."""
+
+    CFUNCTYPE = CFUNCTYPE(None, c_bool, c_uint64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p)
+
+    def __init__(self, rows=0, cols=0, dtype=np.float32):
+        assert dtype == np.float32
+        self.rows, self.cols, self.dtype = rows, cols, dtype
+        self.indices = self.indptr = self.data = None
+        self.is_col_major = None
+
+    def __call__(self, is_col_major, rows, cols, nnz, indices_ptr, indptr_ptr, data_ptr):
+        self.rows, self.cols, self.is_col_major = rows, cols, is_col_major
+        self.indptr = np.zeros((cols if is_col_major else rows) + 1, dtype=np.uint64)
+        self.indices = np.zeros(nnz, dtype=np.uint32)
+        self.data = np.zeros(nnz, dtype=self.dtype)
+        for dst, arr in ((indices_ptr, self.indices), (indptr_ptr, self.indptr), (data_ptr, self.data)):
+            cast(dst, POINTER(c_uint64)).contents.value = arr.ctypes.data_as(c_void_p).value or 0
+
+    def get(self):
+        if self.indptr is None:
+            raise RuntimeError("native call did not produce a result")
+        mat = smat.csc_matrix if self.is_col_major else smat.csr_matrix
+        # int64 index arrays (scipy would otherwise up/down-cast unsigned ones); order is preserved
+        return mat((self.data, self.indices.astype(np.int64), self.indptr.astype(np.int64)),
+                   shape=(self.rows, self.cols))
+
+    @property
+    def cfunc(self):
+        return self.CFUNCTYPE(self)
+
+
+class ProfileRec(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 32), ("layer", c_uint32), ("launches", c_uint32),
+                ("ms", c_double), ("alg_bytes", c_double)]
+
+
+class corelib(object):
+    """The C-ABI library, loaded lazily (so that importing the package works on a CPU-only box)."""
+
+    def __init__(self, so_path=_LIB_PATH):
+        self.so_path = so_path
+        self._lib = None
+
+    # ------------------------------------------------------------------ loading / errors
+    @property
+    def clib_float32(self):
+        if self._lib is None:
+            if not os.path.exists(self.so_path):
+                raise RuntimeError(
+                    f"{self.so_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(hipcc --offload-arch=gfx950).  pecos_amd has no CPU fallback.")
+            self._lib = ctypes.CDLL(self.so_path)
+            self._link(self._lib)
+        return self._lib
+
+    @staticmethod
+    def _link(lib):
+        alloc_t = ScipyCompressedSparseAllocator.CFUNCTYPE
+        sigs = {
+            "xrl_last_error": (c_char_p, []),
+            "xrl_clear_error": (None, []),
+            "xrl_version": (c_char_p, []),
+            "xrl_device_count": (c_int, []),
+            "xrl_set_device": (c_int, [c_int]),
+            "c_xlinear_load_model_from_disk": (c_void_p, [c_char_p]),
+            "c_xlinear_load_model_from_disk_ext": (c_void_p, [c_char_p, c_int]),
+            "c_xlinear_destruct_model": (None, [c_void_p]),
+            "c_xlinear_get_int_attr": (c_uint32, [c_void_p, c_char_p]),
+            "c_xlinear_get_layer_type": (c_int, [c_void_p, c_int]),
+            "c_xlinear_predict_csr_f32": (None, [c_void_p, POINTER(ScipyCsrF32), c_uint32, c_char_p, c_uint32, c_int, alloc_t]),
+            "c_xlinear_predict_drm_f32": (None, [c_void_p, POINTER(ScipyDrmF32), c_uint32, c_char_p, c_uint32, c_int, alloc_t]),
+            "c_xlinear_single_layer_predict_csr_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyCsrF32), POINTER(ScipyCscF32), POINTER(ScipyCscF32), c_char_p, c_uint32, c_int, c_float, alloc_t]),
+            "c_xlinear_single_layer_predict_drm_f32": (None, [POINTER(ScipyDrmF32), POINTER(ScipyCsrF32), POINTER(ScipyCscF32), POINTER(ScipyCscF32), c_char_p, c_uint32, c_int, c_float, alloc_t]),
+            "c_sparse_inner_products_csr2csc_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyCscF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
+            "c_sparse_inner_products_drm2csc_f32": (None, [POINTER(ScipyDrmF32), POINTER(ScipyCscF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
+            "c_sparse_inner_products_csr2dcm_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyDcmF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
+            "c_sparse_inner_products_drm2dcm_f32": (None, [POINTER(ScipyDrmF32), POINTER(ScipyDcmF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
+            "xrl_model_create": (c_void_p, [c_uint32, c_void_p, c_void_p, POINTER(c_float), POINTER(c_uint32), POINTER(c_char_p)]),
+            "xrl_queries_upload_csr": (c_void_p, [c_void_p, POINTER(ScipyCsrF32)]),
+            "xrl_queries_upload_drm": (c_void_p, [c_void_p, POINTER(ScipyDrmF32)]),
+            "xrl_queries_free": (None, [c_void_p]),
+            "xrl_predict_device": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int]),
+            "xrl_effective_topk": (c_uint32, [c_void_p, c_uint32]),
+            "xrl_profile_enable": (None, [c_void_p, c_int]),
+            "xrl_profile_reset": (None, [c_void_p]),
+            "xrl_profile_get": (c_uint32, [c_void_p, POINTER(ProfileRec), c_uint32]),
+            "xrl_set_option": (c_int, [c_void_p, c_char_p, c_int64]),
+            "xrl_model_device_bytes": (c_uint64, [c_void_p]),
+        }
+        for name, (res, args) in sigs.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+
+    EXPORTED_SYMBOLS = None  # filled below from include/xrl_abi.h by tests
+
+    def _check(self):
+        err = self.clib_float32.xrl_last_error()
+        if err:
+            self.clib_float32.xrl_clear_error()
+            raise RuntimeError(err.decode("utf-8", "replace"))
+
+    # ------------------------------------------------------------------ device management (additive)
+    def device_count(self):
+        return int(self.clib_float32.xrl_device_count())
+
+    def set_device(self, device):
+        self.clib_float32.xrl_set_device(int(device))
+        self._check()
+
+    # ------------------------------------------------------------------ xlinear (base.py:978-1405)
+    def xlinear_load_predict_only(self, folder, weight_matrix_type="BINARY_SEARCH_CHUNKED"):
+        """Load a model folder (``<model>/ranker``) onto the GPU; returns the native handle."""
+        type_id = XLINEAR_INFERENCE_MODEL_TYPES[weight_matrix_type]
+        cmodel = self.clib_float32.c_xlinear_load_model_from_disk_ext(c_char_p(folder.encode("utf-8")), c_int(int(type_id)))
+        self._check()
+        return cmodel
+
+    def xlinear_load_mmap(self, folder, lazy_load=False):
+        raise NotImplementedError("mmap model folders are not supported by the MI355X library yet (SURVEY.md N3)")
+
+    def xlinear_destruct_model(self, c_model):
+        if self._lib is not None and c_model:
+            self._lib.c_xlinear_destruct_model(c_void_p(c_model))
+
+    def xlinear_get_int_attr(self, c_model, attr):
+        assert attr in {"depth", "nr_features", "nr_labels", "nr_codes"}, f"attr {attr} not implemented"
+        v = self.clib_float32.c_xlinear_get_int_attr(c_void_p(c_model), c_char_p(attr.encode("utf-8")))
+        self._check()
+        return v
+
+    def xlinear_get_layer_type(self, c_model, layer_depth):
+        v = self.clib_float32.c_xlinear_get_layer_type(c_void_p(c_model), layer_depth)
+        self._check()
+        return v
+
+    def xlinear_predict(self, c_model, X, overriden_beam_size, overriden_post_processor_str, overriden_only_topk,
+                        threads, pred_alloc):
+        """Full beam-search prediction (base.py:1041-1095).  ``None``/0 overrides = model defaults."""
+        clib = self.clib_float32
+        if isinstance(X, smat.csr_matrix):
+            if not X.has_sorted_indices:
+                raise ValueError("Query matrix does not have sorted indices!")
+            X = ScipyCsrF32.init_from(X)
+        elif isinstance(X, np.ndarray):
+            X = ScipyDrmF32.init_from(X)
+        if isinstance(X, ScipyCsrF32):
+            c_predict = clib.c_xlinear_predict_csr_f32
+        elif isinstance(X, ScipyDrmF32):
+            c_predict = clib.c_xlinear_predict_drm_f32
+        else:
+            raise NotImplementedError("type(X) = {} not implemented".format(type(X)))
+        cb = pred_alloc.cfunc
+        c_predict(c_void_p(c_model), byref(X), overriden_beam_size if overriden_beam_size else 0,
+                  overriden_post_processor_str.encode("utf-8") if overriden_post_processor_str else None,
+                  overriden_only_topk if overriden_only_topk else 0, threads, cb)
+        self._check()
+
+    def xlinear_single_layer_predict(self, X, csr_codes, W, C, post_processor_str, only_topk, num_threads, bias, pred_alloc):
+        """One layer from python-owned W / C (base.py:1143-1207)."""
+        clib = self.clib_float32
+        post_processor_str = post_processor_str.encode("utf-8")
+        W = ScipyCscF32.init_from(W)
+        C = ScipyCscF32.init_from(C)
+        if isinstance(X, smat.csr_matrix):
+            if not X.has_sorted_indices:
+                raise ValueError("Query matrix does not have sorted indices!")
+            X = ScipyCsrF32.init_from(X)
+        elif isinstance(X, np.ndarray):
+            X = ScipyDrmF32.init_from(X)
+        if isinstance(X, ScipyCsrF32):
+            c_predict = clib.c_xlinear_single_layer_predict_csr_f32
+        elif isinstance(X, ScipyDrmF32):
+            c_predict = clib.c_xlinear_single_layer_predict_drm_f32
+        else:
+            raise NotImplementedError("type(X) = {} not implemented".format(type(X)))
+        codes = ScipyCsrF32.init_from(csr_codes)
+        cb = pred_alloc.cfunc
+        c_predict(byref(X), byref(codes) if codes is not None else None, byref(W),
+                  byref(C) if C is not None else None, post_processor_str, only_topk, num_threads, bias, cb)
+        self._check()
+
+    def sparse_inner_products(self, X, W, X_row_idx, W_col_idx, pred_values=None, threads=-1):
+        """val[i] = <X[X_row_idx[i], :], W[:, W_col_idx[i]]>  (base.py:1536-1589)."""
+        clib = self.clib_float32
+        nnz = len(X_row_idx)
+        assert nnz == len(W_col_idx)
+        assert X.shape[1] == W.shape[0]
+        if isinstance(X, smat.csr_matrix) and isinstance(W, smat.csc_matrix):
+            pX, pW, fn = ScipyCsrF32.init_from(X), ScipyCscF32.init_from(W), clib.c_sparse_inner_products_csr2csc_f32
+        elif isinstance(X, np.ndarray) and isinstance(W, smat.csc_matrix):
+            pX, pW, fn = ScipyDrmF32.init_from(X), ScipyCscF32.init_from(W), clib.c_sparse_inner_products_drm2csc_f32
+        elif isinstance(X, smat.csr_matrix) and isinstance(W, np.ndarray):
+            pX, pW, fn = ScipyCsrF32.init_from(X), ScipyDcmF32.init_from(W), clib.c_sparse_inner_products_csr2dcm_f32
+        elif isinstance(X, np.ndarray) and isinstance(W, np.ndarray):
+            pX, pW, fn = ScipyDrmF32.init_from(X), ScipyDcmF32.init_from(W), clib.c_sparse_inner_products_drm2dcm_f32
+        else:
+            raise NotImplementedError("type(X)={} and type(W)={} no implemented".format(type(X), type(W)))
+        if pred_values is None or len(pred_values) != nnz or pred_values.dtype != np.float32:
+            pred_values = np.zeros(nnz, pW.dtype)
+        rows = np.ascontiguousarray(X_row_idx, dtype=np.uint32)
+        cols = np.ascontiguousarray(W_col_idx, dtype=np.uint32)
+        fn(byref(pX), byref(pW), nnz, rows.ctypes.data_as(POINTER(c_uint32)), cols.ctypes.data_as(POINTER(c_uint32)),
+           pred_values.ctypes.data_as(POINTER(c_float)), threads)
+        self._check()
+        return pred_values
+
+    # ------------------------------------------------------------------ device-resident path (additive)
+    def queries_upload(self, c_model, X):
+        lib = self.clib_float32
+        if isinstance(X, smat.csr_matrix):
+            if not X.has_sorted_indices:
+                raise ValueError("Query matrix does not have sorted indices!")
+            h = lib.xrl_queries_upload_csr(c_void_p(c_model), byref(ScipyCsrF32.init_from(X)))
+        elif isinstance(X, np.ndarray):
+            h = lib.xrl_queries_upload_drm(c_void_p(c_model), byref(ScipyDrmF32.init_from(X)))
+        else:
+            raise NotImplementedError("type(X) = {} not implemented".format(type(X)))
+        self._check()
+        return h
+
+    def queries_free(self, h):
+        if self._lib is not None and h:
+            self._lib.xrl_queries_free(c_void_p(h))
+
+    def predict_device(self, c_model, queries, beam_size, post_processor, only_topk, d_idx, d_val, d_cnt, out_stride,
+                       stream=None, sync=True):
+        """``d_*`` are raw device addresses (e.g. ``tensor.data_ptr()``)."""
+        rc = self.clib_float32.xrl_predict_device(
+            c_void_p(c_model), c_void_p(queries), beam_size or 0,
+            post_processor.encode("utf-8") if post_processor else None, only_topk or 0,
+            c_void_p(d_idx), c_void_p(d_val), c_void_p(d_cnt), out_stride, c_void_p(stream or 0), 1 if sync else 0)
+        self._check()
+        return rc
+
+    def effective_topk(self, c_model, only_topk):
+        return int(self.clib_float32.xrl_effective_topk(c_void_p(c_model), only_topk or 0))
+
+    def profile_enable(self, c_model, on=True):
+        self.clib_float32.xrl_profile_enable(c_void_p(c_model), 1 if on else 0)
+
+    def profile_reset(self, c_model):
+        self.clib_float32.xrl_profile_reset(c_void_p(c_model))
+
+    def profile_get(self, c_model):
+        n = self.clib_float32.xrl_profile_get(c_void_p(c_model), None, 0)
+        arr = (ProfileRec * max(1, n))()
+        n = self.clib_float32.xrl_profile_get(c_void_p(c_model), arr, n)
+        return [dict(name=arr[i].name.decode(), layer=arr[i].layer, launches=arr[i].launches, ms=arr[i].ms,
+                     alg_bytes=arr[i].alg_bytes) for i in range(n)]
+
+    def set_option(self, c_model, key, value):
+        self.clib_float32.xrl_set_option(c_void_p(c_model), key.encode("utf-8"), int(value))
+        self._check()
+
+    def model_device_bytes(self, c_model):
+        return int(self.clib_float32.xrl_model_device_bytes(c_void_p(c_model)))
+
+
+clib = corelib()

@@ -1,0 +1,430 @@
+// extern "C" surface of libxrl_amd.so (include/xrl_abi.h).  Every entry point catches all C++
+// exceptions and records them for xrl_last_error(); nothing is ever thrown across the C boundary.
+#include "../../include/xrl_abi.h"
+
+#include <cstring>
+
+#include "xrl_predict.h"
+
+using namespace xrl;
+
+namespace {
+thread_local std::string g_err;
+thread_local bool g_has_err = false;
+thread_local int g_device = 0;
+
+void set_err(const std::string& s) { g_err = s; g_has_err = true; }
+
+template <class F> void guarded(F&& fn) {
+    g_has_err = false;
+    try { fn(); }
+    catch (const std::exception& e) { set_err(e.what()); }
+    catch (...) { set_err("unknown error"); }
+}
+
+Model* as_model(void* p) {
+    if (!p) fail("null model handle");
+    return static_cast<Model*>(p);
+}
+
+void use_device(int dev) { XRL_HIP(hipSetDevice(dev)); }
+
+void require_gpu() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        fail("libxrl_amd: no HIP device visible -- this library has no CPU fallback");
+}
+
+void upload_csr(const ScipyCsrF32* X, DevBuf& ptr, DevBuf& idx, DevBuf& val, QueriesDev& d) {
+    if (!X) fail("null X");
+    const uint64_t nnz = X->rows ? X->row_ptr[X->rows] : 0;
+    ptr.upload_raw(X->row_ptr, ((size_t)X->rows + 1) * 8);
+    idx.upload_raw(X->col_idx, nnz * 4);
+    val.upload_raw(X->val, nnz * 4);
+    d.row_ptr = ptr.as<uint64_t>(); d.col_idx = idx.as<uint32_t>(); d.val = val.as<float>();
+    d.rows = X->rows; d.cols = X->cols; d.dense = 0; d.nnz = nnz;
+}
+
+void upload_drm(const ScipyDrmF32* X, DevBuf& val, QueriesDev& d) {
+    if (!X) fail("null X");
+    val.upload_raw(X->val, (size_t)X->rows * X->cols * 4);
+    d.row_ptr = nullptr; d.col_idx = nullptr; d.val = val.as<float>();
+    d.rows = X->rows; d.cols = X->cols; d.dense = 1; d.nnz = 0;
+}
+
+// csr_t::create_pycsr, pecos/core/utils/matrix.hpp:300-316: one synchronous allocator call, then copy.
+void emit_csr(uint32_t rows, uint32_t cols, uint32_t stride, const uint32_t* idx, const float* val,
+              const uint32_t* cnt, py_sparse_allocator_t alloc) {
+    uint64_t nnz = 0;
+    for (uint32_t r = 0; r < rows; ++r) nnz += cnt[r];
+    uint32_t* o_idx = nullptr; uint64_t* o_ptr = nullptr; float* o_val = nullptr;
+    alloc(false, rows, cols, nnz, &o_idx, &o_ptr, &o_val);
+    if (!o_ptr || (nnz && (!o_idx || !o_val))) fail("allocator callback returned null buffers");
+    uint64_t w = 0;
+    o_ptr[0] = 0;
+    for (uint32_t r = 0; r < rows; ++r) {
+        std::memcpy(o_idx + w, idx + (size_t)r * stride, (size_t)cnt[r] * 4);
+        std::memcpy(o_val + w, val + (size_t)r * stride, (size_t)cnt[r] * 4);
+        w += cnt[r];
+        o_ptr[r + 1] = w;
+    }
+}
+
+void run_and_emit(Model& m, const QueriesDev& X, const PredictOpts& o, py_sparse_allocator_t alloc) {
+    Workspace& ws = *m.ws;
+    const Layer& last = *m.layers.back();
+    const uint32_t k = effective_topk(m, o.only_topk);
+    const uint32_t out_cols = last.reordered ? last.c_rows : last.w_cols;   // inference.hpp:1776-1784
+    const size_t cells = (size_t)X.rows * k;
+    ws.out_idx.reserve(cells * 4); ws.out_val.reserve(cells * 4); ws.out_cnt.reserve((size_t)X.rows * 4);
+    ws.h_idx.reserve(cells * 4); ws.h_val.reserve(cells * 4); ws.h_cnt.reserve((size_t)X.rows * 4);
+    predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, false);
+    XRL_HIP(hipMemcpyAsync(ws.h_idx.p, ws.out_idx.p, cells * 4, hipMemcpyDeviceToHost, m.stream));
+    XRL_HIP(hipMemcpyAsync(ws.h_val.p, ws.out_val.p, cells * 4, hipMemcpyDeviceToHost, m.stream));
+    XRL_HIP(hipMemcpyAsync(ws.h_cnt.p, ws.out_cnt.p, (size_t)X.rows * 4, hipMemcpyDeviceToHost, m.stream));
+    XRL_HIP(hipStreamSynchronize(m.stream));
+    emit_csr(X.rows, out_cols, k, ws.h_idx.as<uint32_t>(), ws.h_val.as<float>(), ws.h_cnt.as<uint32_t>(), alloc);
+}
+
+template <class XT>
+void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, uint32_t topk,
+                  py_sparse_allocator_t alloc, bool is_csr) {
+    Model& m = *as_model(ptr);
+    if (!alloc) fail("null allocator callback");
+    std::lock_guard<std::mutex> g(m.mu);
+    use_device(m.device);
+    if (!m.ws) m.ws = std::make_unique<Workspace>();
+    QueriesDev X{};
+    if (is_csr) upload_csr(reinterpret_cast<const ScipyCsrF32*>(input_x), m.ws->x_ptr, m.ws->x_idx, m.ws->x_val, X);
+    else upload_drm(reinterpret_cast<const ScipyDrmF32*>(input_x), m.ws->x_val, X);
+    PredictOpts o; o.beam_size = beam; o.only_topk = topk; o.post_processor = pp;
+    run_and_emit(m, X, o, alloc);
+}
+
+HostCsc host_csc(const ScipyCscF32* M, const char* what) {
+    if (!M) fail(std::string("null ") + what);
+    HostCsc h; h.rows = M->rows; h.cols = M->cols;
+    h.col_ptr.assign(M->col_ptr, M->col_ptr + M->cols + 1);
+    const uint64_t nnz = h.col_ptr.back();
+    h.row_idx.assign(M->row_idx, M->row_idx + nnz);
+    h.val.assign(M->val, M->val + nnz);
+    return h;
+}
+
+std::unique_ptr<Model> model_from_arrays(uint32_t depth, const ScipyCscF32* const* W, const ScipyCscF32* const* C,
+                                         const float* bias, const uint32_t* only_topk, const char* const* pp) {
+    auto m = std::make_unique<Model>();
+    m->device = g_device;
+    for (uint32_t d = 0; d < depth; ++d) {
+        HostCsc w = host_csc(W[d], "W");
+        HostCsc c;
+        if (C && C[d]) c = host_csc(C[d], "C");
+        else {
+            c.rows = w.cols; c.cols = 1; c.col_ptr = {0, w.cols};
+            c.row_idx.resize(w.cols); c.val.assign(w.cols, 1.f);
+            for (uint32_t i = 0; i < w.cols; ++i) c.row_idx[i] = i;
+        }
+        m->layers.push_back(compile_layer(w, c, bias[d], only_topk[d], pp[d] ? pp[d] : "noop"));
+    }
+    finalize_model(*m);
+    return m;
+}
+
+template <class XT>
+void single_layer_predict(const XT* input_x, bool is_csr, const ScipyCsrF32* csr_codes, ScipyCscF32* W, ScipyCscF32* C,
+                          const char* pp, uint32_t only_topk, float bias, py_sparse_allocator_t alloc) {
+    // libpecos.cpp:201-235: a temporary one-layer model around caller-owned W / C.
+    require_gpu();
+    use_device(g_device);
+    if (!alloc) fail("null allocator callback");
+    const ScipyCscF32* Wp = W; const ScipyCscF32* Cp = C;
+    const char* pps = pp ? pp : "noop";
+    auto m = model_from_arrays(1, &Wp, &Cp, &bias, &only_topk, &pps);
+    m->ws = std::make_unique<Workspace>();
+    Workspace& ws = *m->ws;
+    QueriesDev X{};
+    if (is_csr) upload_csr(reinterpret_cast<const ScipyCsrF32*>(input_x), ws.x_ptr, ws.x_idx, ws.x_val, X);
+    else upload_drm(reinterpret_cast<const ScipyDrmF32*>(input_x), ws.x_val, X);
+    PredictOpts o; o.only_topk = only_topk; o.post_processor = pps;
+    BeamDev init{};
+    const uint32_t P = m->layers[0]->c_cols;
+    std::vector<uint32_t> hi, hc; std::vector<float> hv;
+    uint32_t stride = 1;
+    const bool with_codes = csr_codes != nullptr;
+    if (with_codes) {
+        if (csr_codes->rows != X.rows) fail("Instance dimension of query and prev_layer_pred matrix do not match");
+        if (csr_codes->cols != P) fail("Label dimension of prev_layer_pred and C matrix do not match");
+        for (uint32_t r = 0; r < X.rows; ++r) stride = std::max<uint32_t>(stride, (uint32_t)(csr_codes->row_ptr[r + 1] - csr_codes->row_ptr[r]));
+        hi.assign((size_t)X.rows * stride, 0); hv.assign((size_t)X.rows * stride, 0.f); hc.assign(X.rows, 0);
+        for (uint32_t r = 0; r < X.rows; ++r) {
+            const uint64_t b = csr_codes->row_ptr[r], e = csr_codes->row_ptr[r + 1];
+            hc[r] = (uint32_t)(e - b);
+            for (uint64_t t = b; t < e; ++t) { hi[(size_t)r * stride + (t - b)] = csr_codes->col_idx[t]; hv[(size_t)r * stride + (t - b)] = csr_codes->val[t]; }
+        }
+    } else if (P > 1) {   // fill_ones(X.rows, C->cols): every parent, score 1, and NO combine
+        stride = P;
+        hi.resize((size_t)X.rows * P); hv.assign((size_t)X.rows * P, 1.f); hc.assign(X.rows, P);
+        for (uint32_t r = 0; r < X.rows; ++r) for (uint32_t p = 0; p < P; ++p) hi[(size_t)r * P + p] = p;
+    }
+    if (!hi.empty()) {
+        ws.init_idx.upload(hi); ws.init_val.upload(hv); ws.init_cnt.upload(hc);
+        init = BeamDev{ws.init_idx.as<uint32_t>(), ws.init_val.as<float>(), ws.init_cnt.as<uint32_t>(), stride};
+        o.initial = &init; o.initial_max = stride;
+    }
+    o.no_prev_pred = !with_codes;   // combine only when csr_codes were given (libpecos.cpp:215-222)
+    run_and_emit(*m, X, o, alloc);
+}
+
+template <class XT, class WT>
+void inner_products(const XT* pX, bool x_csr, const WT* pW, bool w_csc, uint64_t len, uint32_t* rows, uint32_t* cols, float* out) {
+    require_gpu();
+    use_device(g_device);
+    if (!pX || !pW) fail("null matrix");
+    DevBuf xp, xi, xv, wp, wi, wv, dr, dc, dout;
+    const uint64_t *dxp = nullptr, *dwp = nullptr; const uint32_t *dxi = nullptr, *dwi = nullptr;
+    uint32_t dim;
+    if (x_csr) {
+        auto* X = reinterpret_cast<const ScipyCsrF32*>(pX);
+        const uint64_t nnz = X->rows ? X->row_ptr[X->rows] : 0;
+        xp.upload_raw(X->row_ptr, ((size_t)X->rows + 1) * 8); xi.upload_raw(X->col_idx, nnz * 4); xv.upload_raw(X->val, nnz * 4);
+        dxp = xp.as<uint64_t>(); dxi = xi.as<uint32_t>(); dim = X->cols;
+    } else {
+        auto* X = reinterpret_cast<const ScipyDrmF32*>(pX);
+        xv.upload_raw(X->val, (size_t)X->rows * X->cols * 4); dim = X->cols;
+    }
+    if (w_csc) {
+        auto* Wm = reinterpret_cast<const ScipyCscF32*>(pW);
+        const uint64_t nnz = Wm->cols ? Wm->col_ptr[Wm->cols] : 0;
+        wp.upload_raw(Wm->col_ptr, ((size_t)Wm->cols + 1) * 8); wi.upload_raw(Wm->row_idx, nnz * 4); wv.upload_raw(Wm->val, nnz * 4);
+        dwp = wp.as<uint64_t>(); dwi = wi.as<uint32_t>();
+    } else {
+        auto* Wm = reinterpret_cast<const ScipyDcmF32*>(pW);
+        wv.upload_raw(Wm->val, (size_t)Wm->rows * Wm->cols * 4);
+        dim = Wm->rows;
+    }
+    dr.upload_raw(rows, len * 4); dc.upload_raw(cols, len * 4); dout.reserve(len * 4);
+    launch_k3_inner_products(dxp, dxi, xv.as<float>(), x_csr ? 0 : 1, dwp, dwi, wv.as<float>(), w_csc ? 0 : 1, dim, len,
+                             dr.as<uint32_t>(), dc.as<uint32_t>(), dout.as<float>(), nullptr);
+    XRL_HIP(hipDeviceSynchronize());
+    if (len) XRL_HIP(hipMemcpy(out, dout.p, len * 4, hipMemcpyDeviceToHost));
+}
+}  // namespace
+
+extern "C" {
+
+const char* xrl_last_error(void) { return g_has_err ? g_err.c_str() : nullptr; }
+void xrl_clear_error(void) { g_has_err = false; }
+const char* xrl_version(void) { return "xrl_amd 0.1 (gfx950)"; }
+
+int xrl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int xrl_set_device(int device) {
+    int rc = -1;
+    guarded([&] { use_device(device); g_device = device; rc = 0; });
+    return rc;
+}
+
+void* c_xlinear_load_model_from_disk_ext(const char* model_path, int weight_matrix_type) {
+    void* out = nullptr;
+    guarded([&] {
+        if (!model_path) fail("null model path");
+        require_gpu();
+        use_device(g_device);
+        auto m = load_model_from_disk(model_path, weight_matrix_type);
+        m->device = g_device;
+        out = m.release();
+    });
+    return out;
+}
+
+void* c_xlinear_load_model_from_disk(const char* model_path) {
+    return c_xlinear_load_model_from_disk_ext(model_path, 2 /* DEFAULT_LAYER_TYPE = BINARY_SEARCH_CHUNKED */);
+}
+
+void c_xlinear_destruct_model(void* ptr) {
+    guarded([&] {
+        if (!ptr) return;
+        Model* m = static_cast<Model*>(ptr);
+        (void)hipSetDevice(m->device);
+        delete m;
+    });
+}
+
+uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
+    uint32_t v = 0;
+    guarded([&] {
+        Model& m = *as_model(ptr);
+        if (!attr) fail("null attr");
+        if (!std::strcmp(attr, "depth")) v = (uint32_t)m.layers.size();
+        else if (!std::strcmp(attr, "nr_features")) v = m.nr_features;
+        else if (!std::strcmp(attr, "nr_labels")) v = m.nr_labels;
+        else if (!std::strcmp(attr, "nr_codes")) v = m.nr_codes;
+        else fail(std::string(attr) + " is not implemented in get_int_attr.");
+    });
+    return v;
+}
+
+int c_xlinear_get_layer_type(void* ptr, int layer_depth) {
+    int v = -1;
+    guarded([&] {
+        Model& m = *as_model(ptr);
+        if (layer_depth < 0 || (size_t)layer_depth >= m.layers.size()) fail("layer_depth out of range");
+        v = m.weight_matrix_type;
+    });
+    return v;
+}
+
+void c_xlinear_predict_csr_f32(void* ptr, const ScipyCsrF32* input_x, const uint32_t overridden_beam_size,
+                               const char* overridden_post_processor_str, const uint32_t overridden_only_topk,
+                               const int threads, py_sparse_allocator_t pred_alloc) {
+    (void)threads;
+    guarded([&] { predict_host(ptr, input_x, overridden_beam_size, overridden_post_processor_str, overridden_only_topk, pred_alloc, true); });
+}
+
+void c_xlinear_predict_drm_f32(void* ptr, const ScipyDrmF32* input_x, const uint32_t overridden_beam_size,
+                               const char* overridden_post_processor_str, const uint32_t overridden_only_topk,
+                               const int threads, py_sparse_allocator_t pred_alloc) {
+    (void)threads;
+    guarded([&] { predict_host(ptr, input_x, overridden_beam_size, overridden_post_processor_str, overridden_only_topk, pred_alloc, false); });
+}
+
+void c_xlinear_single_layer_predict_csr_f32(const ScipyCsrF32* input_x, const ScipyCsrF32* csr_codes, ScipyCscF32* W,
+                                            ScipyCscF32* C, const char* post_processor_str, const uint32_t only_topk,
+                                            const int num_threads, const float bias, py_sparse_allocator_t pred_alloc) {
+    (void)num_threads;
+    guarded([&] { single_layer_predict(input_x, true, csr_codes, W, C, post_processor_str, only_topk, bias, pred_alloc); });
+}
+
+void c_xlinear_single_layer_predict_drm_f32(const ScipyDrmF32* input_x, const ScipyCsrF32* csr_codes, ScipyCscF32* W,
+                                            ScipyCscF32* C, const char* post_processor_str, const uint32_t only_topk,
+                                            const int num_threads, const float bias, py_sparse_allocator_t pred_alloc) {
+    (void)num_threads;
+    guarded([&] { single_layer_predict(input_x, false, csr_codes, W, C, post_processor_str, only_topk, bias, pred_alloc); });
+}
+
+void c_sparse_inner_products_csr2csc_f32(const ScipyCsrF32* pX, const ScipyCscF32* pW, uint64_t len, uint32_t* r, uint32_t* c, float* val, int threads) {
+    (void)threads; guarded([&] { inner_products(pX, true, pW, true, len, r, c, val); });
+}
+void c_sparse_inner_products_drm2csc_f32(const ScipyDrmF32* pX, const ScipyCscF32* pW, uint64_t len, uint32_t* r, uint32_t* c, float* val, int threads) {
+    (void)threads; guarded([&] { inner_products(pX, false, pW, true, len, r, c, val); });
+}
+void c_sparse_inner_products_csr2dcm_f32(const ScipyCsrF32* pX, const ScipyDcmF32* pW, uint64_t len, uint32_t* r, uint32_t* c, float* val, int threads) {
+    (void)threads; guarded([&] { inner_products(pX, true, pW, false, len, r, c, val); });
+}
+void c_sparse_inner_products_drm2dcm_f32(const ScipyDrmF32* pX, const ScipyDcmF32* pW, uint64_t len, uint32_t* r, uint32_t* c, float* val, int threads) {
+    (void)threads; guarded([&] { inner_products(pX, false, pW, false, len, r, c, val); });
+}
+
+void* xrl_model_create(uint32_t depth, const ScipyCscF32* const* W, const ScipyCscF32* const* C, const float* bias,
+                       const uint32_t* only_topk, const char* const* post_processor) {
+    void* out = nullptr;
+    guarded([&] {
+        require_gpu();
+        use_device(g_device);
+        if (!depth || !W || !bias || !only_topk || !post_processor) fail("xrl_model_create: bad arguments");
+        out = model_from_arrays(depth, W, C, bias, only_topk, post_processor).release();
+    });
+    return out;
+}
+
+void* xrl_queries_upload_csr(void* model, const ScipyCsrF32* X) {
+    void* out = nullptr;
+    guarded([&] {
+        Model& m = *as_model(model);
+        use_device(m.device);
+        auto q = std::make_unique<Queries>();
+        q->device = m.device;
+        upload_csr(X, q->ptr, q->idx, q->val, q->dev);
+        q->nnz = q->dev.nnz;
+        out = q.release();
+    });
+    return out;
+}
+
+void* xrl_queries_upload_drm(void* model, const ScipyDrmF32* X) {
+    void* out = nullptr;
+    guarded([&] {
+        Model& m = *as_model(model);
+        use_device(m.device);
+        auto q = std::make_unique<Queries>();
+        q->device = m.device;
+        upload_drm(X, q->val, q->dev);
+        out = q.release();
+    });
+    return out;
+}
+
+void xrl_queries_free(void* queries) {
+    guarded([&] {
+        if (!queries) return;
+        Queries* q = static_cast<Queries*>(queries);
+        (void)hipSetDevice(q->device);
+        delete q;
+    });
+}
+
+int xrl_predict_device(void* model, void* queries, uint32_t beam_size, const char* post_processor, uint32_t only_topk,
+                       uint32_t* d_out_idx, float* d_out_val, uint32_t* d_out_cnt, uint32_t out_stride,
+                       void* hip_stream, int sync) {
+    int rc = -1;
+    guarded([&] {
+        Model& m = *as_model(model);
+        if (!queries || !d_out_idx || !d_out_val || !d_out_cnt) fail("xrl_predict_device: null argument");
+        std::lock_guard<std::mutex> g(m.mu);
+        use_device(m.device);
+        PredictOpts o; o.beam_size = beam_size; o.only_topk = only_topk; o.post_processor = post_processor;
+        predict_device(m, static_cast<Queries*>(queries)->dev, o, d_out_idx, d_out_val, d_out_cnt, out_stride,
+                       static_cast<hipStream_t>(hip_stream), sync != 0);
+        rc = 0;
+    });
+    return rc;
+}
+
+uint32_t xrl_effective_topk(void* model, uint32_t only_topk) {
+    uint32_t v = 0;
+    guarded([&] { v = effective_topk(*as_model(model), only_topk); });
+    return v;
+}
+
+void xrl_profile_enable(void* model, int enable) { guarded([&] { as_model(model)->profiling = enable != 0; }); }
+void xrl_profile_reset(void* model) { guarded([&] { as_model(model)->profile.clear(); }); }
+uint32_t xrl_profile_get(void* model, xrl_profile_rec_t* out, uint32_t cap) {
+    uint32_t n = 0;
+    guarded([&] {
+        Model& m = *as_model(model);
+        n = (uint32_t)m.profile.size();
+        for (uint32_t i = 0; i < n && i < cap && out; ++i) {
+            std::memset(&out[i], 0, sizeof(out[i]));
+            std::strncpy(out[i].name, m.profile[i].name.c_str(), sizeof(out[i].name) - 1);
+            out[i].layer = m.profile[i].layer; out[i].launches = m.profile[i].launches;
+            out[i].ms = m.profile[i].ms; out[i].alg_bytes = m.profile[i].alg_bytes;
+        }
+    });
+    return n;
+}
+
+int xrl_set_option(void* model, const char* key, int64_t value) {
+    int rc = -1;
+    guarded([&] {
+        Model& m = *as_model(model);
+        if (!key) fail("null key");
+        if (!std::strcmp(key, "k1_group")) m.k1_group = (int)value;
+        else if (!std::strcmp(key, "sort_items")) m.sort_items = (int)value;
+        else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
+        else fail(std::string("unknown option ") + key);
+        rc = 0;
+    });
+    return rc;
+}
+
+uint64_t xrl_model_device_bytes(void* model) {
+    uint64_t v = 0;
+    guarded([&] { v = as_model(model)->device_bytes(); });
+    return v;
+}
+
+}  // extern "C"

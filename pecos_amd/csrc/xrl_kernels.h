@@ -1,0 +1,58 @@
+// Launch interface of the HIP kernels (xrl_kernels.hip).  All pointers are device pointers.
+#pragma once
+#include "xrl_model.h"
+
+namespace xrl {
+
+// Device-resident query matrix (CSR with 32-bit offsets relative to the matrix, or dense row-major).
+struct QueriesDev {
+    const uint64_t* row_ptr;   // [rows+1] (CSR) or nullptr
+    const uint32_t* col_idx;
+    const float* val;          // CSR values, or the dense matrix
+    uint32_t rows, cols;
+    int dense;
+    uint64_t nnz;              // CSR only
+};
+
+// Beam of the previous layer, fixed stride per query; idx == nullptr means the implicit root
+// (one parent, id 0, score 1: HierarchicalMLModel::predict, inference.hpp:2462-2463).
+struct BeamDev {
+    uint32_t* idx;
+    float* val;
+    uint32_t* cnt;
+    uint32_t stride;
+};
+
+struct LayerPlan {
+    uint32_t row0, nrows;       // query rows [row0, row0+nrows) of the query matrix
+    uint32_t beam_in;           // max #parents per query entering the layer
+    uint32_t k;                 // #survivors kept by this layer
+    uint32_t cand_stride;       // floats reserved per query in `cand`
+    PostProc pp;
+    int first_layer;            // no combine (no_prev_pred)
+    int implicit_root;          // previous beam is the implicit all-ones root
+};
+
+// K0  prolongate: per query, offsets of every beam parent's child block + candidate count.
+void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, BeamDev prev, uint32_t* cand_off,
+                          uint32_t* ncand, hipStream_t s);
+// K1  (query, tile) inner products + bias + post-processor + combine, one item per G lanes.
+void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev,
+               const uint32_t* cand_off, float* cand, int group, hipStream_t s);
+// K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.
+void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
+                    const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
+                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s);
+// stats: sum over (query, parent) of the reference chunk's algorithmic bytes, and of candidates
+void launch_stats(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* ncand,
+                  double* out2 /* [0]=chunk bytes, [1]=candidates */, hipStream_t s);
+// K3  sparse_inner_products (pecos/core/utils/matrix.hpp:1049-1060), 4 layout combos
+void launch_k3_inner_products(const uint64_t* x_ptr, const uint32_t* x_idx, const float* x_val, int x_dense,
+                              const uint64_t* w_ptr, const uint32_t* w_idx, const float* w_val, int w_dense,
+                              uint32_t dim, uint64_t len, const uint32_t* rows, const uint32_t* cols,
+                              float* out, hipStream_t s);
+
+int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
+size_t k2_max_k();
+
+}  // namespace xrl

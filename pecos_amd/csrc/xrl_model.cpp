@@ -1,0 +1,281 @@
+// Host-side model compiler: CSC W + C  ->  tiled rank-bitmap layout in HBM (see xrl_model.h).
+//
+// Mirrors the load-time work of the reference without sharing its data structures:
+//   LayerData<chunked>::init                pecos/core/xmc/inference.hpp:1849-1883
+//   check_if_contiguously_ordered           :658-668
+//   rearrangement_t::initialize_from_codes  :1746-1761   (perm / perm_inv)
+//   make_chunked_from_csc                   :557-650     (transpose-by-parent, rows ascending,
+//                                                         columns ascending inside a row)
+//   check_bias_explicit                     :500-502
+#include "xrl_model.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <thread>
+
+namespace xrl {
+
+PostProc parse_post_processor(const char* name_c) {
+    // PostProcessor<T>::get, inference.hpp:192-240.  Unknown names yield the default-constructed
+    // processor there (identity transform, combiner keeps x) -> PP_NOOP here.
+    PostProc pp;
+    if (!name_c) return pp;
+    const std::string name(name_c);
+    auto ends = [&](const char* s) { const size_t n = std::strlen(s); return name.size() >= n && name.compare(name.size() - n, n, s) == 0; };
+    if (name == "noop") return pp;
+    if (name == "sigmoid") { pp.kind = PP_SIGMOID; return pp; }
+    if (name == "log-sigmoid") { pp.kind = PP_LOG_SIGMOID; return pp; }
+    if (name.rfind("log-l", 0) == 0 && ends("-hinge")) {
+        pp.kind = PP_LOG_LP_HINGE;
+        pp.p = std::atoi(name.substr(5, name.size() - 5 - 6).c_str());
+        return pp;
+    }
+    if (name.rfind("l", 0) == 0 && ends("-hinge")) {
+        pp.kind = PP_LP_HINGE;
+        pp.p = std::atoi(name.substr(1, name.size() - 1 - 6).c_str());
+        return pp;
+    }
+    return pp;
+}
+
+uint64_t Layer::cand_bound(uint32_t beam) const {
+    uint64_t s = 0;
+    for (uint32_t i = 0; i < beam && i < chunk_sizes_desc.size(); ++i) s += chunk_sizes_desc[i];
+    return s;
+}
+
+Model::Model() {}
+Model::~Model() {
+    if (stream) (void)hipStreamDestroy(stream);
+}
+uint64_t Model::device_bytes() const {
+    uint64_t b = 0;
+    for (auto& l : layers) b += l->device_bytes;
+    return b;
+}
+
+namespace {
+template <class F> void parallel_for(size_t n, F&& fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 64) nt = 64;
+    if (n < 2 * nt) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex emu;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&] {
+            try {
+                for (;;) {
+                    const size_t i0 = next.fetch_add(16);
+                    if (i0 >= n) break;
+                    for (size_t i = i0; i < std::min(n, i0 + 16); ++i) fn(i);
+                }
+            } catch (...) { std::lock_guard<std::mutex> g(emu); err = std::current_exception(); }
+        });
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+struct Nz { uint32_t row, col; float val; };
+}  // namespace
+
+std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float bias, uint32_t only_topk,
+                                     const std::string& post_processor) {
+    auto L = std::make_unique<Layer>();
+    L->w_rows = W.rows; L->w_cols = W.cols; L->c_rows = C.rows; L->c_cols = C.cols;
+    L->bias = bias; L->only_topk = only_topk; L->pp_name = post_processor;
+    L->pp = parse_post_processor(post_processor.c_str());
+    if (C.rows != W.cols) fail("layer: C.rows (" + std::to_string(C.rows) + ") != W.cols (" + std::to_string(W.cols) + ")");
+    const bool has_bias = bias > 0.0f;
+    const uint64_t c_nnz = C.nnz();
+    if (c_nnz > 0xFFFFFFFFull) fail("layer: too many children");
+    for (uint64_t i = 0; i < c_nnz; ++i) if (C.row_idx[i] >= W.cols) fail("layer: C row index out of range");
+
+    // children must be contiguous by parent; otherwise rearrange (inference.hpp:658-668,1855-1872)
+    bool contiguous = (c_nnz == C.rows);
+    if (contiguous) for (uint64_t i = 0; i < c_nnz; ++i) if (C.row_idx[i] != i) { contiguous = false; break; }
+    L->reordered = !contiguous;
+    L->n_children = (uint32_t)c_nnz;
+    const uint32_t P = C.cols;
+
+    // tiles
+    std::vector<uint32_t> ptile(P + 1, 0), chunk_col(P + 1, 0);
+    std::vector<TileDesc> tiles;
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint32_t cb = (uint32_t)C.col_ptr[p], ce = (uint32_t)C.col_ptr[p + 1];
+        chunk_col[p] = cb;
+        const uint32_t n = ce - cb;
+        L->chunk_sizes_desc.push_back(n);
+        L->max_chunk_cols = std::max(L->max_chunk_cols, n);
+        const uint32_t nt = (n + kMaxTileCols - 1) / kMaxTileCols;
+        for (uint32_t t = 0; t < nt; ++t) {
+            TileDesc td{};
+            const uint32_t b = cb + (uint32_t)((uint64_t)n * t / nt), e = cb + (uint32_t)((uint64_t)n * (t + 1) / nt);
+            td.col_begin = b; td.ncols = e - b; td.bias_slot = kNoBias;
+            L->max_tile_cols = std::max(L->max_tile_cols, td.ncols);
+            tiles.push_back(td);
+        }
+        ptile[p + 1] = (uint32_t)tiles.size();
+        L->max_tiles_per_parent = std::max(L->max_tiles_per_parent, nt);
+    }
+    chunk_col[P] = (uint32_t)c_nnz;
+    std::sort(L->chunk_sizes_desc.begin(), L->chunk_sizes_desc.end(), std::greater<uint32_t>());
+    const uint32_t T = (uint32_t)tiles.size();
+    L->n_tiles = T;
+    L->nwords = (W.rows + 31) / 32;
+
+    auto orig_col = [&](uint32_t c) -> uint32_t { return contiguous ? c : C.row_idx[c]; };
+
+    // entry bases are known from column nnz alone
+    std::vector<uint64_t> tile_nnz(T, 0);
+    for (uint32_t t = 0; t < T; ++t) {
+        uint64_t n = 0;
+        for (uint32_t c = tiles[t].col_begin; c < tiles[t].col_begin + tiles[t].ncols; ++c) {
+            const uint32_t oc = orig_col(c);
+            n += W.col_ptr[oc + 1] - W.col_ptr[oc];
+        }
+        if (n > 0xFFFFFFF0ull) fail("layer: a tile holds more than 2^32 entries");
+        tile_nnz[t] = n;
+    }
+    uint64_t nnz = 0;
+    for (uint32_t t = 0; t < T; ++t) { tiles[t].ent_base = nnz; nnz += tile_nnz[t]; }
+    L->nnz = nnz;
+
+    const uint64_t bm_words = (uint64_t)T * L->nwords;
+    std::vector<Entry> entries(nnz);
+    std::vector<BmWord> bitmap(bm_words, BmWord{0, 0});
+    std::vector<std::vector<uint32_t>> t_rows(T), t_rptr(T);
+
+    parallel_for(T, [&](size_t t) {
+        TileDesc& td = tiles[t];
+        std::vector<Nz> nz;
+        nz.reserve(tile_nnz[t]);
+        for (uint32_t c = td.col_begin; c < td.col_begin + td.ncols; ++c) {
+            const uint32_t oc = orig_col(c);
+            for (uint64_t e = W.col_ptr[oc]; e < W.col_ptr[oc + 1]; ++e) {
+                const uint32_t r = W.row_idx[e];
+                if (r >= W.rows) fail("layer: W row index out of range");
+                nz.push_back(Nz{r, c - td.col_begin, W.val[e]});
+            }
+        }
+        // rows ascending; inside a row the column order (ascending) is kept: stable
+        std::stable_sort(nz.begin(), nz.end(), [](const Nz& a, const Nz& b) { return a.row < b.row; });
+        auto& rows = t_rows[t]; auto& rptr = t_rptr[t];
+        BmWord* bm = bitmap.data() + t * (uint64_t)L->nwords;
+        Entry* ent = entries.data() + td.ent_base;
+        for (size_t i = 0; i < nz.size(); ++i) {
+            if (i == 0 || nz[i].row != nz[i - 1].row) {
+                rows.push_back(nz[i].row);
+                rptr.push_back((uint32_t)i);
+                bm[nz[i].row >> 5].bits |= 1u << (nz[i].row & 31);
+            }
+            ent[i] = Entry{nz[i].col, nz[i].val};
+        }
+        rptr.push_back((uint32_t)nz.size());
+        td.nrows = (uint32_t)rows.size();
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < L->nwords; ++w) { bm[w].rank = run; run += (uint32_t)__builtin_popcount(bm[w].bits); }
+        // check_bias_explicit, inference.hpp:500-502: last row of the chunk is W's last row
+        td.bias_slot = (has_bias && td.nrows > 0 && rows.back() == W.rows - 1) ? td.nrows - 1 : kNoBias;
+    });
+
+    uint64_t total_rows = 0;
+    for (uint32_t t = 0; t < T; ++t) { tiles[t].rowptr_base = total_rows + t; total_rows += tiles[t].nrows; }
+    L->total_rows = total_rows;
+    std::vector<uint32_t> row_ptr(total_rows + T), row_idx(total_rows);
+    parallel_for(T, [&](size_t t) {
+        std::memcpy(row_ptr.data() + tiles[t].rowptr_base, t_rptr[t].data(), t_rptr[t].size() * 4);
+        if (!t_rows[t].empty()) std::memcpy(row_idx.data() + (tiles[t].rowptr_base - t), t_rows[t].data(), t_rows[t].size() * 4);
+    });
+
+    // algorithmic bytes of the REFERENCE chunk layout per parent:
+    // 8*E_p (entries) + 4*R_p (row_idx) + 4*(R_p+1) (row_ptr as u32)
+    std::vector<float> chunk_alg(P, 0.f);
+    for (uint32_t p = 0; p < P; ++p) {
+        uint64_t E = 0, R = 0;
+        const uint32_t t0 = ptile[p], t1 = ptile[p + 1];
+        if (t1 - t0 == 1) { E = tile_nnz[t0]; R = tiles[t0].nrows; }
+        else if (t1 > t0) {
+            std::vector<uint32_t> u;
+            for (uint32_t t = t0; t < t1; ++t) { E += tile_nnz[t]; u.insert(u.end(), t_rows[t].begin(), t_rows[t].end()); }
+            std::sort(u.begin(), u.end());
+            R = std::unique(u.begin(), u.end()) - u.begin();
+        }
+        chunk_alg[p] = (float)(8.0 * E + 4.0 * R + (R ? 4.0 * (R + 1) : 0.0));
+    }
+
+    L->d_tiles.upload(tiles); L->d_ptile.upload(ptile); L->d_chunk_col.upload(chunk_col);
+    L->d_bitmap.upload(bitmap); L->d_row_ptr.upload(row_ptr); L->d_row_idx.upload(row_idx);
+    L->d_entries.upload(entries); L->d_chunk_alg.upload(chunk_alg);
+    if (!contiguous) {
+        std::vector<uint32_t> perm_inv(C.row_idx.begin(), C.row_idx.begin() + c_nnz);
+        L->d_perm_inv.upload(perm_inv);
+    }
+    L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
+                      L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap;
+
+    LayerDev& d = L->dev;
+    d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
+    d.bitmap = L->d_bitmap.as<BmWord>(); d.row_ptr = L->d_row_ptr.as<uint32_t>(); d.row_idx = L->d_row_idx.as<uint32_t>();
+    d.entries = L->d_entries.as<Entry>(); d.perm_inv = contiguous ? nullptr : L->d_perm_inv.as<uint32_t>();
+    d.chunk_alg_bytes = L->d_chunk_alg.as<float>();
+    d.n_parents = P; d.n_children = L->n_children; d.n_tiles = T; d.nwords = L->nwords; d.w_rows = W.rows;
+    d.max_tiles_per_parent = L->max_tiles_per_parent; d.max_tile_cols = L->max_tile_cols;
+    d.bias = bias; d.has_bias = has_bias ? 1 : 0;
+    return L;
+}
+
+void finalize_model(Model& m) {
+    if (m.layers.empty()) fail("model has no layers");
+    const Layer& last = *m.layers.back();
+    // MLModel::{label,code,feature}_count, inference.hpp:2241-2255 (chunked W.cols = #children kept)
+    m.nr_labels = last.reordered ? last.n_children : last.w_cols;
+    m.nr_codes = last.c_cols;
+    m.nr_features = last.bias > 0.0f ? last.w_rows - 1 : last.w_rows;
+    for (size_t l = 1; l < m.layers.size(); ++l) {
+        const uint32_t prev_out = m.layers[l - 1]->reordered ? m.layers[l - 1]->c_rows : m.layers[l - 1]->w_cols;
+        if (m.layers[l]->c_cols != prev_out)
+            fail("layer " + std::to_string(l) + ": C.cols (" + std::to_string(m.layers[l]->c_cols) +
+                 ") does not match the previous layer's label count (" + std::to_string(prev_out) + ")");
+    }
+    if (!m.stream) XRL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+}
+
+std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_matrix_type) {
+    const JsonValue meta = parse_json_file(path + "/param.json");   // HierarchicalMLModelMetadata, inference.hpp:52-99
+    const JsonValue* depth_v = meta.get("depth");
+    if (!depth_v || depth_v->type != JsonValue::NUMBER) fail(path + "/param.json: missing \"depth\"");
+    if (const JsonValue* mm = meta.get("is_mmap"))
+        if (mm->type == JsonValue::BOOL && mm->b) fail("This folder contains mmap model. Cannot load in npz format.");
+    const int depth = (int)depth_v->num;
+    auto m = std::make_unique<Model>();
+    XRL_HIP(hipGetDevice(&m->device));
+    m->weight_matrix_type = weight_matrix_type;
+    for (int d = 0; d < depth; ++d) {
+        const std::string lp = path + "/" + std::to_string(d) + ".model";
+        const JsonValue p = parse_json_file(lp + "/param.json");     // MLModelMetadata, inference.hpp:101-157
+        const JsonValue* bias = p.get("bias");
+        const JsonValue* kw = p.get("pred_kwargs");
+        if (!bias || bias->type != JsonValue::NUMBER || !kw) fail(lp + "/param.json: missing bias / pred_kwargs");
+        const JsonValue* topk = kw->get("only_topk");
+        const JsonValue* pp = kw->get("post_processor");
+        if (!topk || !pp || pp->type != JsonValue::STRING) fail(lp + "/param.json: missing pred_kwargs.only_topk / post_processor");
+        HostCsc W, C;
+        load_csc_npz(lp + "/W.npz", W);
+        if (d == 0 && !file_exists(lp + "/C.npz")) {   // inference.hpp:1580-1583: root without codes
+            C.rows = W.cols; C.cols = 1;
+            C.col_ptr = {0, W.cols};
+            C.row_idx.resize(W.cols); C.val.assign(W.cols, 1.0f);
+            for (uint32_t i = 0; i < W.cols; ++i) C.row_idx[i] = i;
+        } else {
+            load_csc_npz(lp + "/C.npz", C);
+        }
+        m->layers.push_back(compile_layer(W, C, (float)bias->num, (uint32_t)topk->num, pp->str));
+    }
+    finalize_model(*m);
+    return m;
+}
+
+}  // namespace xrl

@@ -1,0 +1,124 @@
+// Device-resident model layout + host-side model compiler interface.
+//
+// The reference keeps, per layer, a "chunked" W: one chunk per parent cluster holding the
+// weights of that parent's children, row-major inside the chunk
+// (pecos/core/xmc/inference.hpp:292-329 bin_search_chunk_view_t, :244-254 chunk_entry_t,
+// built by make_chunked_from_csc :557-650).  The MI355X layout keeps the same unit of work
+// (one (query, parent) pair = one chunk product, arithmetic order untouched) but is laid out for
+// HBM + 64-wide wavefronts instead of a CPU cache:
+//
+//   * a chunk wider than kMaxTileCols children is split into column TILES (each output column's
+//     accumulation order is unaffected by the split);
+//   * the row lookup "is feature f present in this tile, and where" is a rank-bitmap:
+//     one 8-byte {bits, rank} word per 32 features, i.e. ONE load per probe instead of the
+//     reference's ~log2(R) binary-search steps (:786-803).  It costs rows/4 bytes per tile,
+//     which is what 288 GB of HBM3E is for;
+//   * row_ptr is 32-bit and tile-relative; entries stay {u32 col_offset, f32 val} (8 B).
+#pragma once
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "xrl_common.h"
+#include "xrl_io.h"
+
+namespace xrl {
+
+constexpr uint32_t kMaxTileCols = 128;       // accumulators per (query, tile) item held in LDS
+constexpr uint32_t kNoBias = 0xFFFFFFFFu;
+
+enum PPKind : int { PP_NOOP = 0, PP_SIGMOID = 1, PP_LOG_SIGMOID = 2, PP_LP_HINGE = 3, PP_LOG_LP_HINGE = 4 };
+struct PostProc { int kind = PP_NOOP; int p = 0; };
+PostProc parse_post_processor(const char* name);  // inference.hpp:192-240
+
+struct TileDesc {            // 32 bytes, device
+    uint32_t col_begin;      // first child column (rearranged space) covered by the tile
+    uint32_t ncols;
+    uint32_t nrows;          // distinct non-zero rows R_t
+    uint32_t bias_slot;      // row slot holding W's bias row (== rows-1), or kNoBias
+    uint64_t rowptr_base;    // index of this tile's row_ptr[0]; its row_idx[0] is rowptr_base - tile_id
+    uint64_t ent_base;       // index of this tile's first entry
+};
+
+struct Entry { uint32_t col; float val; };          // 8 bytes, == chunk_entry_t
+struct BmWord { uint32_t bits; uint32_t rank; };    // 8 bytes per 32 features
+
+// Plain-pointer view handed to kernels (all device pointers).
+struct LayerDev {
+    const TileDesc* tiles;
+    const uint32_t* ptile;       // [n_parents+1] tiles of parent p = [ptile[p], ptile[p+1])
+    const uint32_t* chunk_col;   // [n_parents+1] child-column range of parent p (rearranged space)
+    const BmWord* bitmap;        // [n_tiles * nwords]
+    const uint32_t* row_ptr;     // [sum(nrows) + n_tiles], tile-relative entry offsets
+    const uint32_t* row_idx;     // [sum(nrows)] feature id of every tile row (dense-query path)
+    const Entry* entries;        // [nnz]
+    const uint32_t* perm_inv;    // [n_children] rearranged -> original child id, or nullptr
+    const float* chunk_alg_bytes;  // [n_parents] algorithmic bytes of the reference chunk (stats)
+    uint32_t n_parents, n_children, n_tiles, nwords, w_rows;
+    uint32_t max_tiles_per_parent, max_tile_cols;
+    float bias;
+    int has_bias;
+};
+
+struct Layer {
+    // host metadata
+    uint32_t w_rows = 0, w_cols = 0, c_rows = 0, c_cols = 0;
+    float bias = 0.f;
+    uint32_t only_topk = 0;
+    PostProc pp;
+    std::string pp_name;
+    bool reordered = false;
+    uint32_t n_children = 0;               // nnz(C)
+    uint32_t n_tiles = 0, nwords = 0, max_tiles_per_parent = 0, max_tile_cols = 0, max_chunk_cols = 0;
+    uint64_t nnz = 0, total_rows = 0;
+    std::vector<uint32_t> chunk_sizes_desc;  // chunk sizes sorted descending (cand stride bound)
+    // device storage
+    DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg;
+    LayerDev dev{};
+    uint64_t device_bytes = 0;
+    // sum of the `beam` largest chunks: upper bound on candidates per query entering this layer
+    uint64_t cand_bound(uint32_t beam) const;
+};
+
+struct ProfileSlot { std::string name; uint32_t layer; uint32_t launches = 0; double ms = 0, alg_bytes = 0; };
+
+// predict scratch, grow-only, owned by the model handle
+struct Workspace {
+    DevBuf beam_idx[2], beam_val[2], beam_cnt[2];
+    DevBuf cand_off, ncand, cand, stats;
+    // host-ABI predict: uploaded X + result staging
+    DevBuf x_ptr, x_idx, x_val;
+    DevBuf out_idx, out_val, out_cnt;
+    PinnedBuf h_idx, h_val, h_cnt;
+    // initial beam for the single-layer API
+    DevBuf init_idx, init_val, init_cnt;
+};
+
+struct Model {
+    int device = 0;
+    int weight_matrix_type = 2;
+    std::vector<std::unique_ptr<Layer>> layers;
+    uint32_t nr_features = 0, nr_labels = 0, nr_codes = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;                          // one predict at a time per handle
+    std::unique_ptr<Workspace> ws;
+    // options
+    int k1_group = 0;                       // 0 = auto
+    int sort_items = -1;                    // -1 = auto
+    int64_t max_batch_rows = 0;             // 0 = auto
+    bool profiling = false;
+    std::vector<ProfileSlot> profile;
+    Model();
+    ~Model();
+    uint64_t device_bytes() const;
+};
+
+// Build one layer from host CSC W / C (LayerData<chunked>::init, inference.hpp:1849-1883).
+std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float bias, uint32_t only_topk,
+                                     const std::string& post_processor);
+// Load <path>/param.json + {d}.model/ (HierarchicalMLModel::load, inference.hpp:2616-2655).
+std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_matrix_type);
+void finalize_model(Model& m);
+
+}  // namespace xrl

@@ -1,0 +1,160 @@
+// Host orchestrator: per-layer K0 -> K1 -> K2 launches on one HIP stream, ping-pong beam
+// buffers, no host synchronisation inside the layer loop (grid sizes depend only on shapes).
+//
+// Reference driver being restated: HierarchicalMLModel::predict (inference.hpp:2446-2488) calling
+// MLModel::predict_internal (:2029-2080) per layer.
+#include "xrl_predict.h"
+
+#include <algorithm>
+
+namespace xrl {
+
+namespace {
+struct EventPair { hipEvent_t a, b; size_t slot; };
+
+size_t profile_slot(Model& m, const char* name, uint32_t layer) {
+    for (size_t i = 0; i < m.profile.size(); ++i)
+        if (m.profile[i].layer == layer && m.profile[i].name == name) return i;
+    m.profile.push_back(ProfileSlot{name, layer});
+    return m.profile.size() - 1;
+}
+}  // namespace
+
+uint32_t effective_topk(const Model& m, uint32_t only_topk) {
+    return only_topk ? only_topk : m.layers.back()->only_topk;   // inference.hpp:2055
+}
+
+void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_t* d_out_idx, float* d_out_val,
+                    uint32_t* d_out_cnt, uint32_t out_stride, hipStream_t stream, bool sync) {
+    const size_t T = m.layers.size();
+    if (!m.ws) m.ws = std::make_unique<Workspace>();
+    Workspace& ws = *m.ws;
+    if (!stream) stream = m.stream;
+
+    // MLModel::predict_internal's shape checks live in Python for the reference
+    // (xmc/base.py:1603-1607); here a mismatch is a loud error instead of UB.
+    if (!X.dense && X.cols != m.nr_features && X.cols != m.layers[0]->w_rows)
+        fail("X.shape[1] (" + std::to_string(X.cols) + ") != nr_features (" + std::to_string(m.nr_features) + ")");
+    if (X.dense && X.cols < m.nr_features)
+        fail("dense X has fewer columns (" + std::to_string(X.cols) + ") than nr_features (" + std::to_string(m.nr_features) + ")");
+
+    // ---- resolve per-layer k / post-processor (inference.hpp:2471, 2055-2058)
+    std::vector<uint32_t> k(T), beam_in(T), cstride(T);
+    std::vector<PostProc> pp(T);
+    const bool has_init = o.initial != nullptr;
+    for (size_t l = 0; l < T; ++l) {
+        const Layer& L = *m.layers[l];
+        const uint32_t ov = (l == T - 1) ? o.only_topk : o.beam_size;
+        k[l] = ov ? ov : L.only_topk;
+        if (k[l] == 0) fail("layer " + std::to_string(l) + ": only_topk resolved to 0");
+        pp[l] = o.post_processor ? parse_post_processor(o.post_processor) : L.pp;
+        uint64_t bin = (l == 0) ? (has_init ? std::max<uint32_t>(1, o.initial_max) : 1)
+                                : std::min<uint64_t>(k[l - 1], cstride[l - 1]);
+        bin = std::min<uint64_t>(bin, L.c_cols ? L.c_cols : 1);
+        beam_in[l] = (uint32_t)std::max<uint64_t>(1, bin);
+        const uint64_t cb = std::max<uint64_t>(1, L.cand_bound(beam_in[l]));
+        if (cb > 0x7FFFFFFFull) fail("candidate row too long; lower beam_size");
+        cstride[l] = (uint32_t)cb;
+    }
+    const uint32_t k_last = k[T - 1];
+    if (k_last > out_stride) fail("out_stride smaller than the effective only_topk");
+    uint32_t beam_stride = 1;
+    for (size_t l = 0; l + 1 < T; ++l) beam_stride = std::max(beam_stride, k[l]);
+    uint32_t bin_max = 1, cs_max = 1;
+    for (size_t l = 0; l < T; ++l) { bin_max = std::max(bin_max, beam_in[l]); cs_max = std::max(cs_max, cstride[l]); }
+
+    // ---- batch rows so that the candidate buffer stays bounded (default 6 GiB of 288)
+    const uint64_t cand_budget = 6ull << 30;
+    uint64_t nb = std::max<uint64_t>(1, cand_budget / ((uint64_t)cs_max * 4));
+    nb = std::min<uint64_t>(nb, 1u << 22);
+    if (m.max_batch_rows > 0) nb = std::min<uint64_t>(nb, (uint64_t)m.max_batch_rows);
+    nb = std::min<uint64_t>(nb, std::max<uint32_t>(1, X.rows));
+
+    for (int i = 0; i < 2; ++i) {
+        ws.beam_idx[i].reserve(nb * beam_stride * 4);
+        ws.beam_val[i].reserve(nb * beam_stride * 4);
+        ws.beam_cnt[i].reserve(nb * 4);
+    }
+    ws.cand_off.reserve(nb * bin_max * 4);
+    ws.ncand.reserve(nb * 4);
+    ws.cand.reserve(nb * (uint64_t)cs_max * 4);
+    if (m.profiling) {
+        ws.stats.reserve(T * 2 * sizeof(double));
+        XRL_HIP(hipMemsetAsync(ws.stats.p, 0, T * 2 * sizeof(double), stream));
+    }
+
+    std::vector<EventPair> events;
+    auto timed = [&](const char* name, uint32_t layer, auto&& fn) {
+        if (!m.profiling) { fn(); return; }
+        EventPair ev; ev.slot = profile_slot(m, name, layer);
+        XRL_HIP(hipEventCreate(&ev.a)); XRL_HIP(hipEventCreate(&ev.b));
+        XRL_HIP(hipEventRecord(ev.a, stream));
+        fn();
+        XRL_HIP(hipEventRecord(ev.b, stream));
+        events.push_back(ev);
+    };
+
+    for (uint64_t row0 = 0; row0 < X.rows; row0 += nb) {
+        const uint32_t nrows = (uint32_t)std::min<uint64_t>(nb, X.rows - row0);
+        for (size_t l = 0; l < T; ++l) {
+            const Layer& L = *m.layers[l];
+            LayerPlan P{};
+            P.row0 = (uint32_t)row0; P.nrows = nrows; P.beam_in = beam_in[l]; P.k = k[l];
+            P.cand_stride = cstride[l]; P.pp = pp[l];
+            P.first_layer = (l == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;   // no_prev_pred
+            P.implicit_root = (l == 0 && !has_init) ? 1 : 0;
+            BeamDev prev{};
+            if (l == 0 && has_init) {
+                prev = *o.initial;
+                prev.idx += row0 * prev.stride; prev.val += row0 * prev.stride; prev.cnt += row0;
+            } else if (l > 0) {
+                const int b = (int)((l - 1) & 1);
+                prev = BeamDev{ws.beam_idx[b].as<uint32_t>(), ws.beam_val[b].as<float>(), ws.beam_cnt[b].as<uint32_t>(), beam_stride};
+            }
+            uint32_t *oi, *oc; float* ov; uint32_t os;
+            if (l == T - 1) { oi = d_out_idx + row0 * out_stride; ov = d_out_val + row0 * out_stride; oc = d_out_cnt + row0; os = out_stride; }
+            else { const int b = (int)(l & 1); oi = ws.beam_idx[b].as<uint32_t>(); ov = ws.beam_val[b].as<float>(); oc = ws.beam_cnt[b].as<uint32_t>(); os = beam_stride; }
+
+            int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
+            timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), stream); });
+            timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] { launch_k1(L.dev, P, X, prev, ws.cand_off.as<uint32_t>(), ws.cand.as<float>(), g, stream); });
+            timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.cand.as<float>(), oi, ov, oc, os, stream); });
+            if (m.profiling) launch_stats(L.dev, P, prev, ws.ncand.as<uint32_t>(), ws.stats.as<double>() + 2 * l, stream);
+        }
+    }
+
+    if (m.profiling) {
+        XRL_HIP(hipStreamSynchronize(stream));
+        std::vector<double> st(T * 2);
+        XRL_HIP(hipMemcpy(st.data(), ws.stats.p, T * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<char> seen(m.profile.size(), 0);
+        for (auto& ev : events) {
+            float ms = 0.f;
+            XRL_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+            ProfileSlot& ps = m.profile[ev.slot];
+            ps.ms += ms; ps.launches += 1;
+            if (!seen[ev.slot]) {
+                // algorithmic bytes attributed per kernel family:
+                //   k1: every active reference chunk streamed once + x row read once (layer 0) + 4 B/score written
+                //   k2: 4 B/score read + 8 B per survivor written;  k0: 8 B per beam entry
+                seen[ev.slot] = 1;
+                const uint32_t l = ps.layer;
+                const double chunk_b = st[2 * l], n_eval = st[2 * l + 1];
+                if (ps.name == "k1_sparse" || ps.name == "k1_dense") {
+                    double xb = 0;
+                    if (l == 0) xb = X.dense ? 4.0 * X.rows * (double)X.cols : 8.0 * (double)X.nnz;
+                    ps.alg_bytes += chunk_b + 4.0 * n_eval + xb;
+                } else if (ps.name == "k2_topk") {
+                    ps.alg_bytes += 4.0 * n_eval + 8.0 * (double)X.rows * k[l];
+                } else {
+                    ps.alg_bytes += 8.0 * (double)X.rows * beam_in[l];
+                }
+            }
+            (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
+        }
+    } else if (sync) {
+        XRL_HIP(hipStreamSynchronize(stream));
+    }
+}
+
+}  // namespace xrl

@@ -1,0 +1,31 @@
+// Host orchestrator of the beam search (HierarchicalMLModel::predict, inference.hpp:2446-2488).
+#pragma once
+#include "xrl_kernels.h"
+#include "xrl_model.h"
+
+namespace xrl {
+
+
+struct Queries {
+    int device = 0;
+    DevBuf ptr, idx, val;
+    QueriesDev dev{};
+    uint64_t nnz = 0;
+};
+
+struct PredictOpts {
+    uint32_t beam_size = 0;          // 0 = per-layer param.json value
+    uint32_t only_topk = 0;          // 0 = last layer's param.json value
+    const char* post_processor = nullptr;
+    const BeamDev* initial = nullptr;  // non-null: explicit previous-layer predictions (csr_codes)
+    uint32_t initial_max = 0;          // max entries per row in `initial`
+    bool no_prev_pred = false;         // explicit initial beam but no combine (fill_ones case, libpecos.cpp:219-222)
+};
+
+uint32_t effective_topk(const Model& m, uint32_t only_topk);
+
+// Enqueue the whole beam search on `stream`; results land in fixed-stride device buffers.
+void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_t* d_out_idx, float* d_out_val,
+                    uint32_t* d_out_cnt, uint32_t out_stride, hipStream_t stream, bool sync);
+
+}  // namespace xrl
