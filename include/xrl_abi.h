@@ -132,6 +132,11 @@ const char* xrl_version(void);
 int xrl_device_count(void);            /* hipGetDeviceCount; 0 when no GPU is visible */
 int xrl_set_device(int device);        /* device used by subsequent loads on this thread; 0 = ok */
 
+/* Host-only: parse a model folder exactly like the loader does (param.json + uncompressed npz),
+ * WITHOUT touching a GPU.  Writes per layer {W.rows, W.cols, nnz(W), C.rows, C.cols, nnz(C)} into
+ * out[6*layer ...] (up to cap values) and returns the depth, or -1 on error (see xrl_last_error). */
+int xrl_inspect_model(const char* model_path, uint64_t* out, uint32_t cap);
+
 /* Build a model from in-memory CSC layers (same semantics as loading the folder). */
 void* xrl_model_create(uint32_t depth, const ScipyCscF32* const* W, const ScipyCscF32* const* C,
                        const float* bias, const uint32_t* only_topk,
@@ -154,18 +159,26 @@ int xrl_predict_device(void* model, void* queries, uint32_t beam_size, const cha
 /* Effective only_topk of the last layer for the given override (0 = model default). */
 uint32_t xrl_effective_topk(void* model, uint32_t only_topk);
 
-/* Profiling: when enabled, every kernel launch of predict is bracketed by hipEvents on its stream.
- * xrl_profile_get fills up to `cap` records; returns the number available. */
+/* Profiling: when enabled, every kernel launch of predict is bracketed by a hipEvent pair recorded
+ * on the stream the kernel is launched on (no synchronisation is added to the predict call).
+ * xrl_profile_get synchronises, folds the pending pairs and fills up to `cap` records; it returns
+ * the number of records available. */
 typedef struct {
-    char name[32];          /* kernel family: "k0_prolongate", "k1_sparse", "k1_dense", "k2_topk", ... */
+    char name[32];          /* kernel family: "k0_prolongate", "k1_sparse", "k1_dense", "k2_topk" */
     uint32_t layer;
     uint32_t launches;
     double ms;              /* accumulated GPU time of those launches */
-    double alg_bytes;       /* accumulated ALGORITHMIC bytes those launches processed */
+    double reserved;
 } xrl_profile_rec_t;
 void xrl_profile_enable(void* model, int enable);
 void xrl_profile_reset(void* model);
 uint32_t xrl_profile_get(void* model, xrl_profile_rec_t* out, uint32_t cap);
+
+/* One untimed predict that also measures, per layer l, stats_out[2l] = algorithmic bytes of the
+ * reference-layout chunks streamed (8*E_p + 4*R_p + 4*(R_p+1) per (query, beam parent), SURVEY.md
+ * section 8d) and stats_out[2l+1] = candidates evaluated.  stats_cap >= 2*depth.  Returns 0 on success. */
+int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char* post_processor,
+                      uint32_t only_topk, double* stats_out, uint32_t stats_cap);
 
 /* Tuning knobs (benchmark / tests only): key in {"k1_group", "sort_items", "max_batch_rows"} */
 int xrl_set_option(void* model, const char* key, int64_t value);

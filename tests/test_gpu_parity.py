@@ -1,0 +1,227 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against
+ (1) the committed golden fixtures made by the real reference (tests/golden/),
+ (2) the CPU oracle (and oracle/_ref when present) on seeded synthetic models,
+ (3) size-independent properties at BASELINE.json's full sizes.
+Bar (BASELINE.json): label indices and their order bit-exact; scores within 1e-5 relative fp32
+(bit-exact for noop / l{p}-hinge / log-l{p}-hinge; sigmoid variants differ from glibc's expf in
+the last ulp)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as smat
+
+from conftest import GOLDEN, assert_same_topk, load_raw_csr, load_X
+
+pytestmark = pytest.mark.gpu
+
+EXACT_PP = lambda pp: pp is None or "sigmoid" not in pp
+
+
+@pytest.fixture(scope="module")
+def clib():
+    from pecos_amd import clib
+    assert clib.device_count() > 0, "no GPU visible"
+    return clib
+
+
+@pytest.fixture(scope="module")
+def XLM():
+    from pecos_amd import XLinearModel
+    return XLinearModel
+
+
+def test_reference_cli_goldens(manifest, XLM):
+    # test/pecos/xmc/xlinear/test_xlinear.py:314-640 (abs=1e-6 like the reference's own assertion)
+    Xt = load_X(os.path.join(GOLDEN, "ref_fixtures", "Xt.npz"))
+    for c in manifest["cli"]:
+        m = XLM.load(os.path.join(GOLDEN, "models", c["model"]))
+        P = m.predict(Xt, **c["kwargs"])
+        G = smat.load_npz(os.path.join(GOLDEN, "ref_fixtures", c["golden"]))
+        assert np.allclose(P.toarray(), G.toarray(), atol=1e-6), c
+
+
+def test_reference_toy_matrix(manifest, XLM):
+    # test_xlinear.py:106-245: 3 trained models x 11 post-processors x {batch, realtime} x {sparse, dense}
+    models = {}
+    for c in manifest["toy"]:
+        if c["model"] not in models:
+            models[c["model"]] = XLM.load(os.path.join(GOLDEN, "models", c["model"]))
+        m = models[c["model"]]
+        X = load_X(os.path.join(GOLDEN, "ref_fixtures", "Xt.npz"), c["x"])
+        G = smat.load_npz(os.path.join(GOLDEN, "preds", c["pred"])).toarray()
+        kw = dict(beam_size=c["beam_size"], post_processor=c["post_processor"])
+        assert np.allclose(m.predict(X, **kw).toarray(), G, atol=1e-6), c
+        for i in range(X.shape[0]):  # realtime mode
+            q = X[[i], :] if c["x"] == "sparse" else np.ascontiguousarray(X[[i], :])
+            if c["x"] == "sparse":
+                q.sort_indices()
+            assert np.allclose(m.predict(q, **kw).toarray(), G[[i]], atol=1e-6), (c, i)
+
+
+def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
+    # reference outputs on seeded synthetic models: contiguous / permuted / pruned leaves, no-bias,
+    # deep tree, flat (one 300-column chunk -> column tiles), wide chunks, empty query row,
+    # beams up to 70 and only_topk up to 100 (LDS top-k path), every lanes-per-item variant
+    models = {}
+    for c in manifest["synth"]:
+        if c["model"] not in models:
+            models[c["model"]] = XLM.load(os.path.join(GOLDEN, "synth", c["model"]))
+        m = models[c["model"]]
+        X = load_X(os.path.join(GOLDEN, "synth", c["model"] + "__X.npz"), c["x"])
+        G = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"]))
+        for g in (0, 1, 2, 8, 64):
+            clib.set_option(m.model.model_chain, "k1_group", g)
+            P = m.predict(X, **c["kwargs"])
+            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} G={g}")
+        clib.set_option(m.model.model_chain, "k1_group", 0)
+
+
+@pytest.mark.parametrize("name,scale", [("eurlex-4k", 0.5), ("wiki10-31k", 0.1), ("amazon-670k", 0.02)])
+def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
+    import xrl_synth
+    folder = str(tmp_path / "m")
+    ks, X, cfg = xrl_synth.make_config(name, folder, scale=scale)
+    X = X[:400]
+    m = XLM.load(folder)
+    ref = oracle_mod.RefModel(folder) if oracle_mod.ref_available() else oracle_mod.OracleModel.load(folder)
+    for pp in (None, "log-l1-hinge", "sigmoid"):
+        kw = dict(beam_size=cfg["beam"], only_topk=10)
+        if pp:
+            kw["post_processor"] = pp
+        assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} {pp}")
+    # model defaults (no overrides), max_pred_chunk slicing, dense queries
+    assert_same_topk(m.predict(X), ref.predict(X), exact_scores=True, what="defaults")
+    assert_same_topk(m.predict(X, beam_size=5, only_topk=3, max_pred_chunk=37), ref.predict(X, beam_size=5, only_topk=3),
+                     exact_scores=True, what="max_pred_chunk")
+    if X.shape[1] <= 6000:
+        Xd = np.ascontiguousarray(X[:64].toarray())
+        assert_same_topk(m.predict(Xd, beam_size=4, only_topk=6), ref.predict(Xd, beam_size=4, only_topk=6),
+                         exact_scores=True, what="dense")
+
+
+def test_edge_cases(XLM, clib, oracle_mod, tmp_path):
+    import xrl_synth
+    folder = str(tmp_path / "m")
+    xrl_synth.make_model(folder, 300, 400, [80, 50, 15], seed=11, shape=[3, 20, 400])
+    m = XLM.load(folder)
+    om = oracle_mod.OracleModel.load(folder)
+    X = xrl_synth.make_queries(33, 300, 20, seed=12, relabel_seed=11)
+    # all-empty matrix, zero rows, k larger than the number of labels, beam larger than any layer
+    E = smat.csr_matrix((5, 300), dtype=np.float32)
+    assert_same_topk(m.predict(E, beam_size=2, only_topk=4), om.predict(E, beam_size=2, only_topk=4), exact_scores=True, what="empty rows")
+    Z = smat.csr_matrix((0, 300), dtype=np.float32)
+    assert m.predict(Z).shape == (0, 400)
+    assert_same_topk(m.predict(X, beam_size=1000, only_topk=1000), om.predict(X, beam_size=1000, only_topk=1000), exact_scores=True, what="k > L")
+    assert_same_topk(m.predict(X, beam_size=1, only_topk=1), om.predict(X, beam_size=1, only_topk=1), exact_scores=True, what="k = 1")
+    # explicit zeros stored in X still "match" (adds 0*w) and unsorted input is rejected like the reference
+    Xz = X.copy(); Xz.data[::7] = 0.0
+    assert_same_topk(m.predict(Xz, beam_size=3, only_topk=5), om.predict(Xz, beam_size=3, only_topk=5), exact_scores=True, what="explicit zeros")
+    Xu = X.copy(); Xu.indices[:2] = Xu.indices[:2][::-1].copy(); Xu.has_sorted_indices = False
+    with pytest.raises(ValueError, match="sorted"):
+        m.predict(Xu)
+    with pytest.raises(AssertionError):
+        m.predict(X.astype(np.float64))
+    with pytest.raises(AssertionError):
+        m.predict(smat.csr_matrix((3, 299), dtype=np.float32))
+    # all scores tie (zero weights): order must follow candidate position, not label id
+    folder2 = str(tmp_path / "ties")
+    xrl_synth.make_model(folder2, 50, 120, [10, 5], seed=13, shape=[6, 120])
+    for d in range(2):
+        p = os.path.join(folder2, "ranker", f"{d}.model", "W.npz")
+        W = smat.load_npz(p); W.data[:] = 0.0; smat.save_npz(p, W, compressed=False)
+    m2 = XLM.load(folder2); o2 = oracle_mod.OracleModel.load(folder2)
+    Xq = xrl_synth.make_queries(9, 50, 6, seed=14, relabel_seed=13)
+    assert_same_topk(m2.predict(Xq, beam_size=3, only_topk=7), o2.predict(Xq, beam_size=3, only_topk=7), exact_scores=True, what="ties")
+
+
+def test_attributes_and_errors(XLM, clib, tmp_path):
+    m = XLM.load(os.path.join(GOLDEN, "synth", "s_pruned"))
+    info = clib.inspect_model(os.path.join(GOLDEN, "synth", "s_pruned", "ranker"))
+    assert m.depth == 3 and m.nr_features == 300
+    assert m.nr_labels == info[-1]["c_nnz"] and m.nr_pred_cols == info[-1]["c_rows"]   # pruned: fewer kept children
+    assert m.nr_codes == info[-1]["c_cols"]
+    assert clib.xlinear_get_layer_type(m.model.model_chain, 0) == 2
+    with pytest.raises(RuntimeError):
+        XLM.load(str(tmp_path))            # no param.json
+    with pytest.raises(NotImplementedError):
+        XLM.load(os.path.join(GOLDEN, "synth", "s_pruned"), is_predict_only=False)
+    with pytest.raises(NotImplementedError):   # non-uniform per-layer override is not expressible natively
+        pp = m.get_pred_params(); pp.hlm_args.model_chain[0].only_topk = 3; pp.hlm_args.model_chain[1].only_topk = 4
+        m.predict(smat.csr_matrix((1, 300), dtype=np.float32), pred_params=pp)
+
+
+def test_sparse_inner_products(clib, oracle_mod):
+    # KAT of test/pecos/core/test_clib.py:39-69 + random pairs vs the oracle, 4 layout combos
+    X = smat.csr_matrix([[1.0, 0.0], [0.5, 0.5], [0.0, 1.0]], dtype=np.float32)
+    Y = smat.csr_matrix([[0.5, 0.0], [0.0, 1.0], [1.0, 0.0], [0.0, 0.5]], dtype=np.float32)
+    gt = np.array([[0.50, 0.00, 1.00, 0.00], [0.25, 0.50, 0.50, 0.25], [0.00, 1.00, 0.00, 0.50]], dtype=np.float32)
+    r = np.array([0, 1, 2], dtype=np.uint32); c = np.array([1, 2, 3], dtype=np.uint32)
+    true = np.array([gt[i, j] for i, j in zip(r, c)], dtype=np.float32)
+    W = Y.T.tocsc()
+    assert np.allclose(clib.sparse_inner_products(X, W, r, c), true, atol=1e-9)
+    assert np.allclose(clib.sparse_inner_products(X.toarray(), np.asfortranarray(Y.toarray().T), r, c), true, atol=1e-9)
+    rng = np.random.default_rng(5)
+    A = smat.random(200, 500, density=0.05, format="csr", dtype=np.float32, random_state=6); A.sort_indices()
+    B = smat.random(500, 300, density=0.08, format="csc", dtype=np.float32, random_state=7); B.sort_indices()
+    rr = rng.integers(0, 200, 5000).astype(np.uint32); cc = rng.integers(0, 300, 5000).astype(np.uint32)
+    for Aq, Bq in [(A, B), (np.ascontiguousarray(A.toarray()), B), (A, np.asfortranarray(B.toarray())),
+                   (np.ascontiguousarray(A.toarray()), np.asfortranarray(B.toarray()))]:
+        got = clib.sparse_inner_products(Aq, Bq, rr, cc)
+        exp = oracle_mod.sparse_inner_products(Aq, Bq, rr, cc)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
+def test_single_layer_predict(clib, oracle_mod):
+    # c_xlinear_single_layer_predict (libpecos.cpp:201-235) == one oracle layer, with and without csr_codes
+    from pecos_amd.core import ScipyCompressedSparseAllocator
+    folder = os.path.join(GOLDEN, "synth", "s_eurlex")
+    layers = oracle_mod.load_model_folder(folder)
+    X = load_X(os.path.join(GOLDEN, "synth", "s_eurlex__X.npz"))
+    om_top = oracle_mod.OracleModel(layers[:1]); om2 = oracle_mod.OracleModel(layers[:2])
+    L0, L1 = layers[0], layers[1]
+    alloc = ScipyCompressedSparseAllocator()
+    clib.xlinear_single_layer_predict(X, None, L0["W"], L0["C"], "l3-hinge", 3, -1, L0["bias"], alloc)
+    P0 = alloc.get()
+    assert_same_topk(P0, om_top.predict(X, only_topk=3), exact_scores=True, what="layer 0")
+    codes = smat.csr_matrix(P0, dtype=np.float32)
+    alloc = ScipyCompressedSparseAllocator()
+    clib.xlinear_single_layer_predict(X, codes, L1["W"], L1["C"], "l3-hinge", 6, -1, L1["bias"], alloc)
+    assert_same_topk(alloc.get(), om2.predict(X, beam_size=3, only_topk=6), exact_scores=True, what="layer 1 with codes")
+
+
+def test_full_size_properties(XLM, clib, tmp_path):
+    # BASELINE.json configs[1] (Eurlex-4K shape) at FULL size through size-independent properties
+    import xrl_synth
+    folder = str(tmp_path / "m")
+    ks, X, cfg = xrl_synth.make_config("eurlex-4k", folder)
+    m = XLM.load(folder)
+    P = m.predict(X, beam_size=10, only_topk=10)
+    assert P.shape == (X.shape[0], ks[-1])
+    cnt = np.diff(P.indptr)
+    assert np.all(cnt == 10)                                                  # L >> k: every row is full
+    D = P.data.reshape(-1, 10)
+    assert np.all(D[:, :-1] >= D[:, 1:])                                      # rows score-sorted, descending
+    I = P.indices.reshape(-1, 10)
+    assert np.all(np.sort(I, axis=1)[:, 1:] != np.sort(I, axis=1)[:, :-1])    # no duplicate label in a row
+    assert np.all((D > 0) & (D <= 1))                                         # l3-hinge products live in (0, 1]
+    # idempotence + batch-composition independence (rows are independent): permuted / chunked batches
+    perm = np.random.default_rng(0).permutation(X.shape[0])
+    Pp = m.predict(X[perm], beam_size=10, only_topk=10)
+    assert np.array_equal(Pp.indices.reshape(-1, 10), I[perm]) and np.array_equal(Pp.data.reshape(-1, 10), D[perm])
+    Pc = m.predict(X, beam_size=10, only_topk=10, max_pred_chunk=4099)
+    assert np.array_equal(Pc.indices, P.indices) and np.array_equal(Pc.data, P.data)
+    # top-k prefix property: only_topk=5 is the prefix of only_topk=10 at equal beam
+    P5 = m.predict(X, beam_size=10, only_topk=5)
+    assert np.array_equal(P5.indices.reshape(-1, 5), I[:, :5]) and np.array_equal(P5.data.reshape(-1, 5), D[:, :5])
+    # every lanes-per-item variant gives the same bits
+    for g in (1, 4, 16, 64):
+        clib.set_option(m.model.model_chain, "k1_group", g)
+        Pg = m.predict(X, beam_size=10, only_topk=10)
+        assert np.array_equal(Pg.indices, P.indices) and np.array_equal(Pg.data.view(np.uint32), P.data.view(np.uint32))
+    # device-resident path == host-ABI path; batching of rows does not change results
+    clib.set_option(m.model.model_chain, "k1_group", 0)
+    clib.set_option(m.model.model_chain, "max_batch_rows", 1777)
+    Pb = m.predict(X, beam_size=10, only_topk=10)
+    clib.set_option(m.model.model_chain, "max_batch_rows", 0)
+    assert np.array_equal(Pb.indices, P.indices) and np.array_equal(Pb.data, P.data)

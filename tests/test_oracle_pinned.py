@@ -1,0 +1,72 @@
+"""CPU: pin the oracle (oracle/xrl_oracle.c) against the reference's golden vectors and against
+outputs the real reference produced in this container (tests/golden/, made by make_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as smat
+
+from conftest import GOLDEN, assert_same_topk, load_raw_csr, load_X
+
+
+def test_oracle_vs_reference_cli_goldens(manifest, oracle_mod):
+    # test/pecos/xmc/xlinear/test_xlinear.py:314-640 golden prediction files, abs=1e-6 like the reference
+    Xt = load_X(os.path.join(GOLDEN, "ref_fixtures", "Xt.npz"))
+    for c in manifest["cli"]:
+        m = oracle_mod.OracleModel.load(os.path.join(GOLDEN, "models", c["model"]))
+        kw = {k: v for k, v in c["kwargs"].items() if k != "max_pred_chunk"}
+        P = m.predict(Xt, **kw)
+        G = smat.load_npz(os.path.join(GOLDEN, "ref_fixtures", c["golden"]))
+        assert np.allclose(P.toarray(), G.toarray(), atol=1e-6), c
+
+
+def test_oracle_vs_reference_toy_matrix(manifest, oracle_mod):
+    # every post-processor x {sparse, dense} x 3 trained toy models (test_xlinear.py:106-245)
+    models = {}
+    for c in manifest["toy"]:
+        if c["model"] not in models:
+            models[c["model"]] = oracle_mod.OracleModel.load(os.path.join(GOLDEN, "models", c["model"]))
+        X = load_X(os.path.join(GOLDEN, "ref_fixtures", "Xt.npz"), c["x"])
+        P = models[c["model"]].predict(X, beam_size=c["beam_size"], post_processor=c["post_processor"])
+        G = smat.load_npz(os.path.join(GOLDEN, "preds", c["pred"]))
+        assert np.allclose(P.toarray(), G.toarray(), atol=1e-6), c
+
+
+def test_oracle_bit_exact_vs_reference_on_synthetic(manifest, oracle_mod):
+    # seeded synthetic models: label sequence identical, fp32 scores BIT-identical to the compiled reference
+    models = {}
+    for c in manifest["synth"]:
+        if c["model"] not in models:
+            models[c["model"]] = oracle_mod.OracleModel.load(os.path.join(GOLDEN, "synth", c["model"]))
+        X = load_X(os.path.join(GOLDEN, "synth", c["model"] + "__X.npz"), c["x"])
+        P = models[c["model"]].predict(X, **c["kwargs"])
+        G = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"]))
+        assert_same_topk(P, G, exact_scores=True, what=str(c))
+
+
+def test_oracle_vs_live_reference_if_present(oracle_mod, tmp_path):
+    # when oracle/_ref is available (it travels to the GPU box), compare on a fresh seeded model too
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built")
+    import xrl_synth
+    folder = str(tmp_path / "m")
+    xrl_synth.make_model(folder, 400, 700, [120, 80, 25], seed=3, shape=[3, 20, 700])
+    X = xrl_synth.make_queries(40, 400, 30, seed=4, relabel_seed=3)
+    om = oracle_mod.OracleModel.load(folder)
+    rm = oracle_mod.RefModel(folder)
+    for pp in [None, "sigmoid", "log-sigmoid", "l1-hinge", "log-l4-hinge", "noop"]:
+        for Xq in (X, np.ascontiguousarray(X.toarray())):
+            assert_same_topk(om.predict(Xq, beam_size=5, only_topk=7, post_processor=pp),
+                             rm.predict(Xq, beam_size=5, only_topk=7, post_processor=pp), exact_scores=True, what=str(pp))
+
+
+def test_oracle_sparse_inner_products_kat(oracle_mod):
+    # test/pecos/core/test_clib.py:39-69 known-answer test
+    X = smat.csr_matrix([[1.0, 0.0], [0.5, 0.5], [0.0, 1.0]], dtype=np.float32)
+    Y = smat.csr_matrix([[0.5, 0.0], [0.0, 1.0], [1.0, 0.0], [0.0, 0.5]], dtype=np.float32)
+    gt = np.array([[0.50, 0.00, 1.00, 0.00], [0.25, 0.50, 0.50, 0.25], [0.00, 1.00, 0.00, 0.50]], dtype=np.float32)
+    r = np.array([0, 1, 2], dtype=np.uint32); c = np.array([1, 2, 3], dtype=np.uint32)
+    true = np.array([gt[i, j] for i, j in zip(r, c)], dtype=np.float32)
+    W = Y.T.tocsc()
+    for Xq, Wq in [(X, W), (X.toarray(), W), (X, np.asfortranarray(W.toarray())), (X.toarray(), np.asfortranarray(W.toarray()))]:
+        assert np.allclose(oracle_mod.sparse_inner_products(Xq, Wq, r, c), true, atol=1e-9)
