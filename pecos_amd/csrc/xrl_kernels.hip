@@ -99,6 +99,106 @@ void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, BeamDev prev, u
 }
 
 // ---------------------------------------------------------------------------------------------
+// item ordering: counting sort of the layer's (query, beam slot, tile) items by tile id, so that
+// the wavefronts working on one tile run back to back on ONE XCD and find the tile's bitmap /
+// row table / entries in that XCD's L2 (the reference sorts by chunk for the same reason,
+// inference.hpp:991-993).  Order inside a tile is arbitrary (atomics); results do not depend on it.
+// ---------------------------------------------------------------------------------------------
+struct ItemArgs {
+    const uint32_t* ptile;
+    const uint32_t* p_idx; const uint32_t* p_cnt; uint32_t p_stride;
+    uint32_t nrows, beam_in, TT;
+    int implicit_root;
+};
+
+__device__ __forceinline__ bool decode_slot(const ItemArgs& a, uint64_t slot, uint32_t& q, uint32_t& j, uint32_t& tt,
+                                            uint32_t& tile) {
+    tt = (uint32_t)(slot % a.TT);
+    const uint64_t r1 = slot / a.TT;
+    j = (uint32_t)(r1 % a.beam_in);
+    const uint64_t qq = r1 / a.beam_in;
+    if (qq >= a.nrows) return false;
+    q = (uint32_t)qq;
+    uint32_t parent = 0;
+    if (!a.implicit_root) {
+        if (j >= min(a.p_cnt[q], a.beam_in)) return false;
+        parent = a.p_idx[(uint64_t)q * a.p_stride + j];
+    } else if (j != 0) {
+        return false;
+    }
+    const uint32_t t0 = a.ptile[parent], t1 = a.ptile[parent + 1];
+    if (tt >= t1 - t0) return false;
+    tile = t0 + tt;
+    return true;
+}
+
+__global__ void __launch_bounds__(256) sort_count_kernel(ItemArgs a, uint64_t slots, uint32_t* __restrict__ count) {
+    const uint64_t slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (slot >= slots) return;
+    uint32_t q, j, tt, tile;
+    if (decode_slot(a, slot, q, j, tt, tile)) atomicAdd(&count[tile], 1u);
+}
+
+// single block: exclusive scan of count[0..n) in place -> start offsets; count[n] = total; fill[] = 0
+__global__ void __launch_bounds__(1024) sort_scan_kernel(uint32_t* __restrict__ count, uint32_t* __restrict__ fill, uint32_t n) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? count[i] : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) { count[i] = carry + part[threadIdx.x] - v; fill[i] = 0u; }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[n] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+sort_scatter_kernel(ItemArgs a, uint64_t slots, const uint32_t* __restrict__ start, uint32_t* __restrict__ fill,
+                    uint2* __restrict__ items) {
+    const uint64_t slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (slot >= slots) return;
+    uint32_t q, j, tt, tile;
+    if (decode_slot(a, slot, q, j, tt, tile)) {
+        const uint32_t pos = start[tile] + atomicAdd(&fill[tile], 1u);
+        items[pos] = make_uint2(q, j | (tt << 16));
+    }
+}
+
+static ItemArgs make_item_args(const LayerDev& L, const LayerPlan& P, const BeamDev& prev) {
+    ItemArgs a;
+    a.ptile = L.ptile; a.p_idx = prev.idx; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
+    a.nrows = P.nrows; a.beam_in = P.beam_in; a.TT = L.max_tiles_per_parent; a.implicit_root = P.implicit_root;
+    return a;
+}
+
+void launch_sort_items(const LayerDev& L, const LayerPlan& P, BeamDev prev, uint32_t* count /*[n_tiles+1]*/,
+                       uint32_t* fill /*[n_tiles]*/, uint2* items, hipStream_t s) {
+    if (P.nrows == 0) return;
+    if (P.beam_in > 0xFFFFu || L.max_tiles_per_parent > 0xFFFFu) fail("sort_items: beam or tiles-per-parent exceed 16 bits");
+    const ItemArgs a = make_item_args(L, P, prev);
+    const uint64_t slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
+    const uint64_t blocks = (slots + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) fail("sort_items: grid too large; lower max_batch_rows");
+    XRL_HIP(hipMemsetAsync(count, 0, ((size_t)L.n_tiles + 1) * 4, s));
+    hipLaunchKernelGGL(sort_count_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a, slots, count);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, count, fill, L.n_tiles);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a, slots, count, fill, items);
+    XRL_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------
 struct K1Args {
@@ -107,208 +207,269 @@ struct K1Args {
     BeamDev prev;
     const uint32_t* cand_off;
     float* cand;
+    const uint2* items;          // tile-sorted item list, or nullptr (natural order)
+    const uint32_t* n_items;     // device count of valid items (sorted mode)
     uint32_t row0, nrows, beam_in, cand_stride, acc_stride;
     int pp_kind, pp_p, first_layer, implicit_root;
 };
 
-template <int G> struct K1Cfg {
-    static constexpr int W = 64 / G;                     // items per wavefront
-    static constexpr int H = (G < 4) ? 8 : 2 * G;        // FIFO depth per item (>= 2G)
+// XCD-aware block remap (blocks b, b+8, b+16, ... run on one XCD): give every XCD a CONTIGUOUS
+// range of the (tile-sorted) work so a tile's data is fetched into one L2 only.  Bijective.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
+    const uint32_t xcd = b & 7u, q = nb >> 3, r = nb & 7u;
+    const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+struct ItemCtx {
+    bool active;
+    uint32_t q, j, parent, tile;
+    float pscore;
+    TileDesc td;
 };
 
-template <int G, bool DENSE>
-__global__ void __launch_bounds__(64) k1_kernel(K1Args a) {
-    constexpr int W = K1Cfg<G>::W, H = K1Cfg<G>::H;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* acc = reinterpret_cast<float*>(smem);
-    const uint32_t acc_floats = (G == 1) ? a.acc_stride * 64u : a.acc_stride * (uint32_t)W;
-    float* fv = acc + acc_floats;
-    uint32_t* fs = reinterpret_cast<uint32_t*>(fv + W * H);
-
-    const int lane = threadIdx.x;
-    const int grp = lane / G, lig = lane % G;
-    // accumulator / fifo addressing: G==1 keeps [c][lane] (bank = lane, conflict-free for any c)
-    auto ACC = [&](uint32_t c) -> float& { return (G == 1) ? acc[c * 64u + lane] : acc[grp * a.acc_stride + c]; };
-    auto FIDX = [&](uint32_t pos) -> uint32_t { return (G == 1) ? pos * 64u + lane : (uint32_t)grp * H + pos; };
-
-    // ---- item decode: (query, beam slot, tile-in-parent), tile fastest
-    const uint32_t TT = a.L.max_tiles_per_parent;
-    const uint64_t slot = (uint64_t)blockIdx.x * W + grp;
-    const uint32_t tt = (uint32_t)(slot % TT);
-    const uint64_t r1 = slot / TT;
-    const uint32_t j = (uint32_t)(r1 % a.beam_in);
-    const uint64_t q = r1 / a.beam_in;
-    bool active = q < a.nrows;
-    uint32_t parent = 0;
-    float pscore = 1.0f;
-    if (active && !a.implicit_root) {
-        active = j < min(a.prev.cnt[q], a.beam_in);
-        if (active) {
-            parent = a.prev.idx[q * a.prev.stride + j];
-            pscore = a.prev.val[q * a.prev.stride + j];
-        }
-    } else if (active) {
-        active = (j == 0);
-    }
-    TileDesc td{};
-    uint32_t tile = 0;
-    if (active) {
-        const uint32_t t0 = a.L.ptile[parent], t1 = a.L.ptile[parent + 1];
-        active = tt < t1 - t0;
-        if (active) { tile = t0 + tt; td = a.L.tiles[tile]; }
-    }
-    const uint32_t ncols = active ? td.ncols : 0u;
-    const uint32_t* __restrict__ rp = a.L.row_ptr + td.rowptr_base;
-    const Entry* __restrict__ ent = a.L.entries + td.ent_base;
-
-    for (uint32_t c = lig; c < ncols; c += G) ACC(c) = 0.0f;   // std::fill(..., 0.0), inference.hpp:964
-    wave_sync_lds();
-
-    const uint64_t qg = (uint64_t)a.row0 + q;
-    if (DENSE) {
-        // chunk_ops<drm, bin_search>, inference.hpp:815-839: bias FIRST, then every chunk row
-        const float* __restrict__ xd = a.X.val + qg * a.X.cols;
-        const uint32_t* __restrict__ ridx = a.L.row_idx + (td.rowptr_base - tile);
-        uint32_t nr = active ? td.nrows : 0u;
-        if (active && td.bias_slot != kNoBias) {
-            for (uint32_t e = rp[td.bias_slot] + lig; e < rp[td.bias_slot + 1]; e += G) {
-                const Entry en = ent[e];
-                ACC(en.col) = __fadd_rn(ACC(en.col), __fmul_rn(a.L.bias, en.val));
-            }
-            nr -= 1;
-        }
-        wave_sync_lds();
-        for (uint32_t s = 0; __any(s < nr); ++s) {
-            if (s < nr) {
-                const uint32_t f = ridx[s];
-                if (f < a.X.cols) {
-                    const float v = xd[f];
-                    for (uint32_t e = rp[s] + lig; e < rp[s + 1]; e += G) {
-                        const Entry en = ent[e];
-                        ACC(en.col) = __fadd_rn(ACC(en.col), __fmul_rn(v, en.val));
-                    }
-                }
-            }
-            wave_sync_lds();
+template <int W>
+__device__ __forceinline__ ItemCtx k1_item(const K1Args& a, int grp) {
+    ItemCtx it{};
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const uint64_t slot = (uint64_t)blk * W + grp;
+    ItemArgs ia;
+    ia.ptile = a.L.ptile; ia.p_idx = a.prev.idx; ia.p_cnt = a.prev.cnt; ia.p_stride = a.prev.stride;
+    ia.nrows = a.nrows; ia.beam_in = a.beam_in; ia.TT = a.L.max_tiles_per_parent; ia.implicit_root = a.implicit_root;
+    uint32_t tt = 0;
+    if (a.items) {
+        if (slot < *a.n_items) {
+            const uint2 e = a.items[slot];
+            it.q = e.x; it.j = e.y & 0xFFFFu; tt = e.y >> 16;
+            it.parent = a.implicit_root ? 0u : a.prev.idx[(uint64_t)it.q * a.prev.stride + it.j];
+            it.tile = a.L.ptile[it.parent] + tt;
+            it.active = true;
         }
     } else {
-        // chunk_ops<csr, bin_search>, inference.hpp:769-813
-        uint64_t xb = 0, xe = 0;
-        if (active) { xb = a.X.row_ptr[qg]; xe = a.X.row_ptr[qg + 1]; }
-        const uint32_t* __restrict__ xi = a.X.col_idx;
-        const float* __restrict__ xv = a.X.val;
-        const BmWord* __restrict__ bm = a.L.bitmap + (uint64_t)tile * a.L.nwords;
-        uint64_t cur = xb;
-        do {
-            // ---- fill: probe G features per step, compact hits in feature order into the FIFO
-            uint32_t nh = 0;
-            while (__any(cur < xe && nh + G <= (uint32_t)H)) {
-                const bool can = (cur < xe) && (nh + G <= (uint32_t)H);
-                const uint64_t t = cur + lig;
-                bool hit = false;
-                uint32_t hslot = 0;
-                float v = 0.f;
-                if (can && t < xe) {
-                    const uint32_t f = xi[t];
-                    v = xv[t];
-                    if (f < a.L.w_rows) {
-                        const BmWord w = bm[f >> 5];
-                        const uint32_t b = f & 31u;
-                        if ((w.bits >> b) & 1u) {
-                            hit = true;
-                            hslot = w.rank + __popc(w.bits & ((1u << b) - 1u));
-                        }
-                    }
-                }
-                const unsigned long long m = __ballot(hit);
-                const unsigned long long gm = (G == 64) ? m : ((m >> (grp * G)) & ((1ull << G) - 1ull));
-                const uint32_t pos = nh + (uint32_t)__popcll(gm & ((1ull << lig) - 1ull));
-                if (hit) { fv[FIDX(pos)] = v; fs[FIDX(pos)] = hslot; }
-                nh += (uint32_t)__popcll(gm);
-                if (can) cur += G;
-            }
-            wave_sync_lds();
-            // ---- drain: rows in feature order; the G lanes stride over one row's entries
-            for (uint32_t h = 0; __any(h < nh); ++h) {
-                if (h < nh) {
-                    const float v = fv[FIDX(h)];
-                    const uint32_t s = fs[FIDX(h)];
-                    for (uint32_t e = rp[s] + lig; e < rp[s + 1]; e += G) {
-                        const Entry en = ent[e];
-                        // out[col] += scalar * val (inference.hpp:512-517), mul then add, no fma
-                        ACC(en.col) = __fadd_rn(ACC(en.col), __fmul_rn(v, en.val));
-                    }
-                }
-                wave_sync_lds();
-            }
-        } while (__any(cur < xe));
-        // bias LAST (inference.hpp:806-811)
-        if (active && td.bias_slot != kNoBias) {
-            for (uint32_t e = rp[td.bias_slot] + lig; e < rp[td.bias_slot + 1]; e += G) {
-                const Entry en = ent[e];
-                ACC(en.col) = __fadd_rn(ACC(en.col), __fmul_rn(a.L.bias, en.val));
-            }
-        }
-        wave_sync_lds();
+        it.active = decode_slot(ia, slot, it.q, it.j, tt, it.tile);
+        if (it.active) it.parent = a.implicit_root ? 0u : a.prev.idx[(uint64_t)it.q * a.prev.stride + it.j];
     }
+    it.pscore = 1.0f;
+    if (it.active) {
+        if (!a.implicit_root) it.pscore = a.prev.val[(uint64_t)it.q * a.prev.stride + it.j];
+        it.td = a.L.tiles[it.tile];
+    }
+    return it;
+}
 
-    // ---- epilogue: transform (fp64) + combine with the parent's score, write the child block
-    if (active) {
-        float* __restrict__ out = a.cand + q * a.cand_stride + a.cand_off[q * a.beam_in + j] +
-                                  (td.col_begin - a.L.chunk_col[parent]);
-        for (uint32_t c = lig; c < ncols; c += G) {
-            float v = pp_transform(a.pp_kind, a.pp_p, ACC(c));
-            if (!a.first_layer) v = pp_combine(a.pp_kind, v, pscore);
-            out[c] = v;
-        }
+template <int G, class ACC>
+__device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemCtx& it, int lig, ACC&& acc_at) {
+    // transform (fp64) + combine with the parent's score, write the child block
+    if (!it.active) return;
+    float* __restrict__ out = a.cand + (uint64_t)it.q * a.cand_stride + a.cand_off[(uint64_t)it.q * a.beam_in + it.j] +
+                              (it.td.col_begin - a.L.chunk_col[it.parent]);
+    for (uint32_t c = lig; c < it.td.ncols; c += G) {
+        float v = pp_transform(a.pp_kind, a.pp_p, acc_at(c));
+        if (!a.first_layer) v = pp_combine(a.pp_kind, v, it.pscore);
+        out[c] = v;
     }
 }
 
-template <int G, bool DENSE>
-static void launch_k1_inst(const K1Args& a, uint64_t slots, hipStream_t s) {
-    constexpr int W = K1Cfg<G>::W, H = K1Cfg<G>::H;
-    const uint32_t acc_floats = (G == 1) ? a.acc_stride * 64u : a.acc_stride * (uint32_t)W;
-    const size_t lds = (size_t)acc_floats * 4 + (size_t)W * H * 8;
-    if (lds > 160 * 1024) fail("k1: LDS request exceeds 160 KiB");
-    static thread_local size_t configured = 0;
-    if (lds > 48 * 1024 && lds > configured) {
-        XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k1_kernel<G, DENSE>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
+// ---- sparse queries: chunk_ops<csr, bin_search>, inference.hpp:769-813 --------------------------
+template <int G, int U> struct K1Cfg {
+    static constexpr int W = 64 / G;                                  // items per wavefront
+    static constexpr int H = (2 * U * G > 16) ? 2 * U * G : 16;       // hit-FIFO depth per item
+    static constexpr size_t lds_bytes(uint32_t acc_stride) { return (size_t)W * acc_stride * 4 + (size_t)W * H * (4 + 4 + 4 + 16); }
+};
+
+template <int G, int U>
+__global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
+    constexpr int W = K1Cfg<G, U>::W, H = K1Cfg<G, U>::H;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* fe = reinterpret_cast<uint4*>(smem);                        // first two entries of the hit row
+    float* acc = reinterpret_cast<float*>(fe + W * H);
+    float* fv = acc + (size_t)W * a.acc_stride;                        // x value of the hit
+    uint32_t* fa = reinterpret_cast<uint32_t*>(fv + W * H);            // row slot, then row start
+    uint32_t* fl = fa + W * H;                                         // row length
+
+    const int lane = threadIdx.x;
+    const int grp = lane / G, lig = lane % G;
+    const ItemCtx it = k1_item<W>(a, grp);
+    const uint32_t ncols = it.active ? it.td.ncols : 0u;
+    const uint32_t* __restrict__ rp = a.L.row_ptr + it.td.rowptr_base;
+    const Entry* __restrict__ ent = a.L.entries + it.td.ent_base;
+    float* __restrict__ my_acc = acc + (size_t)grp * a.acc_stride;
+    const uint32_t fbase = (uint32_t)grp * H;
+
+    for (uint32_t c = lig; c < ncols; c += G) my_acc[c] = 0.0f;        // std::fill(..., 0.0), inference.hpp:964
+    wave_sync_lds();
+
+    uint64_t xe = 0, cur = 0;
+    if (it.active) { const uint64_t qg = (uint64_t)a.row0 + it.q; cur = a.X.row_ptr[qg]; xe = a.X.row_ptr[qg + 1]; }
+    const uint32_t* __restrict__ xi = a.X.col_idx;
+    const float* __restrict__ xv = a.X.val;
+    const BmWord* __restrict__ bm = a.L.bitmap + (uint64_t)it.tile * a.L.nwords;
+    const unsigned long long below = (1ull << lig) - 1ull;
+
+    do {
+        // ---- fill: U*G consecutive features of the item per step; all x loads, then all bitmap
+        //      probes are issued together; hits are compacted IN FEATURE ORDER into the FIFO
+        uint32_t nh = 0;
+        while (__any(cur < xe && nh + U * G <= (uint32_t)H)) {
+            const bool can = (cur < xe) && (nh + U * G <= (uint32_t)H);
+            uint32_t f[U]; float v[U]; bool ok[U]; BmWord w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint64_t t = cur + (uint64_t)(u * G + lig);
+                ok[u] = can && t < xe;
+                f[u] = ok[u] ? xi[t] : 0xFFFFFFFFu;
+                v[u] = ok[u] ? xv[t] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ok[u] = ok[u] && f[u] < a.L.w_rows;
+                w[u] = ok[u] ? bm[f[u] >> 5] : BmWord{0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t b = f[u] & 31u;
+                const bool hit = ok[u] && ((w[u].bits >> b) & 1u);
+                const unsigned long long m = __ballot(hit);
+                const unsigned long long gm = (G == 64) ? m : ((m >> (grp * G)) & ((1ull << G) - 1ull));
+                if (hit) {
+                    const uint32_t pos = fbase + nh + (uint32_t)__popcll(gm & below);
+                    fv[pos] = v[u];
+                    fa[pos] = w[u].rank + __popc(w[u].bits & ((1u << b) - 1u));
+                }
+                nh += (uint32_t)__popcll(gm);
+            }
+            if (can) cur += U * G;
+        }
+        wave_sync_lds();
+        // ---- D1/D2: one lane per hit fetches the row extent and its first two entries (all hits of
+        //      all items in flight at once -> two dependent memory latencies per batch, not per hit)
+        for (uint32_t h = lig; h < nh; h += G) {
+            const uint32_t s = fa[fbase + h];
+            const uint32_t rs = rp[s], len = rp[s + 1] - rs;
+            uint4 e2 = make_uint4(0u, 0u, 0u, 0u);
+            if (len >= 2) { const Entry e0 = ent[rs], e1 = ent[rs + 1]; e2 = make_uint4(e0.col, __float_as_uint(e0.val), e1.col, __float_as_uint(e1.val)); }
+            else if (len == 1) { const Entry e0 = ent[rs]; e2.x = e0.col; e2.y = __float_as_uint(e0.val); }
+            fa[fbase + h] = rs; fl[fbase + h] = len; fe[fbase + h] = e2;
+        }
+        wave_sync_lds();
+        // ---- D3: rows in feature order; inside a row the lanes take distinct columns
+        for (uint32_t h = 0; __any(h < nh); ++h) {
+            if (h < nh) {
+                const float v = fv[fbase + h];
+                const uint32_t len = fl[fbase + h];
+                if ((uint32_t)lig < min(len, 2u)) {
+                    const uint4 e2 = fe[fbase + h];
+                    const uint32_t col = lig ? e2.z : e2.x;
+                    const float wv = __uint_as_float(lig ? e2.w : e2.y);
+                    // out[col] += scalar * val (inference.hpp:512-517): mul then add, no fma
+                    my_acc[col] = __fadd_rn(my_acc[col], __fmul_rn(v, wv));
+                }
+                if (len > 2) {
+                    const uint32_t rs = fa[fbase + h];
+                    for (uint32_t e = 2 + lig; e < len; e += G) {
+                        const Entry en = ent[rs + e];
+                        my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(v, en.val));
+                    }
+                }
+            }
+            wave_sync_lds();
+        }
+    } while (__any(cur < xe));
+    // bias LAST (inference.hpp:806-811)
+    if (it.active && it.td.bias_slot != kNoBias) {
+        for (uint32_t e = rp[it.td.bias_slot] + lig; e < rp[it.td.bias_slot + 1]; e += G) {
+            const Entry en = ent[e];
+            my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(a.L.bias, en.val));
+        }
     }
+    wave_sync_lds();
+    k1_epilogue<G>(a, it, lig, [&](uint32_t c) { return my_acc[c]; });
+}
+
+// ---- dense queries: chunk_ops<drm, bin_search>, inference.hpp:815-839 (bias FIRST, every row) -----
+template <int G>
+__global__ void __launch_bounds__(64) k1_dense_kernel(K1Args a) {
+    constexpr int W = 64 / G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* acc = reinterpret_cast<float*>(smem);
+    const int lane = threadIdx.x;
+    const int grp = lane / G, lig = lane % G;
+    const ItemCtx it = k1_item<W>(a, grp);
+    const uint32_t ncols = it.active ? it.td.ncols : 0u;
+    const uint32_t* __restrict__ rp = a.L.row_ptr + it.td.rowptr_base;
+    const Entry* __restrict__ ent = a.L.entries + it.td.ent_base;
+    float* __restrict__ my_acc = acc + (size_t)grp * a.acc_stride;
+    for (uint32_t c = lig; c < ncols; c += G) my_acc[c] = 0.0f;
+    wave_sync_lds();
+    const float* __restrict__ xd = a.X.val + ((uint64_t)a.row0 + it.q) * a.X.cols;
+    const uint32_t* __restrict__ ridx = a.L.row_idx + (it.td.rowptr_base - it.tile);
+    uint32_t nr = it.active ? it.td.nrows : 0u;
+    if (it.active && it.td.bias_slot != kNoBias) {
+        for (uint32_t e = rp[it.td.bias_slot] + lig; e < rp[it.td.bias_slot + 1]; e += G) {
+            const Entry en = ent[e];
+            my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(a.L.bias, en.val));
+        }
+        nr -= 1;
+    }
+    wave_sync_lds();
+    for (uint32_t s = 0; __any(s < nr); ++s) {
+        if (s < nr) {
+            const uint32_t f = ridx[s];
+            if (f < a.X.cols) {
+                const float v = xd[f];
+                for (uint32_t e = rp[s] + lig; e < rp[s + 1]; e += G) {
+                    const Entry en = ent[e];
+                    my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(v, en.val));
+                }
+            }
+        }
+        wave_sync_lds();
+    }
+    k1_epilogue<G>(a, it, lig, [&](uint32_t c) { return my_acc[c]; });
+}
+
+template <class KERNEL>
+static void launch_k1_any(KERNEL kernel, const K1Args& a, uint64_t slots, int W, size_t lds, hipStream_t s) {
+    if (lds > 160 * 1024) fail("k1: LDS request exceeds 160 KiB");
+    if (lds > 48 * 1024)
+        XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const uint64_t blocks = (slots + W - 1) / W;
     if (blocks > 0x7FFFFFFFull) fail("k1: grid too large; lower max_batch_rows");
-    hipLaunchKernelGGL((k1_kernel<G, DENSE>), dim3((uint32_t)blocks), dim3(64), lds, s, a);
+    hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(64), lds, s, a);
     XRL_LAUNCH_CHECK();
 }
 
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense) {
-    // lanes per item ~ entries per tile row (power of two), raised until the accumulators of one
-    // wavefront fit ~16 KiB of LDS so that several wavefronts share a CU.
+    // lanes per item: enough to cover a typical tile row, and at least 8 so that the x reads of an
+    // item coalesce into >= 32-byte segments and a wavefront's LDS stays small
     const double row_len = host.total_rows ? (double)host.nnz / (double)host.total_rows : 1.0;
-    int g = 1;
+    int g = dense ? 16 : 8;
     while (g < 64 && g < row_len * 0.75) g <<= 1;
-    const uint32_t S = L.max_tile_cols | 1u;
-    while (g < 64 && (size_t)(64 / g) * S * 4 > 16 * 1024) g <<= 1;
-    (void)dense;
+    (void)L;
     return g;
 }
 
 void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev,
-               const uint32_t* cand_off, float* cand, int group, hipStream_t s) {
+               const uint32_t* cand_off, float* cand, const uint2* items, const uint32_t* n_items, int group,
+               hipStream_t s) {
     if (P.nrows == 0) return;
     K1Args a;
-    a.L = L; a.X = X; a.prev = prev; a.cand_off = cand_off; a.cand = cand;
+    a.L = L; a.X = X; a.prev = prev; a.cand_off = cand_off; a.cand = cand; a.items = items; a.n_items = n_items;
     a.row0 = P.row0; a.nrows = P.nrows; a.beam_in = P.beam_in; a.cand_stride = P.cand_stride;
     a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer; a.implicit_root = P.implicit_root;
-    a.acc_stride = (group == 1) ? L.max_tile_cols : (L.max_tile_cols | 1u);
+    a.acc_stride = L.max_tile_cols | 1u;
     const uint64_t slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
-#define XRL_K1_CASE(GG) case GG: if (X.dense) launch_k1_inst<GG, true>(a, slots, s); else launch_k1_inst<GG, false>(a, slots, s); break;
-    switch (group) {
-        XRL_K1_CASE(1) XRL_K1_CASE(2) XRL_K1_CASE(4) XRL_K1_CASE(8) XRL_K1_CASE(16) XRL_K1_CASE(32) XRL_K1_CASE(64)
-    default: fail("k1: lanes-per-item must be a power of two in [1, 64]");
+    if (X.dense) {
+#define XRL_K1D(GG) case GG: launch_k1_any(&k1_dense_kernel<GG>, a, slots, 64 / GG, (size_t)(64 / GG) * a.acc_stride * 4, s); break;
+        switch (group) { XRL_K1D(1) XRL_K1D(2) XRL_K1D(4) XRL_K1D(8) XRL_K1D(16) XRL_K1D(32) XRL_K1D(64)
+        default: fail("k1: lanes-per-item must be a power of two in [1, 64]"); }
+#undef XRL_K1D
+    } else {
+#define XRL_K1S(GG, UU) case GG: launch_k1_any(&k1_sparse_kernel<GG, UU>, a, slots, 64 / GG, K1Cfg<GG, UU>::lds_bytes(a.acc_stride), s); break;
+        switch (group) { XRL_K1S(1, 8) XRL_K1S(2, 8) XRL_K1S(4, 4) XRL_K1S(8, 2) XRL_K1S(16, 2) XRL_K1S(32, 1) XRL_K1S(64, 1)
+        default: fail("k1: lanes-per-item must be a power of two in [1, 64]"); }
+#undef XRL_K1S
     }
-#undef XRL_K1_CASE
 }
 
 // ---------------------------------------------------------------------------------------------

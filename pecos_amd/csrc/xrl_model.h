@@ -88,6 +88,7 @@ struct PendingEvent { hipEvent_t a, b; size_t slot; };
 struct Workspace {
     DevBuf beam_idx[2], beam_val[2], beam_cnt[2];
     DevBuf cand_off, ncand, cand, stats;
+    DevBuf sort_count, sort_fill, items;     // tile-sorted item list
     // host-ABI predict: uploaded X + result staging
     DevBuf x_ptr, x_idx, x_val;
     DevBuf out_idx, out_val, out_cnt;
