@@ -45,17 +45,33 @@ __device__ __forceinline__ void wave_sync_lds() {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ref_expf(float x) { return (float)exp((double)x); }
 
+// z^p for the integer p of l{p}-hinge.  z is a float, so z*z is EXACT in double (48-bit product) and
+// z^3 = (z*z)*z, z^4 = (z*z)*(z*z) carry a single rounding: they are the correctly rounded powers,
+// which is what glibc's pow returns (its error bound is < 1 ULP, correctly rounded in practice).
+// Larger p fall back to pow().
+__device__ __forceinline__ double hinge_pow(float zf, int p) {
+    const double z = (double)zf;
+    switch (p) {
+    case 0: return 1.0;
+    case 1: return z;
+    case 2: return z * z;
+    case 3: return (z * z) * z;
+    case 4: { const double t = z * z; return t * t; }
+    default: return pow(z, (double)p);
+    }
+}
+
 __device__ __forceinline__ float pp_transform(int kind, int p, float v) {
     switch (kind) {
     case PP_SIGMOID: return (float)(1.0 / (1.0 + (double)ref_expf(-v)));
     case PP_LOG_SIGMOID: return (float)(-log(1.0 + (double)ref_expf(-v)));
     case PP_LP_HINGE: {
         const float z = (float)fmax(0.0, 1.0 - (double)v);
-        return (float)exp(-pow((double)z, (double)p));
+        return (float)exp(-hinge_pow(z, p));
     }
     case PP_LOG_LP_HINGE: {
         const float z = (float)fmax(0.0, 1.0 - (double)v);
-        return (float)(-pow((double)z, (double)p));
+        return (float)(-hinge_pow(z, p));
     }
     default: return v;
     }
@@ -231,14 +247,18 @@ struct ItemCtx {
 template <int W>
 __device__ __forceinline__ ItemCtx k1_item(const K1Args& a, int grp) {
     ItemCtx it{};
-    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
-    const uint64_t slot = (uint64_t)blk * W + grp;
+    uint64_t slot = (uint64_t)blockIdx.x * W + grp;
     ItemArgs ia;
     ia.ptile = a.L.ptile; ia.p_idx = a.prev.idx; ia.p_cnt = a.prev.cnt; ia.p_stride = a.prev.stride;
     ia.nrows = a.nrows; ia.beam_in = a.beam_in; ia.TT = a.L.max_tiles_per_parent; ia.implicit_root = a.implicit_root;
     uint32_t tt = 0;
     if (a.items) {
-        if (slot < *a.n_items) {
+        // tile-sorted list: blocks beyond the valid range idle; the valid blocks are remapped so that
+        // every XCD owns a contiguous run of tiles
+        const uint32_t n_items = *a.n_items;
+        const uint32_t nb = (n_items + W - 1) / W;
+        slot = blockIdx.x < nb ? (uint64_t)xcd_remap(blockIdx.x, nb) * W + grp : (uint64_t)n_items;
+        if (slot < n_items) {
             const uint2 e = a.items[slot];
             it.q = e.x; it.j = e.y & 0xFFFFu; tt = e.y >> 16;
             it.parent = a.implicit_root ? 0u : a.prev.idx[(uint64_t)it.q * a.prev.stride + it.j];
@@ -357,19 +377,15 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
             if (h < nh) {
                 const float v = fv[fbase + h];
                 const uint32_t len = fl[fbase + h];
-                if ((uint32_t)lig < min(len, 2u)) {
-                    const uint4 e2 = fe[fbase + h];
-                    const uint32_t col = lig ? e2.z : e2.x;
-                    const float wv = __uint_as_float(lig ? e2.w : e2.y);
+                const uint32_t rs = fa[fbase + h];
+                const uint4 e2 = fe[fbase + h];
+                for (uint32_t e = lig; e < len; e += G) {
+                    uint32_t col; float wv;
+                    if (e == 0) { col = e2.x; wv = __uint_as_float(e2.y); }
+                    else if (e == 1) { col = e2.z; wv = __uint_as_float(e2.w); }
+                    else { const Entry en = ent[rs + e]; col = en.col; wv = en.val; }
                     // out[col] += scalar * val (inference.hpp:512-517): mul then add, no fma
                     my_acc[col] = __fadd_rn(my_acc[col], __fmul_rn(v, wv));
-                }
-                if (len > 2) {
-                    const uint32_t rs = fa[fbase + h];
-                    for (uint32_t e = 2 + lig; e < len; e += G) {
-                        const Entry en = ent[rs + e];
-                        my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(v, en.val));
-                    }
                 }
             }
             wave_sync_lds();

@@ -114,7 +114,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
 
             int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
             // tile-sorted item order once a layer has enough tiles for locality to matter
-            const bool sorted = (m.sort_items < 0) ? (L.n_tiles >= 64) : (m.sort_items != 0);
+            const bool sorted = m.sort_items > 0;   // off by default: measured slower than it saves (atomics), see DESIGN.md
             const uint2* items = nullptr; const uint32_t* n_items = nullptr;
             if (sorted) {
                 const uint64_t slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;

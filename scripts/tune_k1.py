@@ -23,16 +23,17 @@ def dmalloc(n):
     p = ctypes.c_void_p(); assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n)) == 0; return p.value
 di, dv, dc = dmalloc(X.shape[0] * k * 4), dmalloc(X.shape[0] * k * 4), dmalloc(X.shape[0] * 4)
 print("stats (chunk bytes, n_eval) per layer:", [(f"{a:.3g}", f"{b:.3g}") for a, b in clib.predict_stats(h, q, cfg["beam"], None, k)])
+PP = os.environ.get("XRL_PP") or None
 for extra in (sys.argv[4:] or [""]):
     for kv in extra.split(","):
         if kv: clib.set_option(h, kv.split("=")[0], int(kv.split("=")[1]))
     for g in groups:
         clib.set_option(h, "k1_group", g)
-        clib.predict_device(h, q, cfg["beam"], None, k, di, dv, dc, k, sync=True)
+        clib.predict_device(h, q, cfg["beam"], PP, k, di, dv, dc, k, sync=True)
         clib.profile_reset(h); clib.profile_enable(h, True)
         t0 = time.perf_counter()
-        for _ in range(3): clib.predict_device(h, q, cfg["beam"], None, k, di, dv, dc, k, sync=False)
-        clib.predict_device(h, q, cfg["beam"], None, k, di, dv, dc, k, sync=True)
+        for _ in range(3): clib.predict_device(h, q, cfg["beam"], PP, k, di, dv, dc, k, sync=False)
+        clib.predict_device(h, q, cfg["beam"], PP, k, di, dv, dc, k, sync=True)
         dt = (time.perf_counter() - t0) / 4
         clib.profile_enable(h, False)
         prof = clib.profile_get(h)
