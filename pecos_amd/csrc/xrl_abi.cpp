@@ -465,7 +465,6 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         Model& m = *as_model(model);
         if (!key) fail("null key");
         if (!std::strcmp(key, "k1_group")) m.k1_group = (int)value;
-        else if (!std::strcmp(key, "sort_items")) m.sort_items = (int)value;
         else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
         else fail(std::string("unknown option ") + key);
         rc = 0;

@@ -33,16 +33,14 @@ struct LayerPlan {
     int implicit_root;          // previous beam is the implicit all-ones root
 };
 
-// K0  prolongate: per query, offsets of every beam parent's child block + candidate count.
+// K0  prolongate: per query, offsets of every beam parent's child block + candidate count, and one
+//     16-byte item descriptor per (query, beam slot, tile-in-parent) for K1.
 void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, BeamDev prev, uint32_t* cand_off,
-                          uint32_t* ncand, hipStream_t s);
+                          uint32_t* ncand, void* items, hipStream_t s);
+size_t k0_item_bytes();
 // K1  (query, tile) inner products + bias + post-processor + combine, one item per G lanes.
-void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev,
-               const uint32_t* cand_off, float* cand, const uint2* items, const uint32_t* n_items, int group,
+void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, float* cand, int group,
                hipStream_t s);
-// counting sort of the layer's items by tile id: count[n_tiles+1] (count[n_tiles] = #items), fill[n_tiles]
-void launch_sort_items(const LayerDev& L, const LayerPlan& P, BeamDev prev, uint32_t* count, uint32_t* fill,
-                       uint2* items, hipStream_t s);
 // K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,

@@ -88,131 +88,51 @@ __device__ __forceinline__ float pp_combine(int kind, float x, float parent) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// K0: one thread per query
+// K0: one thread per query.  Besides the child-block offsets (prolongate) it writes one 16-byte
+// ITEM DESCRIPTOR per (query, beam slot, tile-in-parent) so that K1 starts from a single coalesced
+// load instead of a chain of dependent lookups (beam -> parent -> tile range -> offsets).
 // ---------------------------------------------------------------------------------------------
+struct ItemDesc { uint32_t q, tile, out_off; float pscore; };   // tile == kNoTile: inactive slot
+constexpr uint32_t kNoTile = 0xFFFFFFFFu;
+
 __global__ void __launch_bounds__(256)
-k0_prolongate(const uint32_t* __restrict__ chunk_col, uint32_t nrows, uint32_t beam_in, int implicit_root,
-              const uint32_t* __restrict__ p_idx, const uint32_t* __restrict__ p_cnt, uint32_t p_stride,
-              uint32_t* __restrict__ cand_off, uint32_t* __restrict__ ncand) {
+k0_prolongate(const uint32_t* __restrict__ chunk_col, const uint32_t* __restrict__ ptile,
+              const TileDesc* __restrict__ tiles, uint32_t nrows, uint32_t beam_in, uint32_t TT, uint32_t cand_stride,
+              int implicit_root, const uint32_t* __restrict__ p_idx, const float* __restrict__ p_val,
+              const uint32_t* __restrict__ p_cnt, uint32_t p_stride, uint32_t* __restrict__ cand_off,
+              uint32_t* __restrict__ ncand, ItemDesc* __restrict__ items) {
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     if (q >= nrows) return;
     const uint32_t cnt = implicit_root ? 1u : min(p_cnt[q], beam_in);
     uint32_t off = 0;
-    for (uint32_t j = 0; j < cnt; ++j) {
-        const uint32_t parent = implicit_root ? 0u : p_idx[(size_t)q * p_stride + j];
-        cand_off[(size_t)q * beam_in + j] = off;
-        off += chunk_col[parent + 1] - chunk_col[parent];
+    for (uint32_t j = 0; j < beam_in; ++j) {
+        ItemDesc* it = items + ((size_t)q * beam_in + j) * TT;
+        uint32_t nt = 0;
+        if (j < cnt) {
+            const uint32_t parent = implicit_root ? 0u : p_idx[(size_t)q * p_stride + j];
+            const float ps = implicit_root ? 1.0f : p_val[(size_t)q * p_stride + j];
+            const uint32_t cb = chunk_col[parent], t0 = ptile[parent];
+            nt = ptile[parent + 1] - t0;
+            cand_off[(size_t)q * beam_in + j] = off;
+            for (uint32_t tt = 0; tt < nt; ++tt)
+                it[tt] = ItemDesc{q, t0 + tt, q * cand_stride + off + (tiles[t0 + tt].col_begin - cb), ps};
+            off += chunk_col[parent + 1] - cb;
+        }
+        for (uint32_t tt = nt; tt < TT; ++tt) it[tt] = ItemDesc{q, kNoTile, 0u, 0.f};
     }
     ncand[q] = off;
 }
 
 void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, BeamDev prev, uint32_t* cand_off,
-                          uint32_t* ncand, hipStream_t s) {
+                          uint32_t* ncand, void* items, hipStream_t s) {
     if (P.nrows == 0) return;
-    hipLaunchKernelGGL(k0_prolongate, dim3((P.nrows + 255) / 256), dim3(256), 0, s, L.chunk_col, P.nrows,
-                       P.beam_in, P.implicit_root, prev.idx, prev.cnt, prev.stride, cand_off, ncand);
+    if ((uint64_t)P.nrows * P.cand_stride > 0xFFFFFFFFull) fail("k0: candidate buffer exceeds 2^32 floats; lower max_batch_rows");
+    hipLaunchKernelGGL(k0_prolongate, dim3((P.nrows + 255) / 256), dim3(256), 0, s, L.chunk_col, L.ptile, L.tiles,
+                       P.nrows, P.beam_in, L.max_tiles_per_parent, P.cand_stride, P.implicit_root, prev.idx, prev.val,
+                       prev.cnt, prev.stride, cand_off, ncand, static_cast<ItemDesc*>(items));
     XRL_LAUNCH_CHECK();
 }
-
-// ---------------------------------------------------------------------------------------------
-// item ordering: counting sort of the layer's (query, beam slot, tile) items by tile id, so that
-// the wavefronts working on one tile run back to back on ONE XCD and find the tile's bitmap /
-// row table / entries in that XCD's L2 (the reference sorts by chunk for the same reason,
-// inference.hpp:991-993).  Order inside a tile is arbitrary (atomics); results do not depend on it.
-// ---------------------------------------------------------------------------------------------
-struct ItemArgs {
-    const uint32_t* ptile;
-    const uint32_t* p_idx; const uint32_t* p_cnt; uint32_t p_stride;
-    uint32_t nrows, beam_in, TT;
-    int implicit_root;
-};
-
-__device__ __forceinline__ bool decode_slot(const ItemArgs& a, uint64_t slot, uint32_t& q, uint32_t& j, uint32_t& tt,
-                                            uint32_t& tile) {
-    tt = (uint32_t)(slot % a.TT);
-    const uint64_t r1 = slot / a.TT;
-    j = (uint32_t)(r1 % a.beam_in);
-    const uint64_t qq = r1 / a.beam_in;
-    if (qq >= a.nrows) return false;
-    q = (uint32_t)qq;
-    uint32_t parent = 0;
-    if (!a.implicit_root) {
-        if (j >= min(a.p_cnt[q], a.beam_in)) return false;
-        parent = a.p_idx[(uint64_t)q * a.p_stride + j];
-    } else if (j != 0) {
-        return false;
-    }
-    const uint32_t t0 = a.ptile[parent], t1 = a.ptile[parent + 1];
-    if (tt >= t1 - t0) return false;
-    tile = t0 + tt;
-    return true;
-}
-
-__global__ void __launch_bounds__(256) sort_count_kernel(ItemArgs a, uint64_t slots, uint32_t* __restrict__ count) {
-    const uint64_t slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (slot >= slots) return;
-    uint32_t q, j, tt, tile;
-    if (decode_slot(a, slot, q, j, tt, tile)) atomicAdd(&count[tile], 1u);
-}
-
-// single block: exclusive scan of count[0..n) in place -> start offsets; count[n] = total; fill[] = 0
-__global__ void __launch_bounds__(1024) sort_scan_kernel(uint32_t* __restrict__ count, uint32_t* __restrict__ fill, uint32_t n) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n ? count[i] : 0u;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            const uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (i < n) { count[i] = carry + part[threadIdx.x] - v; fill[i] = 0u; }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += part[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) count[n] = carry;
-}
-
-__global__ void __launch_bounds__(256)
-sort_scatter_kernel(ItemArgs a, uint64_t slots, const uint32_t* __restrict__ start, uint32_t* __restrict__ fill,
-                    uint2* __restrict__ items) {
-    const uint64_t slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (slot >= slots) return;
-    uint32_t q, j, tt, tile;
-    if (decode_slot(a, slot, q, j, tt, tile)) {
-        const uint32_t pos = start[tile] + atomicAdd(&fill[tile], 1u);
-        items[pos] = make_uint2(q, j | (tt << 16));
-    }
-}
-
-static ItemArgs make_item_args(const LayerDev& L, const LayerPlan& P, const BeamDev& prev) {
-    ItemArgs a;
-    a.ptile = L.ptile; a.p_idx = prev.idx; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
-    a.nrows = P.nrows; a.beam_in = P.beam_in; a.TT = L.max_tiles_per_parent; a.implicit_root = P.implicit_root;
-    return a;
-}
-
-void launch_sort_items(const LayerDev& L, const LayerPlan& P, BeamDev prev, uint32_t* count /*[n_tiles+1]*/,
-                       uint32_t* fill /*[n_tiles]*/, uint2* items, hipStream_t s) {
-    if (P.nrows == 0) return;
-    if (P.beam_in > 0xFFFFu || L.max_tiles_per_parent > 0xFFFFu) fail("sort_items: beam or tiles-per-parent exceed 16 bits");
-    const ItemArgs a = make_item_args(L, P, prev);
-    const uint64_t slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
-    const uint64_t blocks = (slots + 255) / 256;
-    if (blocks > 0x7FFFFFFFull) fail("sort_items: grid too large; lower max_batch_rows");
-    XRL_HIP(hipMemsetAsync(count, 0, ((size_t)L.n_tiles + 1) * 4, s));
-    hipLaunchKernelGGL(sort_count_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a, slots, count);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, count, fill, L.n_tiles);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3((uint32_t)blocks), dim3(256), 0, s, a, slots, count, fill, items);
-    XRL_LAUNCH_CHECK();
-}
+size_t k0_item_bytes() { return sizeof(ItemDesc); }
 
 // ---------------------------------------------------------------------------------------------
 // K1
@@ -220,80 +140,39 @@ void launch_sort_items(const LayerDev& L, const LayerPlan& P, BeamDev prev, uint
 struct K1Args {
     LayerDev L;
     QueriesDev X;
-    BeamDev prev;
-    const uint32_t* cand_off;
+    const ItemDesc* items;
     float* cand;
-    const uint2* items;          // tile-sorted item list, or nullptr (natural order)
-    const uint32_t* n_items;     // device count of valid items (sorted mode)
-    uint32_t row0, nrows, beam_in, cand_stride, acc_stride;
-    int pp_kind, pp_p, first_layer, implicit_root;
+    uint64_t n_slots;
+    uint32_t row0, acc_stride;
+    int pp_kind, pp_p, first_layer;
 };
-
-// XCD-aware block remap (blocks b, b+8, b+16, ... run on one XCD): give every XCD a CONTIGUOUS
-// range of the (tile-sorted) work so a tile's data is fetched into one L2 only.  Bijective.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
-    const uint32_t xcd = b & 7u, q = nb >> 3, r = nb & 7u;
-    const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    return base + (b >> 3);
-}
-
-struct ItemCtx {
-    bool active;
-    uint32_t q, j, parent, tile;
-    float pscore;
-    TileDesc td;
-};
-
-template <int W>
-__device__ __forceinline__ ItemCtx k1_item(const K1Args& a, int grp) {
-    ItemCtx it{};
-    uint64_t slot = (uint64_t)blockIdx.x * W + grp;
-    ItemArgs ia;
-    ia.ptile = a.L.ptile; ia.p_idx = a.prev.idx; ia.p_cnt = a.prev.cnt; ia.p_stride = a.prev.stride;
-    ia.nrows = a.nrows; ia.beam_in = a.beam_in; ia.TT = a.L.max_tiles_per_parent; ia.implicit_root = a.implicit_root;
-    uint32_t tt = 0;
-    if (a.items) {
-        // tile-sorted list: blocks beyond the valid range idle; the valid blocks are remapped so that
-        // every XCD owns a contiguous run of tiles
-        const uint32_t n_items = *a.n_items;
-        const uint32_t nb = (n_items + W - 1) / W;
-        slot = blockIdx.x < nb ? (uint64_t)xcd_remap(blockIdx.x, nb) * W + grp : (uint64_t)n_items;
-        if (slot < n_items) {
-            const uint2 e = a.items[slot];
-            it.q = e.x; it.j = e.y & 0xFFFFu; tt = e.y >> 16;
-            it.parent = a.implicit_root ? 0u : a.prev.idx[(uint64_t)it.q * a.prev.stride + it.j];
-            it.tile = a.L.ptile[it.parent] + tt;
-            it.active = true;
-        }
-    } else {
-        it.active = decode_slot(ia, slot, it.q, it.j, tt, it.tile);
-        if (it.active) it.parent = a.implicit_root ? 0u : a.prev.idx[(uint64_t)it.q * a.prev.stride + it.j];
-    }
-    it.pscore = 1.0f;
-    if (it.active) {
-        if (!a.implicit_root) it.pscore = a.prev.val[(uint64_t)it.q * a.prev.stride + it.j];
-        it.td = a.L.tiles[it.tile];
-    }
-    return it;
-}
 
 template <int G, class ACC>
-__device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemCtx& it, int lig, ACC&& acc_at) {
-    // transform (fp64) + combine with the parent's score, write the child block
-    if (!it.active) return;
-    float* __restrict__ out = a.cand + (uint64_t)it.q * a.cand_stride + a.cand_off[(uint64_t)it.q * a.beam_in + it.j] +
-                              (it.td.col_begin - a.L.chunk_col[it.parent]);
-    for (uint32_t c = lig; c < it.td.ncols; c += G) {
-        float v = pp_transform(a.pp_kind, a.pp_p, acc_at(c));
+__device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it, const TileDesc& td, int lig, ACC&& acc_at,
+                                            bool add_bias) {
+    // bias (sparse X: LAST, inference.hpp:806-811), transform in fp64, combine with the parent's
+    // score (skipped on the first layer), write the child block
+    if (it.tile == kNoTile) return;
+    float* __restrict__ out = a.cand + it.out_off;
+    const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
+    for (uint32_t c = lig; c < td.ncols; c += G) {
+        float acc = acc_at(c);
+        if (add_bias) acc = __fadd_rn(acc, bp[c]);
+        float v = pp_transform(a.pp_kind, a.pp_p, acc);
         if (!a.first_layer) v = pp_combine(a.pp_kind, v, it.pscore);
         out[c] = v;
     }
 }
 
 // ---- sparse queries: chunk_ops<csr, bin_search>, inference.hpp:769-813 --------------------------
+// One wavefront = 64/G items, G lanes each.  Per step every lane fetches U query features
+// (U*G consecutive features per item; all x loads, then all bitmap probes, are in flight together),
+// hits are compacted IN FEATURE ORDER into a small per-item LDS FIFO (segmented ballot/popcount),
+// then one lane per hit fetches the row extent and its first two entries (all hits of all items at
+// once), and finally the rows are applied in order with the G lanes on distinct columns.
 template <int G, int U> struct K1Cfg {
-    static constexpr int W = 64 / G;                                  // items per wavefront
-    static constexpr int H = (2 * U * G > 16) ? 2 * U * G : 16;       // hit-FIFO depth per item
+    static constexpr int W = 64 / G;                      // items per wavefront
+    static constexpr int H = (G > 16) ? G : 16;           // hit-FIFO depth per item (>= G)
     static constexpr size_t lds_bytes(uint32_t acc_stride) { return (size_t)W * acc_stride * 4 + (size_t)W * H * (4 + 4 + 4 + 16); }
 };
 
@@ -309,60 +188,33 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
 
     const int lane = threadIdx.x;
     const int grp = lane / G, lig = lane % G;
-    const ItemCtx it = k1_item<W>(a, grp);
-    const uint32_t ncols = it.active ? it.td.ncols : 0u;
-    const uint32_t* __restrict__ rp = a.L.row_ptr + it.td.rowptr_base;
-    const Entry* __restrict__ ent = a.L.entries + it.td.ent_base;
+    const uint64_t slot = (uint64_t)blockIdx.x * W + grp;
+    ItemDesc it{0u, kNoTile, 0u, 0.f};
+    if (slot < a.n_slots) it = a.items[slot];
+    const bool active = it.tile != kNoTile;
+    TileDesc td{};
+    uint64_t xe = 0, cur = 0;
+    if (active) {
+        td = a.L.tiles[it.tile];
+        const uint64_t qg = (uint64_t)a.row0 + it.q;
+        cur = a.X.row_ptr[qg]; xe = a.X.row_ptr[qg + 1];
+    }
+    const uint32_t* __restrict__ rp = a.L.row_ptr + td.rowptr_base;
+    const Entry* __restrict__ ent = a.L.entries + td.ent_base;
     float* __restrict__ my_acc = acc + (size_t)grp * a.acc_stride;
     const uint32_t fbase = (uint32_t)grp * H;
-
-    for (uint32_t c = lig; c < ncols; c += G) my_acc[c] = 0.0f;        // std::fill(..., 0.0), inference.hpp:964
+    for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = 0.0f;     // std::fill(..., 0.0), inference.hpp:964
     wave_sync_lds();
 
-    uint64_t xe = 0, cur = 0;
-    if (it.active) { const uint64_t qg = (uint64_t)a.row0 + it.q; cur = a.X.row_ptr[qg]; xe = a.X.row_ptr[qg + 1]; }
     const uint32_t* __restrict__ xi = a.X.col_idx;
     const float* __restrict__ xv = a.X.val;
-    const BmWord* __restrict__ bm = a.L.bitmap + (uint64_t)it.tile * a.L.nwords;
+    const BmWord* __restrict__ bm = a.L.bitmap + (uint64_t)(active ? it.tile : 0u) * a.L.nwords;
     const unsigned long long below = (1ull << lig) - 1ull;
+    uint32_t nh = 0;                                                   // hits waiting in this item's FIFO
 
-    do {
-        // ---- fill: U*G consecutive features of the item per step; all x loads, then all bitmap
-        //      probes are issued together; hits are compacted IN FEATURE ORDER into the FIFO
-        uint32_t nh = 0;
-        while (__any(cur < xe && nh + U * G <= (uint32_t)H)) {
-            const bool can = (cur < xe) && (nh + U * G <= (uint32_t)H);
-            uint32_t f[U]; float v[U]; bool ok[U]; BmWord w[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint64_t t = cur + (uint64_t)(u * G + lig);
-                ok[u] = can && t < xe;
-                f[u] = ok[u] ? xi[t] : 0xFFFFFFFFu;
-                v[u] = ok[u] ? xv[t] : 0.f;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                ok[u] = ok[u] && f[u] < a.L.w_rows;
-                w[u] = ok[u] ? bm[f[u] >> 5] : BmWord{0u, 0u};
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t b = f[u] & 31u;
-                const bool hit = ok[u] && ((w[u].bits >> b) & 1u);
-                const unsigned long long m = __ballot(hit);
-                const unsigned long long gm = (G == 64) ? m : ((m >> (grp * G)) & ((1ull << G) - 1ull));
-                if (hit) {
-                    const uint32_t pos = fbase + nh + (uint32_t)__popcll(gm & below);
-                    fv[pos] = v[u];
-                    fa[pos] = w[u].rank + __popc(w[u].bits & ((1u << b) - 1u));
-                }
-                nh += (uint32_t)__popcll(gm);
-            }
-            if (can) cur += U * G;
-        }
+    auto drain = [&]() {
         wave_sync_lds();
-        // ---- D1/D2: one lane per hit fetches the row extent and its first two entries (all hits of
-        //      all items in flight at once -> two dependent memory latencies per batch, not per hit)
+        // one lane per hit: row extent + first two entries (two dependent latencies for the whole batch)
         for (uint32_t h = lig; h < nh; h += G) {
             const uint32_t s = fa[fbase + h];
             const uint32_t rs = rp[s], len = rp[s + 1] - rs;
@@ -372,7 +224,7 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
             fa[fbase + h] = rs; fl[fbase + h] = len; fe[fbase + h] = e2;
         }
         wave_sync_lds();
-        // ---- D3: rows in feature order; inside a row the lanes take distinct columns
+        // rows in feature order; inside a row the lanes take distinct columns
         for (uint32_t h = 0; __any(h < nh); ++h) {
             if (h < nh) {
                 const float v = fv[fbase + h];
@@ -390,16 +242,51 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
             }
             wave_sync_lds();
         }
-    } while (__any(cur < xe));
-    // bias LAST (inference.hpp:806-811)
-    if (it.active && it.td.bias_slot != kNoBias) {
-        for (uint32_t e = rp[it.td.bias_slot] + lig; e < rp[it.td.bias_slot + 1]; e += G) {
-            const Entry en = ent[e];
-            my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(a.L.bias, en.val));
+        nh = 0;
+    };
+
+    while (__any(cur < xe)) {
+        // ---- load step: U*G consecutive features of the item
+        uint32_t f[U]; float v[U]; BmWord w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t t = cur + (uint64_t)(u * G + lig);
+            const bool ok = t < xe;
+            f[u] = ok ? xi[t] : 0xFFFFFFFFu;
+            v[u] = ok ? xv[t] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = (f[u] < a.L.w_rows) ? bm[f[u] >> 5] : BmWord{0u, 0u};
+        if (cur < xe) cur += (uint64_t)U * G;
+        // ---- push hits into the FIFO in feature order; when an item's FIFO is full, drain and resume
+        uint32_t uptr = 0;
+        do {
+            bool stopped = false;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t b = f[u] & 31u;
+                const bool hit = (f[u] < a.L.w_rows) && ((w[u].bits >> b) & 1u);
+                const unsigned long long m = __ballot(hit);
+                const unsigned long long gm = (G == 64) ? m : ((m >> (grp * G)) & ((1ull << G) - 1ull));
+                const uint32_t cnt = (uint32_t)__popcll(gm);
+                if ((uint32_t)u >= uptr && !stopped) {
+                    if (nh + cnt <= (uint32_t)H) {
+                        if (hit) {
+                            const uint32_t pos = fbase + nh + (uint32_t)__popcll(gm & below);
+                            fv[pos] = v[u];
+                            fa[pos] = w[u].rank + __popc(w[u].bits & ((1u << b) - 1u));
+                        }
+                        nh += cnt; uptr = u + 1;
+                    } else {
+                        stopped = true;
+                    }
+                }
+            }
+            if (__any(uptr < (uint32_t)U)) drain();
+        } while (__any(uptr < (uint32_t)U));
     }
-    wave_sync_lds();
-    k1_epilogue<G>(a, it, lig, [&](uint32_t c) { return my_acc[c]; });
+    drain();
+    k1_epilogue<G>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0);
 }
 
 // ---- dense queries: chunk_ops<drm, bin_search>, inference.hpp:815-839 (bias FIRST, every row) -----
@@ -410,24 +297,23 @@ __global__ void __launch_bounds__(64) k1_dense_kernel(K1Args a) {
     float* acc = reinterpret_cast<float*>(smem);
     const int lane = threadIdx.x;
     const int grp = lane / G, lig = lane % G;
-    const ItemCtx it = k1_item<W>(a, grp);
-    const uint32_t ncols = it.active ? it.td.ncols : 0u;
-    const uint32_t* __restrict__ rp = a.L.row_ptr + it.td.rowptr_base;
-    const Entry* __restrict__ ent = a.L.entries + it.td.ent_base;
+    const uint64_t slot = (uint64_t)blockIdx.x * W + grp;
+    ItemDesc it{0u, kNoTile, 0u, 0.f};
+    if (slot < a.n_slots) it = a.items[slot];
+    const bool active = it.tile != kNoTile;
+    TileDesc td{};
+    if (active) td = a.L.tiles[it.tile];
+    const uint32_t* __restrict__ rp = a.L.row_ptr + td.rowptr_base;
+    const Entry* __restrict__ ent = a.L.entries + td.ent_base;
     float* __restrict__ my_acc = acc + (size_t)grp * a.acc_stride;
-    for (uint32_t c = lig; c < ncols; c += G) my_acc[c] = 0.0f;
+    const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
+    // bias first: acc = 0.0f + bias*w (bias_prod already holds 0.0f + product)
+    for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = a.L.has_bias ? bp[c] : 0.0f;
     wave_sync_lds();
     const float* __restrict__ xd = a.X.val + ((uint64_t)a.row0 + it.q) * a.X.cols;
-    const uint32_t* __restrict__ ridx = a.L.row_idx + (it.td.rowptr_base - it.tile);
-    uint32_t nr = it.active ? it.td.nrows : 0u;
-    if (it.active && it.td.bias_slot != kNoBias) {
-        for (uint32_t e = rp[it.td.bias_slot] + lig; e < rp[it.td.bias_slot + 1]; e += G) {
-            const Entry en = ent[e];
-            my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(a.L.bias, en.val));
-        }
-        nr -= 1;
-    }
-    wave_sync_lds();
+    const uint32_t* __restrict__ ridx = a.L.row_idx + (td.rowptr_base - (active ? it.tile : 0u));
+    uint32_t nr = active ? td.nrows : 0u;
+    if (active && td.bias_slot != kNoBias) nr -= 1;                    // the bias row is the last row
     for (uint32_t s = 0; __any(s < nr); ++s) {
         if (s < nr) {
             const uint32_t f = ridx[s];
@@ -441,15 +327,15 @@ __global__ void __launch_bounds__(64) k1_dense_kernel(K1Args a) {
         }
         wave_sync_lds();
     }
-    k1_epilogue<G>(a, it, lig, [&](uint32_t c) { return my_acc[c]; });
+    k1_epilogue<G>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, false);
 }
 
 template <class KERNEL>
-static void launch_k1_any(KERNEL kernel, const K1Args& a, uint64_t slots, int W, size_t lds, hipStream_t s) {
+static void launch_k1_any(KERNEL kernel, const K1Args& a, int W, size_t lds, hipStream_t s) {
     if (lds > 160 * 1024) fail("k1: LDS request exceeds 160 KiB");
     if (lds > 48 * 1024)
         XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t blocks = (slots + W - 1) / W;
+    const uint64_t blocks = (a.n_slots + W - 1) / W;
     if (blocks > 0x7FFFFFFFull) fail("k1: grid too large; lower max_batch_rows");
     hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(64), lds, s, a);
     XRL_LAUNCH_CHECK();
@@ -465,24 +351,22 @@ int k1_auto_group(const LayerDev& L, const Layer& host, int dense) {
     return g;
 }
 
-void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev,
-               const uint32_t* cand_off, float* cand, const uint2* items, const uint32_t* n_items, int group,
+void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, float* cand, int group,
                hipStream_t s) {
     if (P.nrows == 0) return;
     K1Args a;
-    a.L = L; a.X = X; a.prev = prev; a.cand_off = cand_off; a.cand = cand; a.items = items; a.n_items = n_items;
-    a.row0 = P.row0; a.nrows = P.nrows; a.beam_in = P.beam_in; a.cand_stride = P.cand_stride;
-    a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer; a.implicit_root = P.implicit_root;
+    a.L = L; a.X = X; a.items = static_cast<const ItemDesc*>(items); a.cand = cand;
+    a.n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
+    a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
     a.acc_stride = L.max_tile_cols | 1u;
-    const uint64_t slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
     if (X.dense) {
-#define XRL_K1D(GG) case GG: launch_k1_any(&k1_dense_kernel<GG>, a, slots, 64 / GG, (size_t)(64 / GG) * a.acc_stride * 4, s); break;
+#define XRL_K1D(GG) case GG: launch_k1_any(&k1_dense_kernel<GG>, a, 64 / GG, (size_t)(64 / GG) * a.acc_stride * 4, s); break;
         switch (group) { XRL_K1D(1) XRL_K1D(2) XRL_K1D(4) XRL_K1D(8) XRL_K1D(16) XRL_K1D(32) XRL_K1D(64)
         default: fail("k1: lanes-per-item must be a power of two in [1, 64]"); }
 #undef XRL_K1D
     } else {
-#define XRL_K1S(GG, UU) case GG: launch_k1_any(&k1_sparse_kernel<GG, UU>, a, slots, 64 / GG, K1Cfg<GG, UU>::lds_bytes(a.acc_stride), s); break;
-        switch (group) { XRL_K1S(1, 8) XRL_K1S(2, 8) XRL_K1S(4, 4) XRL_K1S(8, 2) XRL_K1S(16, 2) XRL_K1S(32, 1) XRL_K1S(64, 1)
+#define XRL_K1S(GG, UU) case GG: launch_k1_any(&k1_sparse_kernel<GG, UU>, a, 64 / GG, K1Cfg<GG, UU>::lds_bytes(a.acc_stride), s); break;
+        switch (group) { XRL_K1S(1, 8) XRL_K1S(2, 8) XRL_K1S(4, 8) XRL_K1S(8, 8) XRL_K1S(16, 4) XRL_K1S(32, 2) XRL_K1S(64, 1)
         default: fail("k1: lanes-per-item must be a power of two in [1, 64]"); }
 #undef XRL_K1S
     }

@@ -206,6 +206,19 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         chunk_alg[p] = (float)(8.0 * E + 4.0 * R + (R ? 4.0 * (R + 1) : 0.0));
     }
 
+    // bias contribution of every child column: the reference adds fl32(bias * w) to the column's
+    // accumulator (inference.hpp:806-811 / :824-830); columns without an explicit bias entry add
+    // nothing, and acc + (+0.0f) == acc for every reachable acc, so a dense vector is equivalent.
+    std::vector<float> bias_prod(c_nnz, 0.0f);
+    if (has_bias) {
+        for (uint32_t c = 0; c < (uint32_t)c_nnz; ++c) {
+            const uint32_t oc = orig_col(c);
+            const uint64_t cb = W.col_ptr[oc], ce = W.col_ptr[oc + 1];
+            for (uint64_t e = cb; e < ce; ++e)
+                if (W.row_idx[e] == W.rows - 1) { volatile float pr = bias * W.val[e]; bias_prod[c] = 0.0f + pr; }
+        }
+    }
+    L->d_bias_prod.upload(bias_prod);
     L->d_tiles.upload(tiles); L->d_ptile.upload(ptile); L->d_chunk_col.upload(chunk_col);
     L->d_bitmap.upload(bitmap); L->d_row_ptr.upload(row_ptr); L->d_row_idx.upload(row_idx);
     L->d_entries.upload(entries); L->d_chunk_alg.upload(chunk_alg);
@@ -214,13 +227,14 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         L->d_perm_inv.upload(perm_inv);
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
-                      L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap;
+                      L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap;
 
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
     d.bitmap = L->d_bitmap.as<BmWord>(); d.row_ptr = L->d_row_ptr.as<uint32_t>(); d.row_idx = L->d_row_idx.as<uint32_t>();
     d.entries = L->d_entries.as<Entry>(); d.perm_inv = contiguous ? nullptr : L->d_perm_inv.as<uint32_t>();
     d.chunk_alg_bytes = L->d_chunk_alg.as<float>();
+    d.bias_prod = L->d_bias_prod.as<float>();
     d.n_parents = P; d.n_children = L->n_children; d.n_tiles = T; d.nwords = L->nwords; d.w_rows = W.rows;
     d.max_tiles_per_parent = L->max_tiles_per_parent; d.max_tile_cols = L->max_tile_cols;
     d.bias = bias; d.has_bias = has_bias ? 1 : 0;

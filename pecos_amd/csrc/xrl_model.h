@@ -55,6 +55,7 @@ struct LayerDev {
     const Entry* entries;        // [nnz]
     const uint32_t* perm_inv;    // [n_children] rearranged -> original child id, or nullptr
     const float* chunk_alg_bytes;  // [n_parents] algorithmic bytes of the reference chunk (stats)
+    const float* bias_prod;      // [n_children] fl32(bias * W[bias_row, child]) or +0.0 (no explicit entry / no bias)
     uint32_t n_parents, n_children, n_tiles, nwords, w_rows;
     uint32_t max_tiles_per_parent, max_tile_cols;
     float bias;
@@ -74,7 +75,7 @@ struct Layer {
     uint64_t nnz = 0, total_rows = 0;
     std::vector<uint32_t> chunk_sizes_desc;  // chunk sizes sorted descending (cand stride bound)
     // device storage
-    DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg;
+    DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
     LayerDev dev{};
     uint64_t device_bytes = 0;
     // sum of the `beam` largest chunks: upper bound on candidates per query entering this layer
@@ -88,7 +89,7 @@ struct PendingEvent { hipEvent_t a, b; size_t slot; };
 struct Workspace {
     DevBuf beam_idx[2], beam_val[2], beam_cnt[2];
     DevBuf cand_off, ncand, cand, stats;
-    DevBuf sort_count, sort_fill, items;     // tile-sorted item list
+    DevBuf items;                            // per-layer item descriptors written by K0
     // host-ABI predict: uploaded X + result staging
     DevBuf x_ptr, x_idx, x_val;
     DevBuf out_idx, out_val, out_cnt;
@@ -107,7 +108,6 @@ struct Model {
     std::unique_ptr<Workspace> ws;
     // options
     int k1_group = 0;                       // 0 = auto
-    int sort_items = -1;                    // -1 = auto
     int64_t max_batch_rows = 0;             // 0 = auto
     bool profiling = false;
     std::vector<ProfileSlot> profile;

@@ -73,6 +73,9 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         ws.beam_val[i].reserve(nb * beam_stride * 4);
         ws.beam_cnt[i].reserve(nb * 4);
     }
+    uint64_t slots_max = 1;
+    for (size_t l = 0; l < T; ++l) slots_max = std::max<uint64_t>(slots_max, nb * beam_in[l] * m.layers[l]->max_tiles_per_parent);
+    ws.items.reserve(slots_max * k0_item_bytes());
     ws.cand_off.reserve(nb * bin_max * 4);
     ws.ncand.reserve(nb * 4);
     ws.cand.reserve(nb * (uint64_t)cs_max * 4);
@@ -113,18 +116,8 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             else { const int b = (int)(l & 1); oi = ws.beam_idx[b].as<uint32_t>(); ov = ws.beam_val[b].as<float>(); oc = ws.beam_cnt[b].as<uint32_t>(); os = beam_stride; }
 
             int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
-            // tile-sorted item order once a layer has enough tiles for locality to matter
-            const bool sorted = m.sort_items > 0;   // off by default: measured slower than it saves (atomics), see DESIGN.md
-            const uint2* items = nullptr; const uint32_t* n_items = nullptr;
-            if (sorted) {
-                const uint64_t slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
-                ws.sort_count.reserve(((size_t)L.n_tiles + 1) * 4); ws.sort_fill.reserve((size_t)L.n_tiles * 4);
-                ws.items.reserve(slots * 8);
-                items = ws.items.as<uint2>(); n_items = ws.sort_count.as<uint32_t>() + L.n_tiles;
-            }
-            timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), stream); });
-            if (sorted) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, P, prev, ws.sort_count.as<uint32_t>(), ws.sort_fill.as<uint32_t>(), ws.items.as<uint2>(), stream); });
-            timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] { launch_k1(L.dev, P, X, prev, ws.cand_off.as<uint32_t>(), ws.cand.as<float>(), items, n_items, g, stream); });
+            timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.items.p, stream); });
+            timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] { launch_k1(L.dev, P, X, ws.items.p, ws.cand.as<float>(), g, stream); });
             timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.cand.as<float>(), oi, ov, oc, os, stream); });
             if (o.stats_out) launch_stats(L.dev, P, prev, ws.ncand.as<uint32_t>(), ws.stats.as<double>() + 2 * l, stream);
         }
