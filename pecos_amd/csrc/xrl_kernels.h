@@ -54,6 +54,7 @@ void launch_k3_inner_products(const uint64_t* x_ptr, const uint32_t* x_idx, cons
                               uint32_t dim, uint64_t len, const uint32_t* rows, const uint32_t* cols,
                               float* out, hipStream_t s);
 
+void k1_set_ablate(int mask);   // debug only
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
 size_t k2_max_k();
 

@@ -145,6 +145,7 @@ struct K1Args {
     uint64_t n_slots;
     uint32_t row0, acc_stride;
     int pp_kind, pp_p, first_layer;
+    int ablate;                  // debug: phase-skipping mask for timing ablations (0 in production)
 };
 
 template <int G, class ACC>
@@ -152,13 +153,13 @@ __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it,
                                             bool add_bias) {
     // bias (sparse X: LAST, inference.hpp:806-811), transform in fp64, combine with the parent's
     // score (skipped on the first layer), write the child block
-    if (it.tile == kNoTile) return;
+    if (it.tile == kNoTile || (a.ablate & 16)) return;
     float* __restrict__ out = a.cand + it.out_off;
     const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
     for (uint32_t c = lig; c < td.ncols; c += G) {
         float acc = acc_at(c);
         if (add_bias) acc = __fadd_rn(acc, bp[c]);
-        float v = pp_transform(a.pp_kind, a.pp_p, acc);
+        float v = (a.ablate & 8) ? acc : pp_transform(a.pp_kind, a.pp_p, acc);
         if (!a.first_layer) v = pp_combine(a.pp_kind, v, it.pscore);
         out[c] = v;
     }
@@ -172,16 +173,17 @@ __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it,
 // once), and finally the rows are applied in order with the G lanes on distinct columns.
 template <int G, int U> struct K1Cfg {
     static constexpr int W = 64 / G;                      // items per wavefront
-    static constexpr int H = (G > 16) ? G : 16;           // hit-FIFO depth per item (>= G)
-    static constexpr size_t lds_bytes(uint32_t acc_stride) { return (size_t)W * acc_stride * 4 + (size_t)W * H * (4 + 4 + 4 + 16); }
+    static constexpr int H = (G > 32) ? 2 * G : 64;       // hit-FIFO depth per item (>= G)
+    static constexpr int P = 4;                           // hit rows whose entries are in flight together
+    static constexpr int NS = (G == 64) ? 2 : 1;          // G-wide slices of a row fetched up front
+    static constexpr size_t lds_bytes(uint32_t acc_stride) { return (size_t)W * acc_stride * 4 + (size_t)W * H * 12; }
 };
 
 template <int G, int U>
 __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
-    constexpr int W = K1Cfg<G, U>::W, H = K1Cfg<G, U>::H;
+    constexpr int W = K1Cfg<G, U>::W, H = K1Cfg<G, U>::H, P = K1Cfg<G, U>::P, NS = K1Cfg<G, U>::NS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* fe = reinterpret_cast<uint4*>(smem);                        // first two entries of the hit row
-    float* acc = reinterpret_cast<float*>(fe + W * H);
+    float* acc = reinterpret_cast<float*>(smem);
     float* fv = acc + (size_t)W * a.acc_stride;                        // x value of the hit
     uint32_t* fa = reinterpret_cast<uint32_t*>(fv + W * H);            // row slot, then row start
     uint32_t* fl = fa + W * H;                                         // row length
@@ -203,8 +205,9 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
     const Entry* __restrict__ ent = a.L.entries + td.ent_base;
     float* __restrict__ my_acc = acc + (size_t)grp * a.acc_stride;
     const uint32_t fbase = (uint32_t)grp * H;
-    for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = 0.0f;     // std::fill(..., 0.0), inference.hpp:964
+    if (!(a.ablate & 32)) for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = 0.0f;   // std::fill(..., 0.0), inference.hpp:964
     wave_sync_lds();
+    if (a.ablate & 2) cur = xe;
 
     const uint32_t* __restrict__ xi = a.X.col_idx;
     const float* __restrict__ xv = a.X.val;
@@ -213,34 +216,43 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
     uint32_t nh = 0;                                                   // hits waiting in this item's FIFO
 
     auto drain = [&]() {
+        if (a.ablate & 4) { nh = 0; return; }
         wave_sync_lds();
-        // one lane per hit: row extent + first two entries (two dependent latencies for the whole batch)
+        // one lane per hit: row extent (all hits of all items in flight at once)
         for (uint32_t h = lig; h < nh; h += G) {
             const uint32_t s = fa[fbase + h];
-            const uint32_t rs = rp[s], len = rp[s + 1] - rs;
-            uint4 e2 = make_uint4(0u, 0u, 0u, 0u);
-            if (len >= 2) { const Entry e0 = ent[rs], e1 = ent[rs + 1]; e2 = make_uint4(e0.col, __float_as_uint(e0.val), e1.col, __float_as_uint(e1.val)); }
-            else if (len == 1) { const Entry e0 = ent[rs]; e2.x = e0.col; e2.y = __float_as_uint(e0.val); }
-            fa[fbase + h] = rs; fl[fbase + h] = len; fe[fbase + h] = e2;
+            const uint32_t rs = rp[s];
+            fa[fbase + h] = rs; fl[fbase + h] = rp[s + 1] - rs;
         }
         wave_sync_lds();
-        // rows in feature order; inside a row the lanes take distinct columns
-        for (uint32_t h = 0; __any(h < nh); ++h) {
-            if (h < nh) {
-                const float v = fv[fbase + h];
-                const uint32_t len = fl[fbase + h];
-                const uint32_t rs = fa[fbase + h];
-                const uint4 e2 = fe[fbase + h];
-                for (uint32_t e = lig; e < len; e += G) {
-                    uint32_t col; float wv;
-                    if (e == 0) { col = e2.x; wv = __uint_as_float(e2.y); }
-                    else if (e == 1) { col = e2.z; wv = __uint_as_float(e2.w); }
-                    else { const Entry en = ent[rs + e]; col = en.col; wv = en.val; }
-                    // out[col] += scalar * val (inference.hpp:512-517): mul then add, no fma
-                    my_acc[col] = __fadd_rn(my_acc[col], __fmul_rn(v, wv));
-                }
+        // rows in feature order, P rows' entries in flight together; inside a row the G lanes take
+        // distinct columns, so only the order BETWEEN rows matters (LDS ops of a wave are in order)
+        for (uint32_t h0 = 0; __any(h0 < nh); h0 += P) {
+            float vv[P]; uint32_t rs[P], ln[P]; Entry e[P][NS];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const bool ok = h0 + p < nh;
+                vv[p] = ok ? fv[fbase + h0 + p] : 0.f;
+                rs[p] = ok ? fa[fbase + h0 + p] : 0u;
+                ln[p] = ok ? fl[fbase + h0 + p] : 0u;
             }
-            wave_sync_lds();
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+                    if ((uint32_t)(lig + k * G) < ln[p]) e[p][k] = ent[rs[p] + lig + k * G];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+                    if ((uint32_t)(lig + k * G) < ln[p])   // out[col] += scalar * val (inference.hpp:512-517): mul then add, no fma
+                        my_acc[e[p][k].col] = __fadd_rn(my_acc[e[p][k].col], __fmul_rn(vv[p], e[p][k].val));
+                for (uint32_t x = lig + NS * G; x < ln[p]; x += G) {   // rows longer than NS*G (forced small G)
+                    const Entry en = ent[rs[p] + x];
+                    my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(vv[p], en.val));
+                }
+                wave_sync_lds();
+            }
         }
         nh = 0;
     };
@@ -256,7 +268,7 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
             v[u] = ok ? xv[t] : 0.f;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = (f[u] < a.L.w_rows) ? bm[f[u] >> 5] : BmWord{0u, 0u};
+        for (int u = 0; u < U; ++u) w[u] = (f[u] < a.L.w_rows && !(a.ablate & 1)) ? bm[f[u] >> 5] : BmWord{0u, 0u};
         if (cur < xe) cur += (uint64_t)U * G;
         // ---- push hits into the FIFO in feature order; when an item's FIFO is full, drain and resume
         uint32_t uptr = 0;
@@ -341,13 +353,15 @@ static void launch_k1_any(KERNEL kernel, const K1Args& a, int W, size_t lds, hip
     XRL_LAUNCH_CHECK();
 }
 
+int g_k1_ablate = 0;
+void k1_set_ablate(int mask) { g_k1_ablate = mask; }
+
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense) {
-    // lanes per item: enough to cover a typical tile row, and at least 8 so that the x reads of an
-    // item coalesce into >= 32-byte segments and a wavefront's LDS stays small
-    const double row_len = host.total_rows ? (double)host.nnz / (double)host.total_rows : 1.0;
-    int g = dense ? 16 : 8;
-    while (g < 64 && g < row_len * 0.75) g <<= 1;
-    (void)L;
+    // lanes per item = smallest power of two covering the widest tile (one G-wide slice holds a whole
+    // tile row; G == 64 fetches two slices), at least 8 so that x reads coalesce
+    int g = 8;
+    while (g < 64 && (uint32_t)g < L.max_tile_cols) g <<= 1;
+    (void)host; (void)dense;
     return g;
 }
 
@@ -359,6 +373,7 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     a.n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
     a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
     a.acc_stride = L.max_tile_cols | 1u;
+    a.ablate = g_k1_ablate;
     if (X.dense) {
 #define XRL_K1D(GG) case GG: launch_k1_any(&k1_dense_kernel<GG>, a, 64 / GG, (size_t)(64 / GG) * a.acc_stride * 4, s); break;
         switch (group) { XRL_K1D(1) XRL_K1D(2) XRL_K1D(4) XRL_K1D(8) XRL_K1D(16) XRL_K1D(32) XRL_K1D(64)
@@ -366,7 +381,7 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
 #undef XRL_K1D
     } else {
 #define XRL_K1S(GG, UU) case GG: launch_k1_any(&k1_sparse_kernel<GG, UU>, a, 64 / GG, K1Cfg<GG, UU>::lds_bytes(a.acc_stride), s); break;
-        switch (group) { XRL_K1S(1, 8) XRL_K1S(2, 8) XRL_K1S(4, 8) XRL_K1S(8, 8) XRL_K1S(16, 4) XRL_K1S(32, 2) XRL_K1S(64, 1)
+        switch (group) { XRL_K1S(1, 8) XRL_K1S(2, 8) XRL_K1S(4, 8) XRL_K1S(8, 8) XRL_K1S(16, 4) XRL_K1S(32, 2) XRL_K1S(64, 2)
         default: fail("k1: lanes-per-item must be a power of two in [1, 64]"); }
 #undef XRL_K1S
     }
