@@ -180,7 +180,7 @@ uint32_t xrl_profile_get(void* model, xrl_profile_rec_t* out, uint32_t cap);
 int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char* post_processor,
                       uint32_t only_topk, double* stats_out, uint32_t stats_cap);
 
-/* Tuning knobs (benchmark / tests only): key in {"k1_group", "max_batch_rows"} */
+/* Tuning knobs (benchmark / tests only): key in {"k1_group", "max_batch_rows", "sort_min_tiles"} */
 int xrl_set_option(void* model, const char* key, int64_t value);
 
 /* Bytes of HBM held by the compiled model. */

@@ -39,8 +39,13 @@ void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, BeamDev prev, u
                           uint32_t* ncand, void* items, hipStream_t s);
 size_t k0_item_bytes();
 // K1  (query, tile) inner products + bias + post-processor + combine, one item per G lanes.
-void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, float* cand, int group,
-               hipStream_t s);
+void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, const uint32_t* n_items,
+               float* cand, int group, hipStream_t s);
+// counting sort of the item descriptors by tile (LDS histograms, no global atomics); start[n_tiles] = #items
+void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, void* sorted, uint32_t* H,
+                       uint32_t* start, hipStream_t s);
+uint32_t sort_max_tiles();
+size_t sort_hist_bytes(uint64_t n_slots, uint32_t n_tiles);
 // K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,

@@ -135,12 +135,117 @@ void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, BeamDev prev, u
 size_t k0_item_bytes() { return sizeof(ItemDesc); }
 
 // ---------------------------------------------------------------------------------------------
+// Item ordering: counting sort of the layer's item descriptors by tile id, so that the wavefronts
+// working on one tile run back to back on ONE XCD and find the tile's bitmap / rows / entries in
+// that XCD's L2 instead of HBM (the reference sorts its (query, chunk) pairs by chunk for the same
+// reason, inference.hpp:991-993).  Device-scope atomics are slow across the 8 XCDs, so the sort
+// uses only LDS atomics: per-block LDS histograms -> per-(block, tile) offsets -> LDS-ranked
+// scatter.  Order inside a tile is arbitrary; results do not depend on it.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSortChunk = 8192;    // item slots per block
+
+__global__ void __launch_bounds__(256)
+sort_hist_kernel(const ItemDesc* __restrict__ items, uint64_t n_slots, uint32_t T, uint32_t* __restrict__ H) {
+    extern __shared__ uint32_t hist[];
+    for (uint32_t t = threadIdx.x; t < T; t += 256) hist[t] = 0;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
+    for (uint32_t i = threadIdx.x; i < kSortChunk && base + i < n_slots; i += 256) {
+        const uint32_t tile = items[base + i].tile;
+        if (tile != kNoTile) atomicAdd(&hist[tile], 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < T; t += 256) H[(size_t)blockIdx.x * T + t] = hist[t];
+}
+
+// per tile: exclusive running sum over blocks (in place), total per tile
+__global__ void __launch_bounds__(256)
+sort_colsum_kernel(uint32_t* __restrict__ H, uint32_t B, uint32_t T, uint32_t* __restrict__ total) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= T) return;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < B; ++b) { const uint32_t c = H[(size_t)b * T + t]; H[(size_t)b * T + t] = run; run += c; }
+    total[t] = run;
+}
+
+// single block: exclusive scan of v[0..n) in place; v[n] = grand total
+__global__ void __launch_bounds__(1024) sort_scan_kernel(uint32_t* __restrict__ v, uint32_t n) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t x = i < n ? v[i] : 0u;
+        part[threadIdx.x] = x;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) v[i] = carry + part[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) v[n] = carry;
+}
+
+__global__ void __launch_bounds__(256)
+sort_scatter_kernel(const ItemDesc* __restrict__ items, uint64_t n_slots, uint32_t T, const uint32_t* __restrict__ H,
+                    const uint32_t* __restrict__ start, ItemDesc* __restrict__ sorted) {
+    extern __shared__ uint32_t pos[];
+    for (uint32_t t = threadIdx.x; t < T; t += 256) pos[t] = start[t] + H[(size_t)blockIdx.x * T + t];
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
+    for (uint32_t i = threadIdx.x; i < kSortChunk && base + i < n_slots; i += 256) {
+        const ItemDesc d = items[base + i];
+        if (d.tile != kNoTile) sorted[atomicAdd(&pos[d.tile], 1u)] = d;
+    }
+}
+
+uint32_t sort_max_tiles() { return 36864; }   // LDS histogram: 4 B per tile, <= 144 KiB
+size_t sort_hist_bytes(uint64_t n_slots, uint32_t T) { return ((n_slots + kSortChunk - 1) / kSortChunk) * (size_t)T * 4; }
+
+void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, void* sorted, uint32_t* H,
+                       uint32_t* start /*[n_tiles+1]*/, hipStream_t s) {
+    if (n_slots == 0) return;
+    const uint32_t T = L.n_tiles;
+    if (T > sort_max_tiles()) fail("sort_items: too many tiles for the LDS histogram");
+    const uint32_t B = (uint32_t)((n_slots + kSortChunk - 1) / kSortChunk);
+    const size_t lds = (size_t)T * 4;
+    static thread_local size_t configured = 0;
+    if (lds > 48 * 1024 && lds > configured) {
+        XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(B), dim3(256), lds, s, static_cast<const ItemDesc*>(items), n_slots, T, H);
+    hipLaunchKernelGGL(sort_colsum_kernel, dim3((T + 255) / 256), dim3(256), 0, s, H, B, T, start);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, start, T);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(B), dim3(256), lds, s, static_cast<const ItemDesc*>(items), n_slots, T, H,
+                       start, static_cast<ItemDesc*>(sorted));
+    XRL_LAUNCH_CHECK();
+}
+
+// XCD-aware block remap (blocks b, b+8, b+16, ... run on one XCD): give every XCD a CONTIGUOUS
+// range of the tile-sorted work so a tile's data is fetched into one L2 only.  Bijective on [0, nb).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
+    const uint32_t xcd = b & 7u, q = nb >> 3, r = nb & 7u;
+    const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + (b >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1
 // ---------------------------------------------------------------------------------------------
 struct K1Args {
     LayerDev L;
     QueriesDev X;
     const ItemDesc* items;
+    const uint32_t* n_items;     // device count of (tile-sorted, all active) items, or nullptr: natural order
     float* cand;
     uint64_t n_slots;
     uint32_t row0, acc_stride;
@@ -190,9 +295,14 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
 
     const int lane = threadIdx.x;
     const int grp = lane / G, lig = lane % G;
-    const uint64_t slot = (uint64_t)blockIdx.x * W + grp;
     ItemDesc it{0u, kNoTile, 0u, 0.f};
-    if (slot < a.n_slots) it = a.items[slot];
+    if (a.n_items) {   // tile-sorted list: every XCD takes a contiguous run of tiles
+        const uint32_t n = *a.n_items, nb = (n + W - 1) / W;
+        if (blockIdx.x < nb) { const uint64_t slot = (uint64_t)xcd_remap(blockIdx.x, nb) * W + grp; if (slot < n) it = a.items[slot]; }
+    } else {
+        const uint64_t slot = (uint64_t)blockIdx.x * W + grp;
+        if (slot < a.n_slots) it = a.items[slot];
+    }
     const bool active = it.tile != kNoTile;
     TileDesc td{};
     uint64_t xe = 0, cur = 0;
@@ -309,9 +419,14 @@ __global__ void __launch_bounds__(64) k1_dense_kernel(K1Args a) {
     float* acc = reinterpret_cast<float*>(smem);
     const int lane = threadIdx.x;
     const int grp = lane / G, lig = lane % G;
-    const uint64_t slot = (uint64_t)blockIdx.x * W + grp;
     ItemDesc it{0u, kNoTile, 0u, 0.f};
-    if (slot < a.n_slots) it = a.items[slot];
+    if (a.n_items) {   // tile-sorted list: every XCD takes a contiguous run of tiles
+        const uint32_t n = *a.n_items, nb = (n + W - 1) / W;
+        if (blockIdx.x < nb) { const uint64_t slot = (uint64_t)xcd_remap(blockIdx.x, nb) * W + grp; if (slot < n) it = a.items[slot]; }
+    } else {
+        const uint64_t slot = (uint64_t)blockIdx.x * W + grp;
+        if (slot < a.n_slots) it = a.items[slot];
+    }
     const bool active = it.tile != kNoTile;
     TileDesc td{};
     if (active) td = a.L.tiles[it.tile];
@@ -365,11 +480,11 @@ int k1_auto_group(const LayerDev& L, const Layer& host, int dense) {
     return g;
 }
 
-void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, float* cand, int group,
-               hipStream_t s) {
+void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, const uint32_t* n_items,
+               float* cand, int group, hipStream_t s) {
     if (P.nrows == 0) return;
     K1Args a;
-    a.L = L; a.X = X; a.items = static_cast<const ItemDesc*>(items); a.cand = cand;
+    a.L = L; a.X = X; a.items = static_cast<const ItemDesc*>(items); a.n_items = n_items; a.cand = cand;
     a.n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
     a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
     a.acc_stride = L.max_tile_cols | 1u;

@@ -89,7 +89,7 @@ struct PendingEvent { hipEvent_t a, b; size_t slot; };
 struct Workspace {
     DevBuf beam_idx[2], beam_val[2], beam_cnt[2];
     DevBuf cand_off, ncand, cand, stats;
-    DevBuf items;                            // per-layer item descriptors written by K0
+    DevBuf items, items_sorted, sort_hist, sort_start;   // item descriptors (K0) and their tile-sorted copy
     // host-ABI predict: uploaded X + result staging
     DevBuf x_ptr, x_idx, x_val;
     DevBuf out_idx, out_val, out_cnt;
@@ -109,6 +109,7 @@ struct Model {
     // options
     int k1_group = 0;                       // 0 = auto
     int64_t max_batch_rows = 0;             // 0 = auto
+    int sort_min_tiles = 256;               // tile-sort a layer's items once it has this many tiles (0 = never)
     bool profiling = false;
     std::vector<ProfileSlot> profile;
     std::vector<PendingEvent> pending;     // recorded, not yet resolved (no sync on the timed path)

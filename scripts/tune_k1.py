@@ -40,5 +40,5 @@ for extra in (sys.argv[4:] or [""]):
         row = {}
         for r in prof: row[(r["name"], r["layer"])] = r["ms"] / r["launches"]
         k1 = [row.get(("k1_sparse", l), 0) for l in range(m.depth)]
-        k2 = [row.get(("k2_topk", l), 0) for l in range(m.depth)]
-        print(f"[{extra}] G={g:2d} total {dt*1e3:7.2f} ms ({X.shape[0]/dt/1e6:.2f} Mq/s)  k1/layer " + " ".join(f"{v:7.3f}" for v in k1) + "   k2/layer " + " ".join(f"{v:6.3f}" for v in k2), flush=True)
+        k2 = [row.get(("k2_topk", l), 0) + row.get(("k1_sort_items", l), 0) for l in range(m.depth)]
+        print(f"[{extra}] G={g:2d} total {dt*1e3:7.2f} ms ({X.shape[0]/dt/1e6:.2f} Mq/s)  k1/layer " + " ".join(f"{v:7.3f}" for v in k1) + "   k2+sort/layer " + " ".join(f"{v:6.3f}" for v in k2), flush=True)
