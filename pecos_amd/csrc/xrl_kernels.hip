@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
     const float* __restrict__ xv = a.X.val;
     const BmWord* __restrict__ bm = a.L.bitmap + (uint64_t)(active ? it.tile : 0u) * a.L.nwords;
     const unsigned long long below = (1ull << lig) - 1ull;
+    const uint64_t xlast = xe > cur ? xe - 1 : 0;                      // a valid x index for clamped loads
     uint32_t nh = 0;                                                   // hits waiting in this item's FIFO
 
     auto drain = [&]() {
@@ -346,11 +347,16 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
                 rs[p] = ok ? fa[fbase + h0 + p] : 0u;
                 ln[p] = ok ? fl[fbase + h0 + p] : 0u;
             }
+            // loads are UNCONDITIONAL (index clamped into the row; row 0 of the tile when the slot is
+            // empty) so that all P*NS of them are issued back to back -- a load behind a per-lane branch
+            // makes hipcc wait vmcnt(0) before each one
 #pragma unroll
             for (int p = 0; p < P; ++p)
 #pragma unroll
-                for (int k = 0; k < NS; ++k)
-                    if ((uint32_t)(lig + k * G) < ln[p]) e[p][k] = ent[rs[p] + lig + k * G];
+                for (int k = 0; k < NS; ++k) {
+                    const uint32_t x = (uint32_t)(lig + k * G);
+                    e[p][k] = ent[rs[p] + (x < ln[p] ? x : 0u)];
+                }
 #pragma unroll
             for (int p = 0; p < P; ++p) {
 #pragma unroll
@@ -374,11 +380,18 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
         for (int u = 0; u < U; ++u) {
             const uint64_t t = cur + (uint64_t)(u * G + lig);
             const bool ok = t < xe;
-            f[u] = ok ? xi[t] : 0xFFFFFFFFu;
-            v[u] = ok ? xv[t] : 0.f;
+            const uint64_t tc = ok ? t : xlast;          // clamped: the load itself is unconditional
+            const uint32_t fi = xi[tc];
+            const float vi = xv[tc];
+            f[u] = ok ? fi : 0xFFFFFFFFu;
+            v[u] = vi;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) w[u] = (f[u] < a.L.w_rows && !(a.ablate & 1)) ? bm[f[u] >> 5] : BmWord{0u, 0u};
+        for (int u = 0; u < U; ++u) {
+            const bool inr = f[u] < a.L.w_rows && !(a.ablate & 1);
+            const BmWord wi = bm[inr ? (f[u] >> 5) : 0u];
+            w[u].bits = inr ? wi.bits : 0u; w[u].rank = wi.rank;
+        }
         if (cur < xe) cur += (uint64_t)U * G;
         // ---- push hits into the FIFO in feature order; when an item's FIFO is full, drain and resume
         uint32_t uptr = 0;
