@@ -49,6 +49,12 @@ __device__ __forceinline__ float ref_expf(float x) { return (float)exp((double)x
 // z^3 = (z*z)*z, z^4 = (z*z)*(z*z) carry a single rounding: they are the correctly rounded powers,
 // which is what glibc's pow returns (its error bound is < 1 ULP, correctly rounded in practice).
 // Larger p fall back to pow().
+__device__ __forceinline__ double hinge_pow4(float zf, int p) {   // p in [0, 4] only
+    const double z = (double)zf;
+    const double z2 = z * z;
+    return p == 0 ? 1.0 : p == 1 ? z : p == 2 ? z2 : p == 3 ? z2 * z : z2 * z2;
+}
+
 __device__ __forceinline__ double hinge_pow(float zf, int p) {
     const double z = (double)zf;
     switch (p) {
@@ -61,7 +67,16 @@ __device__ __forceinline__ double hinge_pow(float zf, int p) {
     }
 }
 
+// PPC: compile-time post-processor CLASS.  0 = light (noop, l{p}-hinge and log-l{p}-hinge with
+// p <= 4: at most one fp64 exp, ~12 VGPRs), 1 = generic (adds sigmoid / log-sigmoid / pow(), ~42
+// VGPRs).  Keeping the heavy libm paths out of the default kernels keeps them at 8 waves per SIMD.
+template <int PPC>
 __device__ __forceinline__ float pp_transform(int kind, int p, float v) {
+    if (PPC == 0) {
+        if (kind == PP_LP_HINGE) { const float z = (float)fmax(0.0, 1.0 - (double)v); return (float)exp(-hinge_pow4(z, p)); }
+        if (kind == PP_LOG_LP_HINGE) { const float z = (float)fmax(0.0, 1.0 - (double)v); return (float)(-hinge_pow4(z, p)); }
+        return v;
+    }
     switch (kind) {
     case PP_SIGMOID: return (float)(1.0 / (1.0 + (double)ref_expf(-v)));
     case PP_LOG_SIGMOID: return (float)(-log(1.0 + (double)ref_expf(-v)));
@@ -253,7 +268,7 @@ struct K1Args {
     int ablate;                  // debug: phase-skipping mask for timing ablations (0 in production)
 };
 
-template <int G, class ACC>
+template <int G, int PPC, class ACC>
 __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it, const TileDesc& td, int lig, ACC&& acc_at,
                                             bool add_bias) {
     // bias (sparse X: LAST, inference.hpp:806-811), transform in fp64, combine with the parent's
@@ -264,7 +279,7 @@ __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it,
     for (uint32_t c = lig; c < td.ncols; c += G) {
         float acc = acc_at(c);
         if (add_bias) acc = __fadd_rn(acc, bp[c]);
-        float v = (a.ablate & 8) ? acc : pp_transform(a.pp_kind, a.pp_p, acc);
+        float v = (a.ablate & 8) ? acc : pp_transform<PPC>(a.pp_kind, a.pp_p, acc);
         if (!a.first_layer) v = pp_combine(a.pp_kind, v, it.pscore);
         out[c] = v;
     }
@@ -276,17 +291,19 @@ __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it,
 // hits are compacted IN FEATURE ORDER into a small per-item LDS FIFO (segmented ballot/popcount),
 // then one lane per hit fetches the row extent and its first two entries (all hits of all items at
 // once), and finally the rows are applied in order with the G lanes on distinct columns.
-template <int G, int U> struct K1Cfg {
+// NS = G-wide slices of a hit row fetched up front (NS*G >= widest tile in the tuned configurations;
+// longer rows fall back to in-loop loads), P = hit rows in flight together (P*NS ~ 8 loads per lane).
+template <int G, int NS> struct K1Cfg {
     static constexpr int W = 64 / G;                      // items per wavefront
+    static constexpr int U = (G >= 32) ? 2 : (G == 16 ? 4 : 8);   // query features per lane per step
     static constexpr int H = (G > 32) ? 2 * G : 64;       // hit-FIFO depth per item (>= G)
-    static constexpr int P = 4;                           // hit rows whose entries are in flight together
-    static constexpr int NS = (G == 64) ? 2 : 1;          // G-wide slices of a row fetched up front
+    static constexpr int P = (NS == 1) ? 8 : (NS == 2 ? 4 : 2);
     static constexpr size_t lds_bytes(uint32_t acc_stride) { return (size_t)W * acc_stride * 4 + (size_t)W * H * 12; }
 };
 
-template <int G, int U>
+template <int G, int NS, int PPC>
 __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
-    constexpr int W = K1Cfg<G, U>::W, H = K1Cfg<G, U>::H, P = K1Cfg<G, U>::P, NS = K1Cfg<G, U>::NS;
+    constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* acc = reinterpret_cast<float*>(smem);
     float* fv = acc + (size_t)W * a.acc_stride;                        // x value of the hit
@@ -421,11 +438,11 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
         } while (__any(uptr < (uint32_t)U));
     }
     drain();
-    k1_epilogue<G>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0);
+    k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0);
 }
 
 // ---- dense queries: chunk_ops<drm, bin_search>, inference.hpp:815-839 (bias FIRST, every row) -----
-template <int G>
+template <int G, int PPC>
 __global__ void __launch_bounds__(64) k1_dense_kernel(K1Args a) {
     constexpr int W = 64 / G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -467,7 +484,7 @@ __global__ void __launch_bounds__(64) k1_dense_kernel(K1Args a) {
         }
         wave_sync_lds();
     }
-    k1_epilogue<G>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, false);
+    k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, false);
 }
 
 template <class KERNEL>
@@ -485,12 +502,17 @@ int g_k1_ablate = 0;
 void k1_set_ablate(int mask) { g_k1_ablate = mask; }
 
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense) {
-    // lanes per item = smallest power of two covering the widest tile (one G-wide slice holds a whole
-    // tile row; G == 64 fetches two slices), at least 8 so that x reads coalesce
-    int g = 8;
-    while (g < 64 && (uint32_t)g < L.max_tile_cols) g <<= 1;
+    // lanes per item: a 16- or 32-lane group whose NS slices cover the widest tile row
     (void)host; (void)dense;
-    return g;
+    if (L.max_tile_cols <= 8) return 8;
+    if (L.max_tile_cols <= 16) return 16;
+    return 32;
+}
+
+static int pp_class(const PostProc& pp) {
+    if (pp.kind == PP_NOOP) return 0;
+    if ((pp.kind == PP_LP_HINGE || pp.kind == PP_LOG_LP_HINGE) && pp.p >= 0 && pp.p <= 4) return 0;
+    return 1;
 }
 
 void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, const uint32_t* n_items,
@@ -502,17 +524,29 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
     a.acc_stride = L.max_tile_cols | 1u;
     a.ablate = g_k1_ablate;
+    const int ppc = pp_class(P.pp);
     if (X.dense) {
-#define XRL_K1D(GG) case GG: launch_k1_any(&k1_dense_kernel<GG>, a, 64 / GG, (size_t)(64 / GG) * a.acc_stride * 4, s); break;
+#define XRL_K1D(GG) case GG: if (ppc) launch_k1_any(&k1_dense_kernel<GG, 1>, a, 64 / GG, (size_t)(64 / GG) * a.acc_stride * 4, s); \
+                             else launch_k1_any(&k1_dense_kernel<GG, 0>, a, 64 / GG, (size_t)(64 / GG) * a.acc_stride * 4, s); break;
         switch (group) { XRL_K1D(1) XRL_K1D(2) XRL_K1D(4) XRL_K1D(8) XRL_K1D(16) XRL_K1D(32) XRL_K1D(64)
         default: fail("k1: lanes-per-item must be a power of two in [1, 64]"); }
 #undef XRL_K1D
-    } else {
-#define XRL_K1S(GG, UU) case GG: launch_k1_any(&k1_sparse_kernel<GG, UU>, a, 64 / GG, K1Cfg<GG, UU>::lds_bytes(a.acc_stride), s); break;
-        switch (group) { XRL_K1S(1, 8) XRL_K1S(2, 8) XRL_K1S(4, 8) XRL_K1S(8, 8) XRL_K1S(16, 4) XRL_K1S(32, 2) XRL_K1S(64, 2)
-        default: fail("k1: lanes-per-item must be a power of two in [1, 64]"); }
-#undef XRL_K1S
+        return;
     }
+#define XRL_K1S(GG, NN) do { if (ppc) launch_k1_any(&k1_sparse_kernel<GG, NN, 1>, a, 64 / GG, K1Cfg<GG, NN>::lds_bytes(a.acc_stride), s); \
+                             else launch_k1_any(&k1_sparse_kernel<GG, NN, 0>, a, 64 / GG, K1Cfg<GG, NN>::lds_bytes(a.acc_stride), s); } while (0)
+    const uint32_t ns = (L.max_tile_cols + (uint32_t)group - 1) / (uint32_t)group;
+    switch (group) {
+    case 1: XRL_K1S(1, 1); break;
+    case 2: XRL_K1S(2, 1); break;
+    case 4: XRL_K1S(4, 1); break;
+    case 8: XRL_K1S(8, 1); break;
+    case 16: XRL_K1S(16, 1); break;
+    case 32: if (ns <= 1) XRL_K1S(32, 1); else if (ns == 2) XRL_K1S(32, 2); else if (ns == 3) XRL_K1S(32, 3); else XRL_K1S(32, 4); break;
+    case 64: if (ns <= 1) XRL_K1S(64, 1); else XRL_K1S(64, 2); break;
+    default: fail("k1: lanes-per-item must be a power of two in [1, 64]");
+    }
+#undef XRL_K1S
 }
 
 // ---------------------------------------------------------------------------------------------
