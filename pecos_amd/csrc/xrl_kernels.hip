@@ -297,8 +297,8 @@ template <int G, int NS> struct K1Cfg {
     static constexpr int W = 64 / G;                      // items per wavefront
     static constexpr int U = (G >= 32) ? 2 : (G == 16 ? 4 : 8);   // query features per lane per step
     static constexpr int H = (G > 32) ? 2 * G : 64;       // hit-FIFO depth per item (>= G)
-    static constexpr int P = (NS == 1) ? 8 : (NS == 2 ? 4 : 2);
-    static constexpr size_t lds_bytes(uint32_t acc_stride) { return (size_t)W * acc_stride * 4 + (size_t)W * H * 12; }
+    static constexpr int P = (NS == 1) ? 4 : 2;           // rows per register batch (two batches in flight)
+    static constexpr size_t lds_bytes(uint32_t acc_stride) { return (size_t)W * (acc_stride + NS * G) * 4 + (size_t)W * H * 12; }
 };
 
 template <int G, int NS, int PPC>
@@ -306,7 +306,8 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
     constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* acc = reinterpret_cast<float*>(smem);
-    float* fv = acc + (size_t)W * a.acc_stride;                        // x value of the hit
+    const uint32_t acc_item = a.acc_stride + NS * G;                   // + private dummy slots
+    float* fv = acc + (size_t)W * acc_item;                            // x value of the hit
     uint32_t* fa = reinterpret_cast<uint32_t*>(fv + W * H);            // row slot, then row start
     uint32_t* fl = fa + W * H;                                         // row length
 
@@ -330,7 +331,7 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
     }
     const uint32_t* __restrict__ rp = a.L.row_ptr + td.rowptr_base;
     const Entry* __restrict__ ent = a.L.entries + td.ent_base;
-    float* __restrict__ my_acc = acc + (size_t)grp * a.acc_stride;
+    float* __restrict__ my_acc = acc + (size_t)grp * acc_item;
     const uint32_t fbase = (uint32_t)grp * H;
     if (!(a.ablate & 32)) for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = 0.0f;   // std::fill(..., 0.0), inference.hpp:964
     wave_sync_lds();
@@ -353,39 +354,58 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
             fa[fbase + h] = rs; fl[fbase + h] = rp[s + 1] - rs;
         }
         wave_sync_lds();
-        // rows in feature order, P rows' entries in flight together; inside a row the G lanes take
-        // distinct columns, so only the order BETWEEN rows matters (LDS ops of a wave are in order)
-        for (uint32_t h0 = 0; __any(h0 < nh); h0 += P) {
-            float vv[P]; uint32_t rs[P], ln[P]; Entry e[P][NS];
+        // rows in feature order.  Two register batches of P rows each are kept in flight: while batch
+        // A is applied, the entries of batch B are already on their way (unconditional, clamped loads;
+        // a load behind a per-lane branch makes hipcc wait vmcnt(0) before each one).  Inside a row the
+        // G lanes x NS slices hold distinct columns, so the NS accumulators are gathered together, and
+        // only the order BETWEEN rows matters (LDS operations of one wavefront execute in order).
+        struct Batch { float vv[P]; uint32_t rs[P], ln[P]; Entry e[P][NS]; };
+        auto load_batch = [&](uint32_t h0, Batch& B) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const bool ok = h0 + p < nh;
-                vv[p] = ok ? fv[fbase + h0 + p] : 0.f;
-                rs[p] = ok ? fa[fbase + h0 + p] : 0u;
-                ln[p] = ok ? fl[fbase + h0 + p] : 0u;
+                const uint32_t idx = fbase + (ok ? h0 + p : 0u);
+                const float fvv = fv[idx]; const uint32_t frs = fa[idx], fln = fl[idx];
+                B.vv[p] = fvv; B.rs[p] = ok ? frs : 0u; B.ln[p] = ok ? fln : 0u;
             }
-            // loads are UNCONDITIONAL (index clamped into the row; row 0 of the tile when the slot is
-            // empty) so that all P*NS of them are issued back to back -- a load behind a per-lane branch
-            // makes hipcc wait vmcnt(0) before each one
 #pragma unroll
             for (int p = 0; p < P; ++p)
 #pragma unroll
                 for (int k = 0; k < NS; ++k) {
                     const uint32_t x = (uint32_t)(lig + k * G);
-                    e[p][k] = ent[rs[p] + (x < ln[p] ? x : 0u)];
+                    B.e[p][k] = ent[B.rs[p] + (x < B.ln[p] ? x : 0u)];
                 }
+        };
+        auto apply_batch = [&](const Batch& B) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
+                uint32_t ci[NS]; float pr[NS], ac[NS];
 #pragma unroll
-                for (int k = 0; k < NS; ++k)
-                    if ((uint32_t)(lig + k * G) < ln[p])   // out[col] += scalar * val (inference.hpp:512-517): mul then add, no fma
-                        my_acc[e[p][k].col] = __fadd_rn(my_acc[e[p][k].col], __fmul_rn(vv[p], e[p][k].val));
-                for (uint32_t x = lig + NS * G; x < ln[p]; x += G) {   // rows longer than NS*G (forced small G)
-                    const Entry en = ent[rs[p] + x];
-                    my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(vv[p], en.val));
+                for (int k = 0; k < NS; ++k) {   // lanes without an entry add 0 to a private dummy slot
+                    const bool valid = (uint32_t)(lig + k * G) < B.ln[p];
+                    ci[k] = valid ? B.e[p][k].col : a.acc_stride + (uint32_t)(k * G + lig);
+                    pr[k] = valid ? __fmul_rn(B.vv[p], B.e[p][k].val) : 0.0f;   // scalar * val (inference.hpp:512-517)
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) ac[k] = my_acc[ci[k]];
+#pragma unroll
+                for (int k = 0; k < NS; ++k) my_acc[ci[k]] = __fadd_rn(ac[k], pr[k]);   // mul then add, no fma
+                if (__any(B.ln[p] > (uint32_t)(NS * G))) {   // rows longer than NS*G (only with a forced small G)
+                    for (uint32_t x = lig + NS * G; x < B.ln[p]; x += G) {
+                        const Entry en = ent[B.rs[p] + x];
+                        my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(B.vv[p], en.val));
+                    }
                 }
                 wave_sync_lds();
             }
+        };
+        Batch A, B2;
+        load_batch(0u, A);
+        for (uint32_t h0 = 0; __any(h0 < nh); h0 += 2 * P) {
+            load_batch(h0 + P, B2);
+            apply_batch(A);
+            load_batch(h0 + 2 * P, A);
+            apply_batch(B2);
         }
         nh = 0;
     };
