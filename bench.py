@@ -194,27 +194,34 @@ def main():
 
 
 def cpu_baseline(folder, X, model, beam, topk, budget_s, log):
-    """Time the real reference (oracle/_ref) on this box's cores on a bounded sample; fall back to the
-    single-threaded C restatement ("port") when oracle/_ref is absent.  Also compares the GPU output
-    with the reference's on that sample (indices exact, scores 1e-5 rel)."""
+    """Time the real reference (oracle/_ref, built from /root/reference's own sources) on this box's
+    host cores on a bounded sample of the workload; fall back to the single-threaded C restatement
+    ("port") when oracle/_ref is absent.  The reference's OpenMP path does not scale to hundreds of
+    threads on a small batch, so the thread count is swept and the BEST is reported (cores = threads
+    used).  Also compares the GPU output with the reference's on that sample."""
     import numpy as np
     from oracle import xrl_oracle as O
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     n = X.shape[0]
-    results = {}
     parity = None
     if O.ref_available():
+        results = {}
         for wtype in ("BINARY_SEARCH_CHUNKED", "HASH_CHUNKED"):
             t0 = time.time()
             rm = O.RefModel(folder, wtype)
             load_s = time.time() - t0
-            ns = min(n, 4096)
-            rm.predict(X[:ns], beam_size=beam, only_topk=topk)           # warm-up (page faults)
-            t0 = time.perf_counter(); rm.predict(X[:ns], beam_size=beam, only_topk=topk); t1 = time.perf_counter() - t0
-            ns = int(min(n, max(ns, ns * (budget_s / 2) / max(t1, 1e-3))))
-            t0 = time.perf_counter(); P = rm.predict(X[:ns], beam_size=beam, only_topk=topk); t1 = time.perf_counter() - t0
-            results[wtype] = dict(qps=ns / t1, sample=ns, load_s=round(load_s, 1))
-            log(f"cpu reference {wtype}: {ns} queries in {t1:.2f}s = {ns / t1:.0f} q/s on {cores} cores (load {load_s:.1f}s)")
+            ns = min(n, 8192)
+            rm.predict(X[:ns], beam_size=beam, only_topk=topk, threads=min(ncpu, 32))   # warm-up (page faults)
+            best = None
+            for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
+                t0 = time.perf_counter(); rm.predict(X[:ns], beam_size=beam, only_topk=topk, threads=th); t1 = time.perf_counter() - t0
+                if best is None or ns / t1 > best[0]:
+                    best = (ns / t1, th)
+            th = best[1]
+            ns = int(min(n, max(ns, best[0] * budget_s / 2)))
+            t0 = time.perf_counter(); P = rm.predict(X[:ns], beam_size=beam, only_topk=topk, threads=th); t1 = time.perf_counter() - t0
+            results[wtype] = dict(qps=ns / t1, sample=ns, threads=th, load_s=round(load_s, 1))
+            log(f"cpu reference {wtype}: {ns} queries in {t1:.2f}s = {ns / t1:.0f} q/s with {th} threads of {ncpu} (load {load_s:.1f}s)")
             if wtype == "BINARY_SEARCH_CHUNKED":
                 G = model.predict(X[:ns], beam_size=beam, only_topk=topk)
                 same_rows = np.array_equal(G.indptr, P.indptr)
@@ -225,11 +232,11 @@ def cpu_baseline(folder, X, model, beam, topk, budget_s, log):
                 parity = dict(vs="reference BINARY_SEARCH_CHUNKED", sample=ns, indices_identical=bool(same_idx),
                               scores_bit_identical=bit, max_rel_err=rel, top1_agreement=p1)
             del rm
-        best = max(results, key=lambda w: results[w]["qps"])
-        base = dict(value=round(results[best]["qps"], 1), unit="queries/s", cores=cores, kind="reference",
-                    sample=f"first {results[best]['sample']} queries of the workload, layout {best}, threads=-1 (all cores), "
-                           f"1 warm-up + 1 timed call; other layout: " +
-                           "; ".join(f"{w}={results[w]['qps']:.0f} q/s" for w in results if w != best))
+        bw = max(results, key=lambda w: results[w]["qps"])
+        base = dict(value=round(results[bw]["qps"], 1), unit="queries/s", cores=results[bw]["threads"], kind="reference",
+                    sample=f"first {results[bw]['sample']} queries of the workload, layout {bw}, best of a thread sweep "
+                           f"({results[bw]['threads']} OpenMP threads on a {ncpu}-cpu host), 1 warm-up + 1 timed call; other layout: " +
+                           "; ".join(f"{w}={results[w]['qps']:.0f} q/s @ {results[w]['threads']} thr" for w in results if w != bw))
     else:
         om = O.OracleModel.load(folder)
         ns = min(n, 256)

@@ -109,7 +109,7 @@ struct Model {
     // options
     int k1_group = 0;                       // 0 = auto
     int64_t max_batch_rows = 0;             // 0 = auto
-    int sort_min_tiles = 256;               // tile-sort a layer's items once it has this many tiles (0 = never)
+    int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
     bool profiling = false;
     std::vector<ProfileSlot> profile;
     std::vector<PendingEvent> pending;     // recorded, not yet resolved (no sync on the timed path)
