@@ -169,10 +169,19 @@ def main():
             avg_ms = fam[dom]["ms"] / max(1, fam[dom]["launches"])
             per_launch = alg_k1 / max(1.0, launches_per_step)
             ach = per_launch / (avg_ms * 1e-3) / 1e9
+            traffic, tsrc = None, None
+            tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")   # written from separate rocprofv3 --pmc passes
+            if os.path.exists(tfile):
+                tj = json.load(open(tfile))
+                if tj.get("config") == args.config and tj.get("scale") == args.scale and tj.get("n_gpus") == world:
+                    traffic, tsrc = tj.get("hbm_bytes_per_launch"), tj.get("source")
             roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4),
-                        traffic=None, alg_bytes_per_launch=per_launch, avg_launch_ms=round(avg_ms, 4),
+                        traffic=traffic, traffic_source=tsrc, alg_bytes_per_launch=per_launch, avg_launch_ms=round(avg_ms, 4),
                         launches_per_step=launches_per_step,
                         per_kernel_ms_per_step={n: round(v["ms"] / max(1, args.steps), 4) for n, v in fam.items()},
+                        per_layer=[dict(layer=r["layer"], ms=round(r["ms"] / max(1, r["launches"]), 4),
+                                        ref_chunk_bytes=st[r["layer"]][0], candidates=st[r["layer"]][1])
+                                   for r in prof if r["name"] == dom],
                         note="algorithmic bytes assume NO inter-query reuse (SURVEY.md 8d); frac>1 means chunks are served from L2/MALL")
         cfg_out = dict(workload=f"{args.config} synthetic x{args.scale}: N={n_total} D={X.shape[1]} L={ks[-1]} tree={ks} "
                                 f"nnz/row={getattr(X, 'nnz', X.size) / max(1, n_total):.1f} beam={beam} topk={k} pp=l3-hinge bias=1.0",
