@@ -82,7 +82,10 @@ def main():
             np.save(os.path.join(folder, "X.npy"), X)
         json.dump({"ks": ks, "cfg": cfg2}, open(os.path.join(folder, "meta.json"), "w"))
         open(done, "w").write("ok")
+    t_wait = time.time()
     while not os.path.exists(done):
+        if time.time() - t_wait > 900:
+            raise RuntimeError("timed out waiting for local rank 0 to generate the synthetic workload")
         time.sleep(0.5)
     meta = json.load(open(os.path.join(folder, "meta.json")))
     ks = meta["ks"]
