@@ -291,25 +291,28 @@ __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it,
 // hits are compacted IN FEATURE ORDER into a small per-item LDS FIFO (segmented ballot/popcount),
 // then one lane per hit fetches the row extent and its first two entries (all hits of all items at
 // once), and finally the rows are applied in order with the G lanes on distinct columns.
-// NS = G-wide slices of a hit row fetched up front (NS*G >= widest tile in the tuned configurations;
-// longer rows fall back to in-loop loads), P = hit rows in flight together (P*NS ~ 8 loads per lane).
+// NS = number of G-wide UNITS a tile row can span (NS*G >= widest tile in the tuned configurations;
+// with a forced smaller G the last unit carries the remainder through an in-loop path).
+// P  = units per register batch; two batches are in flight.
 template <int G, int NS> struct K1Cfg {
     static constexpr int W = 64 / G;                      // items per wavefront
     static constexpr int U = (G >= 32) ? 2 : (G == 16 ? 4 : 8);   // query features per lane per step
-    static constexpr int H = (G > 32) ? 2 * G : 64;       // hit-FIFO depth per item (>= G)
-    static constexpr int P = (NS == 1) ? 4 : 2;           // rows per register batch (two batches in flight)
-    static constexpr size_t lds_bytes(uint32_t acc_stride) { return (size_t)W * (acc_stride + NS * G) * 4 + (size_t)W * H * 12; }
+    static constexpr int H = (G > 32) ? 2 * G : 64;       // hit queue depth per item (>= G)
+    static constexpr int UH = H * NS;                     // unit queue depth per item
+    static constexpr int P = 4;
+    static constexpr size_t lds_bytes(uint32_t acc_stride) {
+        return (size_t)W * UH * 16 + (size_t)W * H * 8 + (size_t)W * (acc_stride + G) * 4;
+    }
 };
 
 template <int G, int NS, int PPC>
 __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
-    constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U;
+    constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, UH = K1Cfg<G, NS>::UH, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* acc = reinterpret_cast<float*>(smem);
-    const uint32_t acc_item = a.acc_stride + NS * G;                   // + private dummy slots
-    float* fv = acc + (size_t)W * acc_item;                            // x value of the hit
-    uint32_t* fa = reinterpret_cast<uint32_t*>(fv + W * H);            // row slot, then row start
-    uint32_t* fl = fa + W * H;                                         // row length
+    uint4* uq = reinterpret_cast<uint4*>(smem);                        // units {x value, entry start, count, -}
+    uint2* hq = reinterpret_cast<uint2*>(uq + W * UH);                 // hits  {x value, row slot}
+    float* acc = reinterpret_cast<float*>(hq + W * H);
+    const uint32_t acc_item = a.acc_stride + G;                        // + one private dummy slot per lane
 
     const int lane = threadIdx.x;
     const int grp = lane / G, lig = lane % G;
@@ -332,7 +335,9 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
     const uint32_t* __restrict__ rp = a.L.row_ptr + td.rowptr_base;
     const Entry* __restrict__ ent = a.L.entries + td.ent_base;
     float* __restrict__ my_acc = acc + (size_t)grp * acc_item;
-    const uint32_t fbase = (uint32_t)grp * H;
+    uint2* __restrict__ my_hq = hq + (size_t)grp * H;
+    uint4* __restrict__ my_uq = uq + (size_t)grp * UH;
+    const uint32_t dummy = a.acc_stride + (uint32_t)lig;
     if (!(a.ablate & 32)) for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = 0.0f;   // std::fill(..., 0.0), inference.hpp:964
     wave_sync_lds();
     if (a.ablate & 2) cur = xe;
@@ -342,58 +347,65 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
     const BmWord* __restrict__ bm = a.L.bitmap + (uint64_t)(active ? it.tile : 0u) * a.L.nwords;
     const unsigned long long below = (1ull << lig) - 1ull;
     const uint64_t xlast = xe > cur ? xe - 1 : 0;                      // a valid x index for clamped loads
-    uint32_t nh = 0;                                                   // hits waiting in this item's FIFO
+    uint32_t nh = 0;                                                   // hits waiting in this item's queue
 
     auto drain = [&]() {
         if (a.ablate & 4) { nh = 0; return; }
         wave_sync_lds();
-        // one lane per hit: row extent (all hits of all items in flight at once)
-        for (uint32_t h = lig; h < nh; h += G) {
-            const uint32_t s = fa[fbase + h];
-            const uint32_t rs = rp[s];
-            fa[fbase + h] = rs; fl[fbase + h] = rp[s + 1] - rs;
+        // ---- D1: one lane per hit fetches the row extent and cuts the row into units of <= G entries,
+        //      written in order (segmented scan of the unit counts when a row can span several units)
+        uint32_t nu = 0;                                               // units queued for this item
+        for (uint32_t h0 = 0; __any(h0 < nh); h0 += G) {
+            const uint32_t h = h0 + lig;
+            const bool ok = h < nh;
+            const uint2 hv = my_hq[ok ? h : 0u];
+            const uint32_t s = ok ? hv.y : 0u;
+            const uint32_t rs = rp[s], re = rp[s + 1];                 // unconditional (slot 0 when idle)
+            const uint32_t len = ok ? re - rs : 0u;
+            uint32_t cnt = (NS == 1) ? (len ? 1u : 0u) : min((len + G - 1) / G, (uint32_t)NS);
+            uint32_t incl = cnt;
+            if (G > 1) {
+#pragma unroll
+                for (int d = 1; d < G; d <<= 1) { const uint32_t y = __shfl_up(incl, d, G); if (lig >= d) incl += y; }
+            }
+            const uint32_t base = nu + incl - cnt;
+#pragma unroll
+            for (int k = 0; k < NS; ++k)
+                if ((uint32_t)k < cnt) {
+                    const uint32_t n_k = (k == NS - 1) ? len - (uint32_t)k * G : min(len - (uint32_t)k * G, (uint32_t)G);
+                    my_uq[base + k] = make_uint4(hv.x, rs + (uint32_t)k * G, n_k, 0u);
+                }
+            nu += (G > 1) ? __shfl(incl, G - 1, G) : incl;
         }
         wave_sync_lds();
-        // rows in feature order.  Two register batches of P rows each are kept in flight: while batch
-        // A is applied, the entries of batch B are already on their way (unconditional, clamped loads;
-        // a load behind a per-lane branch makes hipcc wait vmcnt(0) before each one).  Inside a row the
-        // G lanes x NS slices hold distinct columns, so the NS accumulators are gathered together, and
-        // only the order BETWEEN rows matters (LDS operations of one wavefront execute in order).
-        struct Batch { float vv[P]; uint32_t rs[P], ln[P]; Entry e[P][NS]; };
-        auto load_batch = [&](uint32_t h0, Batch& B) {
+        // ---- D3: units in order.  Two register batches of P units are in flight: while batch A is
+        //      applied the entries of batch B are already loading (unconditional, clamped loads; a load
+        //      behind a per-lane branch makes hipcc wait vmcnt(0) before each one).  The lanes of a unit
+        //      hold distinct columns; lanes without an entry add 0 to a private dummy slot.  LDS
+        //      operations of one wavefront execute in order, so only a compiler fence separates units.
+        struct Batch { uint4 u[P]; Entry e[P]; };
+        auto load_batch = [&](uint32_t i0, Batch& B) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const bool ok = h0 + p < nh;
-                const uint32_t idx = fbase + (ok ? h0 + p : 0u);
-                const float fvv = fv[idx]; const uint32_t frs = fa[idx], fln = fl[idx];
-                B.vv[p] = fvv; B.rs[p] = ok ? frs : 0u; B.ln[p] = ok ? fln : 0u;
+                const bool ok = i0 + p < nu;
+                const uint4 d = my_uq[ok ? i0 + p : 0u];
+                B.u[p] = make_uint4(d.x, ok ? d.y : 0u, ok ? d.z : 0u, 0u);
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p)
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const uint32_t x = (uint32_t)(lig + k * G);
-                    B.e[p][k] = ent[B.rs[p] + (x < B.ln[p] ? x : 0u)];
-                }
+            for (int p = 0; p < P; ++p) B.e[p] = ent[B.u[p].y + ((uint32_t)lig < B.u[p].z ? (uint32_t)lig : 0u)];
         };
         auto apply_batch = [&](const Batch& B) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                uint32_t ci[NS]; float pr[NS], ac[NS];
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {   // lanes without an entry add 0 to a private dummy slot
-                    const bool valid = (uint32_t)(lig + k * G) < B.ln[p];
-                    ci[k] = valid ? B.e[p][k].col : a.acc_stride + (uint32_t)(k * G + lig);
-                    pr[k] = valid ? __fmul_rn(B.vv[p], B.e[p][k].val) : 0.0f;   // scalar * val (inference.hpp:512-517)
-                }
-#pragma unroll
-                for (int k = 0; k < NS; ++k) ac[k] = my_acc[ci[k]];
-#pragma unroll
-                for (int k = 0; k < NS; ++k) my_acc[ci[k]] = __fadd_rn(ac[k], pr[k]);   // mul then add, no fma
-                if (__any(B.ln[p] > (uint32_t)(NS * G))) {   // rows longer than NS*G (only with a forced small G)
-                    for (uint32_t x = lig + NS * G; x < B.ln[p]; x += G) {
-                        const Entry en = ent[B.rs[p] + x];
-                        my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(B.vv[p], en.val));
+                const float v = __uint_as_float(B.u[p].x);
+                const bool valid = (uint32_t)lig < B.u[p].z;
+                const uint32_t ci = valid ? B.e[p].col : dummy;
+                const float pr = valid ? __fmul_rn(v, B.e[p].val) : 0.0f;      // scalar * val (inference.hpp:512-517)
+                my_acc[ci] = __fadd_rn(my_acc[ci], pr);                        // mul then add, no fma
+                if (__any(B.u[p].z > (uint32_t)G)) {                           // remainder of an over-long last unit
+                    for (uint32_t x = lig + G; x < B.u[p].z; x += G) {
+                        const Entry en = ent[B.u[p].y + x];
+                        my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(v, en.val));
                     }
                 }
                 wave_sync_lds();
@@ -401,10 +413,10 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
         };
         Batch A, B2;
         load_batch(0u, A);
-        for (uint32_t h0 = 0; __any(h0 < nh); h0 += 2 * P) {
-            load_batch(h0 + P, B2);
+        for (uint32_t i0 = 0; __any(i0 < nu); i0 += 2 * P) {
+            load_batch(i0 + P, B2);
             apply_batch(A);
-            load_batch(h0 + 2 * P, A);
+            load_batch(i0 + 2 * P, A);
             apply_batch(B2);
         }
         nh = 0;
@@ -430,7 +442,7 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
             w[u].bits = inr ? wi.bits : 0u; w[u].rank = wi.rank;
         }
         if (cur < xe) cur += (uint64_t)U * G;
-        // ---- push hits into the FIFO in feature order; when an item's FIFO is full, drain and resume
+        // ---- push hits into the queue in feature order; when an item's queue is full, drain and resume
         uint32_t uptr = 0;
         do {
             bool stopped = false;
@@ -443,11 +455,8 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
                 const uint32_t cnt = (uint32_t)__popcll(gm);
                 if ((uint32_t)u >= uptr && !stopped) {
                     if (nh + cnt <= (uint32_t)H) {
-                        if (hit) {
-                            const uint32_t pos = fbase + nh + (uint32_t)__popcll(gm & below);
-                            fv[pos] = v[u];
-                            fa[pos] = w[u].rank + __popc(w[u].bits & ((1u << b) - 1u));
-                        }
+                        if (hit) my_hq[nh + (uint32_t)__popcll(gm & below)] =
+                                     make_uint2(__float_as_uint(v[u]), w[u].rank + __popc(w[u].bits & ((1u << b) - 1u)));
                         nh += cnt; uptr = u + 1;
                     } else {
                         stopped = true;
