@@ -305,8 +305,8 @@ template <int G, int NS> struct K1Cfg {
     }
 };
 
-template <int G, int NS, int PPC>
-__global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
+template <int G, int NS, int PPC, bool DENSE>
+__global__ void __launch_bounds__(64) k1_kernel(K1Args a) {
     constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, UH = K1Cfg<G, NS>::UH, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* uq = reinterpret_cast<uint4*>(smem);                        // units {x value, entry start, count, -}
@@ -338,7 +338,12 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
     uint2* __restrict__ my_hq = hq + (size_t)grp * H;
     uint4* __restrict__ my_uq = uq + (size_t)grp * UH;
     const uint32_t dummy = a.acc_stride + (uint32_t)lig;
-    if (!(a.ablate & 32)) for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = 0.0f;   // std::fill(..., 0.0), inference.hpp:964
+    if (DENSE) {   // dense queries: bias FIRST (inference.hpp:824-830); bias_prod already holds 0.0f + bias*w
+        const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
+        for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = a.L.has_bias ? bp[c] : 0.0f;
+    } else if (!(a.ablate & 32)) {
+        for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = 0.0f;   // std::fill(..., 0.0), inference.hpp:964
+    }
     wave_sync_lds();
     if (a.ablate & 2) cur = xe;
 
@@ -422,6 +427,27 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
         nh = 0;
     };
 
+    if (DENSE) {
+        // chunk_ops<drm, bin_search>, inference.hpp:815-839: EVERY tile row (except the bias row, which is
+        // the last one) is a hit with x value x[row feature]; rows go through the same unit queue.
+        const float* __restrict__ xd = a.X.val + ((uint64_t)a.row0 + it.q) * a.X.cols;
+        const uint32_t* __restrict__ ridx = a.L.row_idx + (td.rowptr_base - (active ? it.tile : 0u));
+        uint32_t nr = active ? td.nrows : 0u;
+        if (active && td.bias_slot != kNoBias) nr -= 1;
+        for (uint32_t s0 = 0; __any(s0 < nr); s0 += H) {
+            for (uint32_t j = lig; j < (uint32_t)H; j += G) {
+                const uint32_t sidx = s0 + j;
+                const bool ok = sidx < nr;
+                const uint32_t f = ridx[ok ? sidx : 0u];
+                const float xval = xd[f < a.X.cols ? f : 0u];
+                if (ok) my_hq[j] = make_uint2(__float_as_uint(f < a.X.cols ? xval : 0.0f), sidx);
+            }
+            nh = s0 < nr ? min((uint32_t)H, nr - s0) : 0u;
+            drain();
+        }
+        k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, false);
+        return;
+    }
     while (__any(cur < xe)) {
         // ---- load step: U*G consecutive features of the item
         uint32_t f[U]; float v[U]; BmWord w[U];
@@ -470,52 +496,6 @@ __global__ void __launch_bounds__(64) k1_sparse_kernel(K1Args a) {
     k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0);
 }
 
-// ---- dense queries: chunk_ops<drm, bin_search>, inference.hpp:815-839 (bias FIRST, every row) -----
-template <int G, int PPC>
-__global__ void __launch_bounds__(64) k1_dense_kernel(K1Args a) {
-    constexpr int W = 64 / G;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* acc = reinterpret_cast<float*>(smem);
-    const int lane = threadIdx.x;
-    const int grp = lane / G, lig = lane % G;
-    ItemDesc it{0u, kNoTile, 0u, 0.f};
-    if (a.n_items) {   // tile-sorted list: every XCD takes a contiguous run of tiles
-        const uint32_t n = *a.n_items, nb = (n + W - 1) / W;
-        if (blockIdx.x < nb) { const uint64_t slot = (uint64_t)xcd_remap(blockIdx.x, nb) * W + grp; if (slot < n) it = a.items[slot]; }
-    } else {
-        const uint64_t slot = (uint64_t)blockIdx.x * W + grp;
-        if (slot < a.n_slots) it = a.items[slot];
-    }
-    const bool active = it.tile != kNoTile;
-    TileDesc td{};
-    if (active) td = a.L.tiles[it.tile];
-    const uint32_t* __restrict__ rp = a.L.row_ptr + td.rowptr_base;
-    const Entry* __restrict__ ent = a.L.entries + td.ent_base;
-    float* __restrict__ my_acc = acc + (size_t)grp * a.acc_stride;
-    const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
-    // bias first: acc = 0.0f + bias*w (bias_prod already holds 0.0f + product)
-    for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = a.L.has_bias ? bp[c] : 0.0f;
-    wave_sync_lds();
-    const float* __restrict__ xd = a.X.val + ((uint64_t)a.row0 + it.q) * a.X.cols;
-    const uint32_t* __restrict__ ridx = a.L.row_idx + (td.rowptr_base - (active ? it.tile : 0u));
-    uint32_t nr = active ? td.nrows : 0u;
-    if (active && td.bias_slot != kNoBias) nr -= 1;                    // the bias row is the last row
-    for (uint32_t s = 0; __any(s < nr); ++s) {
-        if (s < nr) {
-            const uint32_t f = ridx[s];
-            if (f < a.X.cols) {
-                const float v = xd[f];
-                for (uint32_t e = rp[s] + lig; e < rp[s + 1]; e += G) {
-                    const Entry en = ent[e];
-                    my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(v, en.val));
-                }
-            }
-        }
-        wave_sync_lds();
-    }
-    k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, false);
-}
-
 template <class KERNEL>
 static void launch_k1_any(KERNEL kernel, const K1Args& a, int W, size_t lds, hipStream_t s) {
     if (lds > 160 * 1024) fail("k1: LDS request exceeds 160 KiB");
@@ -554,28 +534,22 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     a.acc_stride = L.max_tile_cols | 1u;
     a.ablate = g_k1_ablate;
     const int ppc = pp_class(P.pp);
-    if (X.dense) {
-#define XRL_K1D(GG) case GG: if (ppc) launch_k1_any(&k1_dense_kernel<GG, 1>, a, 64 / GG, (size_t)(64 / GG) * a.acc_stride * 4, s); \
-                             else launch_k1_any(&k1_dense_kernel<GG, 0>, a, 64 / GG, (size_t)(64 / GG) * a.acc_stride * 4, s); break;
-        switch (group) { XRL_K1D(1) XRL_K1D(2) XRL_K1D(4) XRL_K1D(8) XRL_K1D(16) XRL_K1D(32) XRL_K1D(64)
-        default: fail("k1: lanes-per-item must be a power of two in [1, 64]"); }
-#undef XRL_K1D
-        return;
-    }
-#define XRL_K1S(GG, NN) do { if (ppc) launch_k1_any(&k1_sparse_kernel<GG, NN, 1>, a, 64 / GG, K1Cfg<GG, NN>::lds_bytes(a.acc_stride), s); \
-                             else launch_k1_any(&k1_sparse_kernel<GG, NN, 0>, a, 64 / GG, K1Cfg<GG, NN>::lds_bytes(a.acc_stride), s); } while (0)
+#define XRL_K1(GG, NN) do { \
+        const size_t lds = K1Cfg<GG, NN>::lds_bytes(a.acc_stride); \
+        if (X.dense) { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, true>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, true>, a, 64 / GG, lds, s); } \
+        else { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, false>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, false>, a, 64 / GG, lds, s); } } while (0)
     const uint32_t ns = (L.max_tile_cols + (uint32_t)group - 1) / (uint32_t)group;
     switch (group) {
-    case 1: XRL_K1S(1, 1); break;
-    case 2: XRL_K1S(2, 1); break;
-    case 4: XRL_K1S(4, 1); break;
-    case 8: XRL_K1S(8, 1); break;
-    case 16: XRL_K1S(16, 1); break;
-    case 32: if (ns <= 1) XRL_K1S(32, 1); else if (ns == 2) XRL_K1S(32, 2); else if (ns == 3) XRL_K1S(32, 3); else XRL_K1S(32, 4); break;
-    case 64: if (ns <= 1) XRL_K1S(64, 1); else XRL_K1S(64, 2); break;
+    case 1: XRL_K1(1, 1); break;
+    case 2: XRL_K1(2, 1); break;
+    case 4: XRL_K1(4, 1); break;
+    case 8: XRL_K1(8, 1); break;
+    case 16: XRL_K1(16, 1); break;
+    case 32: if (ns <= 1) XRL_K1(32, 1); else if (ns == 2) XRL_K1(32, 2); else if (ns == 3) XRL_K1(32, 3); else XRL_K1(32, 4); break;
+    case 64: if (ns <= 1) XRL_K1(64, 1); else XRL_K1(64, 2); break;
     default: fail("k1: lanes-per-item must be a power of two in [1, 64]");
     }
-#undef XRL_K1S
+#undef XRL_K1
 }
 
 // ---------------------------------------------------------------------------------------------
