@@ -94,6 +94,20 @@ void c_xlinear_predict_drm_f32(void* ptr, const ScipyDrmF32* input_x,
                                const uint32_t overridden_only_topk, const int threads,
                                py_sparse_allocator_t pred_alloc);
 
+/* libpecos.cpp:179-198 (C_XLINEAR_PREDICT_ON_SELECTED_OUTPUTS): scores for a given (query, label)
+ * pattern.  The reference only offers this for weight_matrix_type == CSC (inference.hpp:2143-2147) and
+ * uses the CSC arithmetic (vector_ops::inner_product, :1018-1078); this library accepts any handle and
+ * reproduces that arithmetic and the reference's output order (the walk of
+ * prolongate_sparse_predictions, :1302-1358).  Result CSR has selected_outputs_csr's row_ptr. */
+void c_xlinear_predict_on_selected_outputs_csr_f32(void* ptr, const ScipyCsrF32* input_x,
+                                                   const ScipyCsrF32* selected_outputs_csr,
+                                                   const char* overridden_post_processor_str,
+                                                   const int threads, py_sparse_allocator_t pred_alloc);
+void c_xlinear_predict_on_selected_outputs_drm_f32(void* ptr, const ScipyDrmF32* input_x,
+                                                   const ScipyCsrF32* selected_outputs_csr,
+                                                   const char* overridden_post_processor_str,
+                                                   const int threads, py_sparse_allocator_t pred_alloc);
+
 /* libpecos.cpp:201-235 (C_XLINEAR_SINGLE_LAYER_PREDICT): one layer from caller-owned W / C,
  * optional previous-layer predictions csr_codes (NULL => all-ones N x C.cols, no combine). */
 void c_xlinear_single_layer_predict_csr_f32(const ScipyCsrF32* input_x, const ScipyCsrF32* csr_codes,

@@ -289,3 +289,134 @@ int orc_sparse_inner_products(const uint64_t* x_indptr, const uint32_t* x_idx, c
     }
     return 0;
 }
+
+/*
+ * HierarchicalMLModel::predict_on_selected_outputs, inference.hpp:2507-2571, with
+ *   the per-layer patterns   S_{l-1} = pattern(S_l x C_l) (smat_x_smat, sorted indices)   :2527-2541
+ *   prolongate_sparse_predictions                                                        :1302-1358
+ *   w_ops<csc_t>::compute_sparse_predictions / vector_ops::inner_product                 :1018-1078, 1081-1149
+ *     sparse X: res = 0; res += bias*w_bias (if explicit); res += dot(x, w)   (dot accumulated separately)
+ *     dense  X: bias>0: res = bias*w_bias, then res += x[idx]*w over the non-bias entries in order
+ *               bias<=0: dot over all entries
+ * (only LAYER_TYPE_CSC supports this entry point in the reference, :2143-2147).
+ * sel_*: CSR pattern of the selected outputs (N x L).  Output: out_idx/out_val in the reference's
+ * traversal order, row_ptr identical to sel_indptr.  Returns 0, or -1 / -2 (a selected label has no
+ * path to the root / appears twice: the reference would emit uninitialised slots).
+ */
+static int orc_u32_cmp(const void* a, const void* b) {
+    const uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
+    return (x > y) - (x < y);
+}
+
+int orc_predict_selected(const orc_layer_t* layers, uint32_t depth, uint32_t n_rows,
+                         const uint64_t* x_indptr, const uint32_t* x_idx, const float* x_val,
+                         const float* x_dense, uint32_t x_cols,
+                         const uint64_t* sel_indptr, const uint32_t* sel_idx,
+                         int pp_kind, int pp_p, uint32_t* out_idx, float* out_val) {
+    int rc = 0;
+    /* child -> parent maps */
+    uint32_t** parent = (uint32_t**)calloc(depth, sizeof(uint32_t*));
+    for (uint32_t l = 0; l < depth; ++l) {
+        const orc_csc_t* C = &layers[l].C;
+        parent[l] = (uint32_t*)malloc(((size_t)C->rows + 1) * 4);
+        for (uint32_t i = 0; i < C->rows; ++i) parent[l][i] = 0xFFFFFFFFu;
+        for (uint32_t p = 0; p < C->cols; ++p)
+            for (uint64_t c = C->col_ptr[p]; c < C->col_ptr[p + 1]; ++c) parent[l][C->row_idx[c]] = p;
+    }
+    uint32_t max_w_rows = 0;
+    for (uint32_t l = 0; l < depth; ++l) if (layers[l].W.rows > max_w_rows) max_w_rows = layers[l].W.rows;
+    float* xs = (float*)calloc((size_t)max_w_rows + 1, sizeof(float));
+    uint8_t* touched = (uint8_t*)calloc((size_t)max_w_rows + 1, 1);
+    for (uint32_t q = 0; q < n_rows && rc == 0; ++q) {
+        const uint64_t sb = sel_indptr[q], se = sel_indptr[q + 1];
+        const size_t n_sel = (size_t)(se - sb);
+        /* patterns bottom-up: pat[l] = sorted unique nodes of layer l */
+        uint32_t** pat = (uint32_t**)calloc(depth, sizeof(uint32_t*));
+        size_t* npat = (size_t*)calloc(depth, sizeof(size_t));
+        pat[depth - 1] = (uint32_t*)malloc((n_sel + 1) * 4);
+        memcpy(pat[depth - 1], sel_idx + sb, n_sel * 4);
+        qsort(pat[depth - 1], n_sel, 4, orc_u32_cmp);          /* membership is a set (valid_cols, :1325-1329) */
+        for (size_t i = 1; i < n_sel; ++i) if (pat[depth - 1][i] == pat[depth - 1][i - 1]) rc = -2;
+        npat[depth - 1] = n_sel;
+        for (uint32_t l = depth - 1; l > 0; --l) {
+            pat[l - 1] = (uint32_t*)malloc((npat[l] + 1) * 4);
+            size_t m = 0;
+            for (size_t i = 0; i < npat[l]; ++i) {
+                const uint32_t pr = pat[l][i] < layers[l].C.rows ? parent[l][pat[l][i]] : 0xFFFFFFFFu;
+                if (pr == 0xFFFFFFFFu) { rc = -1; break; }
+                pat[l - 1][m++] = pr;
+            }
+            qsort(pat[l - 1], m, 4, orc_u32_cmp);
+            size_t u = 0;
+            for (size_t i = 0; i < m; ++i) if (i == 0 || pat[l - 1][i] != pat[l - 1][i - 1]) pat[l - 1][u++] = pat[l - 1][i];
+            npat[l - 1] = u;
+        }
+        if (!x_dense)
+            for (uint64_t t = x_indptr[q]; t < x_indptr[q + 1]; ++t)
+                if (x_idx[t] <= max_w_rows) { xs[x_idx[t]] = x_val[t]; touched[x_idx[t]] = 1; }
+        const float* xd = x_dense ? x_dense + (size_t)q * x_cols : NULL;
+        /* top-down */
+        uint32_t root = 0; float one = 1.0f;
+        uint32_t* prev_node = &root; float* prev_v = &one; size_t n_prev = 1;
+        int prev_owned = 0;
+        for (uint32_t l = 0; l < depth && rc == 0; ++l) {
+            const orc_layer_t* L = &layers[l];
+            const int kind = pp_kind >= 0 ? pp_kind : L->pp_kind;
+            const int pw = pp_kind >= 0 ? pp_p : L->pp_p;
+            const int use_bias = L->bias > 0.0f;
+            uint32_t* node = (uint32_t*)malloc((npat[l] + 1) * 4);
+            float* val = (float*)malloc((npat[l] + 1) * 4);
+            size_t k = 0;
+            for (size_t i = 0; i < n_prev && rc == 0; ++i) {
+                const uint32_t p = prev_node[i];
+                if (p >= L->C.cols) { rc = -1; break; }
+                for (uint64_t c = L->C.col_ptr[p]; c < L->C.col_ptr[p + 1]; ++c) {
+                    const uint32_t j = L->C.row_idx[c];
+                    if (!bsearch(&j, pat[l], npat[l], 4, orc_u32_cmp)) continue;   /* valid_cols.count(...) */
+                    if (k >= npat[l]) { rc = -2; break; }
+                    const uint64_t cb = L->W.col_ptr[j], ce = L->W.col_ptr[j + 1];
+                    const int has_b = use_bias && ce > cb && L->W.row_idx[ce - 1] == L->W.rows - 1;
+                    float res = 0.0f;
+                    if (xd) {
+                        if (use_bias) {
+                            uint64_t range = ce;
+                            if (has_b) { range = ce - 1; float pr = L->bias * L->W.val[ce - 1]; res = res + pr; }
+                            for (uint64_t e = cb; e < range; ++e) { float pr = xd[L->W.row_idx[e]] * L->W.val[e]; res = res + pr; }
+                        } else {
+                            float ret = 0.0f;
+                            for (uint64_t e = cb; e < ce; ++e) { float pr = xd[L->W.row_idx[e]] * L->W.val[e]; ret = ret + pr; }
+                            res = ret;
+                        }
+                    } else {
+                        if (has_b) { float pr = L->bias * L->W.val[ce - 1]; res = res + pr; }
+                        float ret = 0.0f;
+                        for (uint64_t e = cb; e < ce; ++e) {
+                            const uint32_t f = L->W.row_idx[e];
+                            if (touched[f]) { float pr = xs[f] * L->W.val[e]; ret = ret + pr; }
+                        }
+                        res = res + ret;
+                    }
+                    float v = orc_transform(kind, pw, res);
+                    if (l > 0) v = orc_combine(kind, v, prev_v[i]);
+                    node[k] = j; val[k] = v; ++k;
+                }
+            }
+            if (rc == 0 && k != npat[l]) rc = -2;
+            if (prev_owned) { free(prev_node); free(prev_v); }
+            prev_node = node; prev_v = val; n_prev = k; prev_owned = 1;
+        }
+        if (rc == 0) {
+            if (n_prev != n_sel) rc = -2;
+            else for (size_t i = 0; i < n_sel; ++i) { out_idx[sb + i] = prev_node[i]; out_val[sb + i] = prev_v[i]; }
+        }
+        if (prev_owned) { free(prev_node); free(prev_v); }
+        if (!x_dense)
+            for (uint64_t t = x_indptr[q]; t < x_indptr[q + 1]; ++t)
+                if (x_idx[t] <= max_w_rows) { xs[x_idx[t]] = 0.0f; touched[x_idx[t]] = 0; }
+        for (uint32_t l = 0; l < depth; ++l) free(pat[l]);
+        free(pat); free(npat);
+    }
+    for (uint32_t l = 0; l < depth; ++l) free(parent[l]);
+    free(parent); free(xs); free(touched);
+    return rc;
+}

@@ -158,6 +158,28 @@ class OracleModel:
         idx, val, cnt, _ = self.predict_arrays(X, beam_size, only_topk, post_processor)
         return _dense_rows_to_csr(idx, val, cnt, self.nr_labels)
 
+    def predict_on_selected_outputs(self, X, selected_outputs_csr, post_processor=None):
+        S = smat.csr_matrix(selected_outputs_csr)
+        sp, si = S.indptr.astype(np.uint64), S.indices.astype(np.uint32)
+        kind, p = parse_post_processor(post_processor) if post_processor else (-1, 0)
+        out_idx = np.zeros(S.nnz, np.uint32); out_val = np.zeros(S.nnz, np.float32)
+        if smat.issparse(X):
+            X = smat.csr_matrix(X, dtype=np.float32); X.sort_indices()
+            ip, ii, iv = X.indptr.astype(np.uint64), X.indices.astype(np.uint32), X.data.astype(np.float32)
+            xargs = (ip.ctypes.data, ii.ctypes.data, iv.ctypes.data, None, X.shape[1])
+        else:
+            Xd = np.ascontiguousarray(X, dtype=np.float32)
+            xargs = (None, None, None, Xd.ctypes.data, Xd.shape[1])
+        f = self.lib.orc_predict_selected
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        rc = f(C.addressof(self._arr), len(self.layers), X.shape[0], *xargs, sp.ctypes.data, si.ctypes.data, kind, p,
+               out_idx.ctypes.data, out_val.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"oracle predict_on_selected_outputs failed ({rc})")
+        return smat.csr_matrix((out_val, out_idx.astype(np.int64), S.indptr.astype(np.int64)), shape=S.shape)
+
 
 def sparse_inner_products(X, W, rows, cols):
     """Restatement of clib.sparse_inner_products (pecos/core/base.py:1536-1589)."""
@@ -252,5 +274,38 @@ class RefModel:
         fn.restype = None
         fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int, _ALLOC]
         fn(self.h, C.byref(px), beam_size, pp, only_topk, threads, cb)
+        return smat.csr_matrix((res["data"], res["indices"].astype(np.int64), res["indptr"].astype(np.int64)),
+                               shape=res["shape"])
+
+    def predict_on_selected_outputs(self, X, selected_outputs_csr, post_processor=None, threads=-1):
+        """c_xlinear_predict_on_selected_outputs_{csr,drm}_f32 (libpecos.cpp:179-198); CSC layers only."""
+        res = {}
+
+        def alloc(is_col_major, rows, cols, nnz, indices_pp, indptr_pp, data_pp):
+            res["indptr"] = np.zeros(rows + 1, np.uint64)
+            res["indices"] = np.zeros(nnz, np.uint32)
+            res["data"] = np.zeros(nnz, np.float32)
+            res["shape"] = (rows, cols)
+            C.cast(indices_pp, C.POINTER(C.c_uint64)).contents.value = res["indices"].ctypes.data
+            C.cast(indptr_pp, C.POINTER(C.c_uint64)).contents.value = res["indptr"].ctypes.data
+            C.cast(data_pp, C.POINTER(C.c_uint64)).contents.value = res["data"].ctypes.data
+
+        cb = _ALLOC(alloc)
+        pp = post_processor.encode() if post_processor else None
+        S = smat.csr_matrix(selected_outputs_csr, dtype=np.float32)
+        sb = (S.indptr.astype(np.uint64), S.indices.astype(np.uint32), S.data.astype(np.float32))
+        ps = _CsrF32(S.shape[0], S.shape[1], sb[0].ctypes.data, sb[1].ctypes.data, sb[2].ctypes.data)
+        if smat.issparse(X):
+            X = smat.csr_matrix(X, dtype=np.float32); X.sort_indices()
+            bufs = (X.indptr.astype(np.uint64), X.indices.astype(np.uint32), X.data.astype(np.float32))
+            px = _CsrF32(X.shape[0], X.shape[1], bufs[0].ctypes.data, bufs[1].ctypes.data, bufs[2].ctypes.data)
+            fn = self.lib.c_xlinear_predict_on_selected_outputs_csr_f32
+        else:
+            bufs = np.ascontiguousarray(X, np.float32)
+            px = _DrmF32(bufs.shape[0], bufs.shape[1], bufs.ctypes.data)
+            fn = self.lib.c_xlinear_predict_on_selected_outputs_drm_f32
+        fn.restype = None
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, _ALLOC]
+        fn(self.h, C.byref(px), C.byref(ps), pp, threads, cb)
         return smat.csr_matrix((res["data"], res["indices"].astype(np.int64), res["indptr"].astype(np.int64)),
                                shape=res["shape"])

@@ -177,6 +177,8 @@ class corelib(object):
             "c_xlinear_get_layer_type": (c_int, [c_void_p, c_int]),
             "c_xlinear_predict_csr_f32": (None, [c_void_p, POINTER(ScipyCsrF32), c_uint32, c_char_p, c_uint32, c_int, alloc_t]),
             "c_xlinear_predict_drm_f32": (None, [c_void_p, POINTER(ScipyDrmF32), c_uint32, c_char_p, c_uint32, c_int, alloc_t]),
+            "c_xlinear_predict_on_selected_outputs_csr_f32": (None, [c_void_p, POINTER(ScipyCsrF32), POINTER(ScipyCsrF32), c_char_p, c_int, alloc_t]),
+            "c_xlinear_predict_on_selected_outputs_drm_f32": (None, [c_void_p, POINTER(ScipyDrmF32), POINTER(ScipyCsrF32), c_char_p, c_int, alloc_t]),
             "c_xlinear_single_layer_predict_csr_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyCsrF32), POINTER(ScipyCscF32), POINTER(ScipyCscF32), c_char_p, c_uint32, c_int, c_float, alloc_t]),
             "c_xlinear_single_layer_predict_drm_f32": (None, [POINTER(ScipyDrmF32), POINTER(ScipyCsrF32), POINTER(ScipyCscF32), POINTER(ScipyCscF32), c_char_p, c_uint32, c_int, c_float, alloc_t]),
             "c_sparse_inner_products_csr2csc_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyCscF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
@@ -271,6 +273,30 @@ class corelib(object):
         c_predict(c_void_p(c_model), byref(X), overriden_beam_size if overriden_beam_size else 0,
                   overriden_post_processor_str.encode("utf-8") if overriden_post_processor_str else None,
                   overriden_only_topk if overriden_only_topk else 0, threads, cb)
+        self._check()
+
+    def xlinear_predict_on_selected_outputs(self, c_model, X, selected_outputs_csr, overriden_post_processor_str, threads,
+                                            pred_alloc):
+        """Scores for a given (query, label) pattern (base.py:1097-1141)."""
+        clib = self.clib_float32
+        if isinstance(X, smat.csr_matrix):
+            if not X.has_sorted_indices:
+                raise ValueError("Query matrix does not have sorted indices!")
+            X = ScipyCsrF32.init_from(X)
+        elif isinstance(X, np.ndarray):
+            X = ScipyDrmF32.init_from(X)
+        if not isinstance(selected_outputs_csr, smat.csr_matrix):
+            raise ValueError("type(selected_outputs_csr) = {} not implemented".format(type(selected_outputs_csr)))
+        S = ScipyCsrF32.init_from(selected_outputs_csr.astype(np.float32))
+        if isinstance(X, ScipyCsrF32):
+            c_predict = clib.c_xlinear_predict_on_selected_outputs_csr_f32
+        elif isinstance(X, ScipyDrmF32):
+            c_predict = clib.c_xlinear_predict_on_selected_outputs_drm_f32
+        else:
+            raise NotImplementedError("type(X) = {} not implemented".format(type(X)))
+        cb = pred_alloc.cfunc
+        c_predict(c_void_p(c_model), byref(X), byref(S),
+                  overriden_post_processor_str.encode("utf-8") if overriden_post_processor_str else None, threads, cb)
         self._check()
 
     def xlinear_single_layer_predict(self, X, csr_codes, W, C, post_processor_str, only_topk, num_threads, bias, pred_alloc):

@@ -125,6 +125,7 @@ std::unique_ptr<Model> model_from_arrays(uint32_t depth, const ScipyCscF32* cons
             for (uint32_t i = 0; i < w.cols; ++i) c.row_idx[i] = i;
         }
         m->layers.push_back(compile_layer(w, c, bias[d], only_topk[d], pp[d] ? pp[d] : "noop"));
+        m->layers.back()->w_host = std::make_shared<HostCsc>(std::move(w));
     }
     finalize_model(*m);
     return m;
@@ -173,6 +174,27 @@ void single_layer_predict(const XT* input_x, bool is_csr, const ScipyCsrF32* csr
     }
     o.no_prev_pred = !with_codes;   // combine only when csr_codes were given (libpecos.cpp:215-222)
     run_and_emit(*m, X, o, alloc);
+}
+
+template <class XT>
+void selected_host(void* ptr, const XT* input_x, bool is_csr, const ScipyCsrF32* S, const char* pp, py_sparse_allocator_t alloc) {
+    // libpecos.cpp:179-198 (C_XLINEAR_PREDICT_ON_SELECTED_OUTPUTS)
+    Model& m = *as_model(ptr);
+    if (!alloc) fail("null allocator callback");
+    if (!S) fail("null selected_outputs_csr");
+    std::lock_guard<std::mutex> g(m.mu);
+    use_device(m.device);
+    if (!m.ws) m.ws = std::make_unique<Workspace>();
+    QueriesDev X{};
+    if (is_csr) upload_csr(reinterpret_cast<const ScipyCsrF32*>(input_x), m.ws->x_ptr, m.ws->x_idx, m.ws->x_val, X);
+    else upload_drm(reinterpret_cast<const ScipyDrmF32*>(input_x), m.ws->x_val, X);
+    std::vector<uint32_t> oi; std::vector<float> ov;
+    predict_selected(m, X, S->rows, S->cols, S->row_ptr, S->col_idx, pp, oi, ov);
+    uint32_t* o_idx = nullptr; uint64_t* o_ptr = nullptr; float* o_val = nullptr;
+    alloc(false, S->rows, S->cols, oi.size(), &o_idx, &o_ptr, &o_val);
+    if (!o_ptr || (!oi.empty() && (!o_idx || !o_val))) fail("allocator callback returned null buffers");
+    std::memcpy(o_ptr, S->row_ptr, ((size_t)S->rows + 1) * 8);
+    if (!oi.empty()) { std::memcpy(o_idx, oi.data(), oi.size() * 4); std::memcpy(o_val, ov.data(), ov.size() * 4); }
 }
 
 template <class XT, class WT>
@@ -294,6 +316,20 @@ void c_xlinear_predict_drm_f32(void* ptr, const ScipyDrmF32* input_x, const uint
                                const int threads, py_sparse_allocator_t pred_alloc) {
     (void)threads;
     guarded([&] { predict_host(ptr, input_x, overridden_beam_size, overridden_post_processor_str, overridden_only_topk, pred_alloc, false); });
+}
+
+void c_xlinear_predict_on_selected_outputs_csr_f32(void* ptr, const ScipyCsrF32* input_x, const ScipyCsrF32* selected_outputs_csr,
+                                                   const char* overridden_post_processor_str, const int threads,
+                                                   py_sparse_allocator_t pred_alloc) {
+    (void)threads;
+    guarded([&] { selected_host(ptr, input_x, true, selected_outputs_csr, overridden_post_processor_str, pred_alloc); });
+}
+
+void c_xlinear_predict_on_selected_outputs_drm_f32(void* ptr, const ScipyDrmF32* input_x, const ScipyCsrF32* selected_outputs_csr,
+                                                   const char* overridden_post_processor_str, const int threads,
+                                                   py_sparse_allocator_t pred_alloc) {
+    (void)threads;
+    guarded([&] { selected_host(ptr, input_x, false, selected_outputs_csr, overridden_post_processor_str, pred_alloc); });
 }
 
 void c_xlinear_single_layer_predict_csr_f32(const ScipyCsrF32* input_x, const ScipyCsrF32* csr_codes, ScipyCscF32* W,

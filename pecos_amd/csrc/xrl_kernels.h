@@ -60,6 +60,11 @@ void launch_k3_inner_products(const uint64_t* x_ptr, const uint32_t* x_idx, cons
                               float* out, hipStream_t s);
 
 void k1_set_ablate(int mask);   // debug only
+// K4  predict_on_selected_outputs: one layer of (query, node) pairs against CSC W
+void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, uint32_t w_rows, float bias,
+                        const QueriesDev& X, const uint32_t* pair_q, const uint32_t* node, const uint32_t* ppos,
+                        const uint64_t* prev_off, const float* prev_val, float* out_val, uint64_t n_pairs,
+                        const PostProc& pp, int first_layer, hipStream_t s);
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
 size_t k2_max_k();
 

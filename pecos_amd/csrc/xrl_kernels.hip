@@ -729,6 +729,89 @@ void launch_stats(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uin
 }
 
 // ---------------------------------------------------------------------------------------------
+// K4: predict_on_selected_outputs, one layer: one thread per (query, selected node) pair against the
+// CSC column (vector_ops::inner_product, inference.hpp:1018-1078):
+//   sparse X: res = 0; res += bias*w_bias (explicit entry only); res += dot(x, w)  [dot summed separately]
+//   dense  X: bias>0: res = bias*w_bias, then res += x[idx]*w over the non-bias entries, in order
+//             bias<=0: dot over all entries
+// then transform, and combine with the parent's value (prolongate_sparse_predictions, :1302-1358).
+// ---------------------------------------------------------------------------------------------
+struct K4Args {
+    const uint64_t* col_ptr; const uint32_t* row_idx; const float* val;   // W in CSC, ORIGINAL column ids
+    QueriesDev X;
+    const uint32_t* pair_q; const uint32_t* node; const uint32_t* ppos;
+    const uint64_t* prev_off;    // [rows+1] offsets of the previous layer's per-query lists
+    const float* prev_val;
+    float* out_val;
+    uint64_t n_pairs;
+    uint32_t w_rows;
+    float bias;
+    int pp_kind, pp_p, first_layer;
+};
+
+template <int PPC>
+__global__ void __launch_bounds__(256) k4_selected_kernel(K4Args a) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_pairs) return;
+    const uint32_t q = a.pair_q[i], j = a.node[i];
+    const uint64_t cb = a.col_ptr[j], ce = a.col_ptr[j + 1];
+    const bool use_bias = a.bias > 0.0f;
+    const bool has_b = use_bias && ce > cb && a.row_idx[ce - 1] == a.w_rows - 1;
+    float res = 0.0f;
+    if (a.X.dense) {
+        const float* __restrict__ x = a.X.val + (uint64_t)q * a.X.cols;
+        uint64_t range = ce;
+        if (use_bias && has_b) { range = ce - 1; res = __fadd_rn(res, __fmul_rn(a.bias, a.val[ce - 1])); }
+        for (uint64_t e = cb; e < range; ++e) {
+            const uint32_t f = a.row_idx[e];
+            res = __fadd_rn(res, __fmul_rn(f < a.X.cols ? x[f] : 0.0f, a.val[e]));
+        }
+    } else {
+        if (has_b) res = __fadd_rn(res, __fmul_rn(a.bias, a.val[ce - 1]));
+        float dot = 0.0f;
+        uint64_t s = a.X.row_ptr[q];
+        const uint64_t se = a.X.row_ptr[q + 1];
+        uint64_t t = cb;
+        if ((ce - cb) > 8 * (se - s)) {          // long column: x-driven binary search, same ascending order
+            for (; s < se && t < ce; ++s) {
+                const uint32_t f = a.X.col_idx[s];
+                uint64_t lo = t, hi = ce;
+                while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (a.row_idx[mid] < f) lo = mid + 1; else hi = mid; }
+                t = lo;
+                if (t < ce && a.row_idx[t] == f) { dot = __fadd_rn(dot, __fmul_rn(a.X.val[s], a.val[t])); ++t; }
+            }
+        } else {
+            while (s < se && t < ce) {
+                const uint32_t fx = a.X.col_idx[s], fw = a.row_idx[t];
+                if (fx == fw) { dot = __fadd_rn(dot, __fmul_rn(a.X.val[s], a.val[t])); ++s; ++t; }
+                else if (fx < fw) ++s;
+                else ++t;
+            }
+        }
+        res = __fadd_rn(res, dot);
+    }
+    float v = pp_transform<PPC>(a.pp_kind, a.pp_p, res);
+    if (!a.first_layer) v = pp_combine(a.pp_kind, v, a.prev_val[a.prev_off[q] + a.ppos[i]]);
+    a.out_val[i] = v;
+}
+
+void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, uint32_t w_rows, float bias,
+                        const QueriesDev& X, const uint32_t* pair_q, const uint32_t* node, const uint32_t* ppos,
+                        const uint64_t* prev_off, const float* prev_val, float* out_val, uint64_t n_pairs,
+                        const PostProc& pp, int first_layer, hipStream_t s) {
+    if (n_pairs == 0) return;
+    K4Args a;
+    a.col_ptr = col_ptr; a.row_idx = row_idx; a.val = val; a.X = X; a.pair_q = pair_q; a.node = node; a.ppos = ppos;
+    a.prev_off = prev_off; a.prev_val = prev_val; a.out_val = out_val; a.n_pairs = n_pairs; a.w_rows = w_rows; a.bias = bias;
+    a.pp_kind = pp.kind; a.pp_p = pp.p; a.first_layer = first_layer;
+    const uint64_t blocks = (n_pairs + 255) / 256;
+    if (blocks > 0x7FFFFFFFull) fail("k4: too many (query, label) pairs in one call");
+    if (pp_class(pp)) hipLaunchKernelGGL(k4_selected_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k4_selected_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, s, a);
+    XRL_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3: sparse_inner_products, one thread per (row, col) pair, sequential fp32 accumulation in
 // ascending index order (do_dot_product overloads, matrix.hpp:836-877)
 // ---------------------------------------------------------------------------------------------

@@ -99,6 +99,9 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     L->reordered = !contiguous;
     L->n_children = (uint32_t)c_nnz;
     const uint32_t P = C.cols;
+    L->h_c_ptr = C.col_ptr; L->h_c_idx.assign(C.row_idx.begin(), C.row_idx.begin() + c_nnz);
+    L->h_parent.assign(C.rows, 0xFFFFFFFFu);
+    for (uint32_t p = 0; p < P; ++p) for (uint64_t c = C.col_ptr[p]; c < C.col_ptr[p + 1]; ++c) L->h_parent[C.row_idx[c]] = p;
 
     // tiles
     std::vector<uint32_t> ptile(P + 1, 0), chunk_col(P + 1, 0);
@@ -243,6 +246,20 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     return L;
 }
 
+void ensure_device_csc(Layer& L) {
+    if (L.csc_ready) return;
+    HostCsc tmp;
+    const HostCsc* W = L.w_host.get();
+    if (!W) {
+        if (L.w_path.empty()) fail("predict_on_selected_outputs: the layer's CSC weights are not available");
+        load_csc_npz(L.w_path, tmp);
+        W = &tmp;
+    }
+    L.d_csc_ptr.upload(W->col_ptr); L.d_csc_idx.upload(W->row_idx); L.d_csc_val.upload(W->val);
+    L.device_bytes += L.d_csc_ptr.cap + L.d_csc_idx.cap + L.d_csc_val.cap;
+    L.csc_ready = true;
+}
+
 void finalize_model(Model& m) {
     if (m.layers.empty()) fail("model has no layers");
     const Layer& last = *m.layers.back();
@@ -289,6 +306,7 @@ std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_
             load_csc_npz(lp + "/C.npz", C);
         }
         m->layers.push_back(compile_layer(W, C, (float)bias->num, (uint32_t)topk->num, pp->str));
+        m->layers.back()->w_path = lp + "/W.npz";
     }
     finalize_model(*m);
     return m;

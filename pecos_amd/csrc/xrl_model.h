@@ -74,6 +74,11 @@ struct Layer {
     uint32_t n_tiles = 0, nwords = 0, max_tiles_per_parent = 0, max_tile_cols = 0, max_chunk_cols = 0;
     uint64_t nnz = 0, total_rows = 0;
     std::vector<uint32_t> chunk_sizes_desc;  // chunk sizes sorted descending (cand stride bound)
+    // predict_on_selected_outputs (inference.hpp:2507-2571): host copy of C's pattern, child -> parent,
+    // and W in CSC form on the device (uploaded lazily: from w_path, or from w_host for in-memory models)
+    std::vector<uint64_t> h_c_ptr; std::vector<uint32_t> h_c_idx, h_parent;
+    std::string w_path; std::shared_ptr<HostCsc> w_host;
+    DevBuf d_csc_ptr, d_csc_idx, d_csc_val; bool csc_ready = false;
     // device storage
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
     LayerDev dev{};
@@ -124,5 +129,6 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
 // Load <path>/param.json + {d}.model/ (HierarchicalMLModel::load, inference.hpp:2616-2655).
 std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_matrix_type);
 void finalize_model(Model& m);
+void ensure_device_csc(Layer& L);   // upload W as CSC (original column ids) if not there yet
 
 }  // namespace xrl

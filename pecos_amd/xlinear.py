@@ -222,6 +222,29 @@ class HierarchicalMLModel:
         return pred_alloc.get()
 
 
+def _selected(self, X, selected_outputs_csr, pred_params=None, **kwargs):
+    """HierarchicalMLModel.predict_on_selected_outputs, pecos/xmc/base.py:1682-1790."""
+    if X.dtype != np.float32:
+        raise ValueError("X.dtype = {} is not supported".format(X.dtype))
+    if not isinstance(X, smat.csr_matrix) and not (isinstance(X, np.ndarray) and X.flags["C_CONTIGUOUS"]):
+        raise ValueError("type(X) = {} is not supported".format(type(X)))
+    if X.shape[1] != self.nr_features:
+        raise ValueError("Feature dimension of query matrix does not match weight matrix")
+    if not isinstance(selected_outputs_csr, smat.csr_matrix):
+        raise ValueError("type(selected_outputs_csr) = {} is not supported".format(type(selected_outputs_csr)))
+    if selected_outputs_csr.shape[1] != self.nr_pred_cols:
+        raise ValueError("Label dimension of selected output matrix does not match")
+    if X.shape[0] != selected_outputs_csr.shape[0]:
+        raise ValueError("Instance dimension of query and selected output matrix do not match")
+    _, pp, _ = self._resolve_overrides(pred_params, {k: v for k, v in kwargs.items() if k == "post_processor"})
+    pred_alloc = ScipyCompressedSparseAllocator()
+    clib.xlinear_predict_on_selected_outputs(self.model_chain, X, selected_outputs_csr, pp, kwargs.get("threads", -1), pred_alloc)
+    return pred_alloc.get()
+
+
+HierarchicalMLModel.predict_on_selected_outputs = _selected
+
+
 def vstack_csr(matrices):
     """Row-stack CSR blocks keeping the (score-sorted) order inside rows (smat_util.py:343-390)."""
     indptr = [np.zeros(1, dtype=np.int64)]
@@ -289,13 +312,16 @@ class XLinearModel:
         max_pred_chunk = kwargs.get("max_pred_chunk", 10**7)
         if not (max_pred_chunk is None or isinstance(max_pred_chunk, int)):
             raise TypeError("type(max_pred_chunk) is not supported.")
-        if selected_outputs_csr is not None:
-            raise NotImplementedError("predict_on_selected_outputs is not implemented on MI355X yet (SURVEY.md N1)")
         if max_pred_chunk is None or max_pred_chunk >= X.shape[0]:
             kw = {k: v for k, v in kwargs.items() if k != "max_pred_chunk"}
-            return self.model.predict(X, pred_params=None if pred_params is None else pred_params.hlm_args, **kw)
+            hp = None if pred_params is None else pred_params.hlm_args
+            if selected_outputs_csr is None:
+                return self.model.predict(X, pred_params=hp, **kw)
+            return self.model.predict_on_selected_outputs(X, selected_outputs_csr, pred_params=hp, **kw)
         new_kwargs = kwargs.copy()
         new_kwargs.pop("max_pred_chunk", None)
-        Ys = [self.predict(X[i: i + max_pred_chunk, :], pred_params=pred_params, **new_kwargs)
+        Ys = [self.predict(X[i: i + max_pred_chunk, :], pred_params=pred_params,
+                           selected_outputs_csr=(selected_outputs_csr[i: i + max_pred_chunk, :]
+                                                 if selected_outputs_csr is not None else None), **new_kwargs)
               for i in range(0, X.shape[0], max_pred_chunk)]
         return vstack_csr(Ys)

@@ -190,6 +190,42 @@ def test_single_layer_predict(clib, oracle_mod):
     assert_same_topk(alloc.get(), om2.predict(X, beam_size=3, only_topk=6), exact_scores=True, what="layer 1 with codes")
 
 
+def test_predict_on_selected_outputs(manifest, XLM, oracle_mod):
+    # N1: c_xlinear_predict_on_selected_outputs (libpecos.cpp:179-198).  (1) the reference's own -so golden
+    # (test_xlinear.py:368-383); (2) bit-exact vs the CSC-route restatement (pinned on the real reference),
+    # output ORDER included, sparse and dense queries.
+    Xt = load_X(os.path.join(GOLDEN, "ref_fixtures", "Xt.npz"))
+    G = smat.load_npz(os.path.join(GOLDEN, "ref_fixtures", "Yt_pred.npz")).tocsr()
+    m = XLM.load(os.path.join(GOLDEN, "models", "mls10"))
+    P = m.predict(Xt, selected_outputs_csr=G)
+    assert np.allclose(P.toarray(), G.toarray(), atol=1e-6)
+    for name in ["s_eurlex", "s_contig", "s_deep", "s_nobias", "s_flat", "s_wide"]:
+        folder = os.path.join(GOLDEN, "synth", name)
+        X = load_X(os.path.join(GOLDEN, "synth", name + "__X.npz"))
+        m = XLM.load(folder)
+        om = oracle_mod.OracleModel.load(folder)
+        rm = oracle_mod.RefModel(folder, "CSC") if oracle_mod.ref_available() else None
+        S = om.predict(X, beam_size=6, only_topk=8)
+        S = smat.csr_matrix((S.data, S.indices, S.indptr), shape=(S.shape[0], m.nr_pred_cols))
+        for pp in (None, "sigmoid", "log-l2-hinge", "noop"):
+            for Xq in (X, np.ascontiguousarray(X.toarray())):
+                kw = {"post_processor": pp} if pp else {}
+                a = m.predict(Xq, selected_outputs_csr=S, **kw)
+                b = om.predict_on_selected_outputs(Xq, S, pp)
+                assert_same_topk(a, b, exact_scores=EXACT_PP(pp), what=f"{name} {pp}")
+                if rm is not None:
+                    assert_same_topk(a, rm.predict_on_selected_outputs(Xq, S, pp), exact_scores=EXACT_PP(pp), what=f"ref {name} {pp}")
+        # top-k and selected-outputs agree on the top-k pattern (test_xlinear.py:1059-1137)
+        T = m.predict(X, beam_size=6, only_topk=8)
+        Ssel = m.predict(X, selected_outputs_csr=T, beam_size=6)
+        assert np.allclose(Ssel.toarray(), T.toarray(), atol=1e-6)
+    with pytest.raises(ValueError):
+        m.predict(X, selected_outputs_csr=smat.csr_matrix((X.shape[0], 3), dtype=np.float32))
+    dup = smat.csr_matrix((np.ones(2, np.float32), np.array([1, 1]), np.array([0, 2] + [2] * (X.shape[0] - 1))), shape=(X.shape[0], m.nr_pred_cols))
+    with pytest.raises(RuntimeError, match="twice"):
+        m.predict(X, selected_outputs_csr=dup)
+
+
 def test_full_size_properties(XLM, clib, tmp_path):
     # BASELINE.json configs[1] (Eurlex-4K shape) at FULL size through size-independent properties
     import xrl_synth

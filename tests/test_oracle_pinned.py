@@ -70,3 +70,23 @@ def test_oracle_sparse_inner_products_kat(oracle_mod):
     W = Y.T.tocsc()
     for Xq, Wq in [(X, W), (X.toarray(), W), (X, np.asfortranarray(W.toarray())), (X.toarray(), np.asfortranarray(W.toarray()))]:
         assert np.allclose(oracle_mod.sparse_inner_products(Xq, Wq, r, c), true, atol=1e-9)
+
+
+def test_oracle_selected_outputs(manifest, oracle_mod):
+    # reference golden: `predict -so Yt_pred.npz` reproduces Yt_pred (test_xlinear.py:368-383), and the
+    # CSC-route restatement is bit-identical to the real reference (values AND output order) when present
+    Xt = load_X(os.path.join(GOLDEN, "ref_fixtures", "Xt.npz"))
+    G = smat.load_npz(os.path.join(GOLDEN, "ref_fixtures", "Yt_pred.npz")).tocsr()
+    om = oracle_mod.OracleModel.load(os.path.join(GOLDEN, "models", "mls10"))
+    assert np.allclose(om.predict_on_selected_outputs(Xt, G).toarray(), G.toarray(), atol=1e-6)
+    if not oracle_mod.ref_available():
+        return
+    for name in ["s_eurlex", "s_deep", "s_nobias", "s_flat"]:
+        folder = os.path.join(GOLDEN, "synth", name)
+        X = load_X(os.path.join(GOLDEN, "synth", name + "__X.npz"))
+        om = oracle_mod.OracleModel.load(folder); rm = oracle_mod.RefModel(folder, "CSC")
+        S = om.predict(X, beam_size=6, only_topk=8)
+        for pp in (None, "sigmoid", "log-l2-hinge"):
+            for Xq in (X, np.ascontiguousarray(X.toarray())):
+                assert_same_topk(om.predict_on_selected_outputs(Xq, S, pp), rm.predict_on_selected_outputs(Xq, S, pp),
+                                 exact_scores=True, what=f"{name} {pp}")
