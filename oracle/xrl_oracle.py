@@ -248,7 +248,8 @@ class RefModel:
             self.lib.c_xlinear_destruct_model(self.h)
             self.h = None
 
-    def predict(self, X, beam_size=0, only_topk=0, post_processor=None, threads=-1):
+    def predict(self, X, beam_size=0, only_topk=0, post_processor=None, threads=8):
+        # threads: the reference's OpenMP path crawls with hundreds of threads on small batches
         res = {}
 
         def alloc(is_col_major, rows, cols, nnz, indices_pp, indptr_pp, data_pp):
@@ -277,7 +278,7 @@ class RefModel:
         return smat.csr_matrix((res["data"], res["indices"].astype(np.int64), res["indptr"].astype(np.int64)),
                                shape=res["shape"])
 
-    def predict_on_selected_outputs(self, X, selected_outputs_csr, post_processor=None, threads=-1):
+    def predict_on_selected_outputs(self, X, selected_outputs_csr, post_processor=None, threads=8):
         """c_xlinear_predict_on_selected_outputs_{csr,drm}_f32 (libpecos.cpp:179-198); CSC layers only."""
         res = {}
 
