@@ -266,6 +266,8 @@ struct K1Args {
     uint32_t row0, acc_stride;
     int pp_kind, pp_p, first_layer;
     int ablate;                  // debug: phase-skipping mask for timing ablations (0 in production)
+    uint32_t lds_per_wave;       // bytes of dynamic LDS owned by each wavefront of a block
+    uint32_t n_vblocks;          // number of wavefront-sized work blocks
 };
 
 template <int G, int PPC, class ACC>
@@ -306,22 +308,27 @@ template <int G, int NS> struct K1Cfg {
 };
 
 template <int G, int NS, int PPC, bool DENSE>
-__global__ void __launch_bounds__(64) k1_kernel(K1Args a) {
+__global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, UH = K1Cfg<G, NS>::UH, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    // the wavefronts of a block are fully independent: each owns a slice of the dynamic LDS
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t vblock = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (vblock >= a.n_vblocks) return;
+    unsigned char* smem = smem_all + (size_t)wave * a.lds_per_wave;
     uint4* uq = reinterpret_cast<uint4*>(smem);                        // units {x value, entry start, count, -}
     uint2* hq = reinterpret_cast<uint2*>(uq + W * UH);                 // hits  {x value, row slot}
     float* acc = reinterpret_cast<float*>(hq + W * H);
     const uint32_t acc_item = a.acc_stride + G;                        // + one private dummy slot per lane
 
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int grp = lane / G, lig = lane % G;
     ItemDesc it{0u, kNoTile, 0u, 0.f};
     if (a.n_items) {   // tile-sorted list: every XCD takes a contiguous run of tiles
         const uint32_t n = *a.n_items, nb = (n + W - 1) / W;
-        if (blockIdx.x < nb) { const uint64_t slot = (uint64_t)xcd_remap(blockIdx.x, nb) * W + grp; if (slot < n) it = a.items[slot]; }
+        if (vblock < nb) { const uint64_t slot = (uint64_t)xcd_remap(vblock, nb) * W + grp; if (slot < n) it = a.items[slot]; }
     } else {
-        const uint64_t slot = (uint64_t)blockIdx.x * W + grp;
+        const uint64_t slot = (uint64_t)vblock * W + grp;
         if (slot < a.n_slots) it = a.items[slot];
     }
     const bool active = it.tile != kNoTile;
@@ -496,14 +503,23 @@ __global__ void __launch_bounds__(64) k1_kernel(K1Args a) {
     k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0);
 }
 
+int g_k1_wpb = 1;   // wavefronts per workgroup (tuning knob)
+void k1_set_wpb(int w) { g_k1_wpb = (w == 2 || w == 4) ? w : 1; }
+
 template <class KERNEL>
-static void launch_k1_any(KERNEL kernel, const K1Args& a, int W, size_t lds, hipStream_t s) {
+static void launch_k1_any(KERNEL kernel, K1Args a, int W, size_t lds_wave, hipStream_t s) {
+    lds_wave = (lds_wave + 15) & ~(size_t)15;
+    int wpb = g_k1_wpb;
+    while (wpb > 1 && lds_wave * wpb > 160 * 1024) wpb >>= 1;
+    const size_t lds = lds_wave * wpb;
     if (lds > 160 * 1024) fail("k1: LDS request exceeds 160 KiB");
     if (lds > 48 * 1024)
         XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const uint64_t blocks = (a.n_slots + W - 1) / W;
-    if (blocks > 0x7FFFFFFFull) fail("k1: grid too large; lower max_batch_rows");
-    hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(64), lds, s, a);
+    const uint64_t vblocks = (a.n_slots + W - 1) / W;
+    const uint64_t blocks = (vblocks + wpb - 1) / wpb;
+    if (vblocks > 0x7FFFFFFFull) fail("k1: grid too large; lower max_batch_rows");
+    a.lds_per_wave = (uint32_t)lds_wave; a.n_vblocks = (uint32_t)vblocks;
+    hipLaunchKernelGGL(kernel, dim3((uint32_t)blocks), dim3(64 * wpb), lds, s, a);
     XRL_LAUNCH_CHECK();
 }
 
