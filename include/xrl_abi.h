@@ -197,6 +197,10 @@ int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char
 /* Tuning knobs (benchmark / tests only): key in {"k1_group", "max_batch_rows", "sort_min_tiles"} */
 int xrl_set_option(void* model, const char* key, int64_t value);
 
+/* Debug: with option k1_ablate bit 6 set, K1 accumulates per-phase shader cycles
+ * [prologue, fill, D1, D3, epilogue, #waves, -, -]; this reads (and optionally resets) them. */
+void xrl_debug_k1_phases(unsigned long long* out8, int reset);
+
 /* Bytes of HBM held by the compiled model. */
 uint64_t xrl_model_device_bytes(void* model);
 

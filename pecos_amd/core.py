@@ -198,6 +198,7 @@ class corelib(object):
             "xrl_profile_get": (c_uint32, [c_void_p, POINTER(ProfileRec), c_uint32]),
             "xrl_set_option": (c_int, [c_void_p, c_char_p, c_int64]),
             "xrl_model_device_bytes": (c_uint64, [c_void_p]),
+            "xrl_debug_k1_phases": (None, [POINTER(c_uint64), c_int]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(lib, name)
@@ -405,6 +406,12 @@ class corelib(object):
     def set_option(self, c_model, key, value):
         self.clib_float32.xrl_set_option(c_void_p(c_model), key.encode("utf-8"), int(value))
         self._check()
+
+    def debug_k1_phases(self, reset=True):
+        out = (c_uint64 * 8)()
+        self.clib_float32.xrl_debug_k1_phases(out, 1 if reset else 0)
+        self._check()
+        return [int(v) for v in out]
 
     def model_device_bytes(self, c_model):
         return int(self.clib_float32.xrl_model_device_bytes(c_void_p(c_model)))

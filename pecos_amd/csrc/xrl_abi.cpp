@@ -511,6 +511,8 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
     return rc;
 }
 
+void xrl_debug_k1_phases(unsigned long long* out8, int reset) { guarded([&] { k1_phase_read(out8, reset != 0); }); }
+
 uint64_t xrl_model_device_bytes(void* model) {
     uint64_t v = 0;
     guarded([&] { v = as_model(model)->device_bytes(); });

@@ -61,6 +61,8 @@ void launch_k3_inner_products(const uint64_t* x_ptr, const uint32_t* x_idx, cons
 
 void k1_set_ablate(int mask);   // debug only
 void k1_set_wpb(int waves_per_block);
+unsigned long long* k1_phase_buffer();
+void k1_phase_read(unsigned long long out[8], bool reset);   // debug: per-phase cycle totals of K1
 // K4  predict_on_selected_outputs: one layer of (query, node) pairs against CSC W
 void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, uint32_t w_rows, float bias,
                         const QueriesDev& X, const uint32_t* pair_q, const uint32_t* node, const uint32_t* ppos,

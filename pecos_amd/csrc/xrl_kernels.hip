@@ -268,6 +268,7 @@ struct K1Args {
     int ablate;                  // debug: phase-skipping mask for timing ablations (0 in production)
     uint32_t lds_per_wave;       // bytes of dynamic LDS owned by each wavefront of a block
     uint32_t n_vblocks;          // number of wavefront-sized work blocks
+    unsigned long long* phase;   // debug (ablate bit 6): per-phase cycle totals [prologue, fill, D1, D3, epilogue, waves]
 };
 
 template <int G, int PPC, class ACC>
@@ -323,6 +324,9 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
 
     const int lane = threadIdx.x & 63;
     const int grp = lane / G, lig = lane % G;
+    const bool prof = a.phase != nullptr;
+    unsigned long long t_last = prof ? __builtin_readcyclecounter() : 0ull, t_ph[5] = {0, 0, 0, 0, 0};
+    auto tick = [&](int ph) { if (prof) { const unsigned long long t = __builtin_readcyclecounter(); t_ph[ph] += t - t_last; t_last = t; } };
     ItemDesc it{0u, kNoTile, 0u, 0.f};
     if (a.n_items) {   // tile-sorted list: every XCD takes a contiguous run of tiles
         const uint32_t n = *a.n_items, nb = (n + W - 1) / W;
@@ -360,9 +364,11 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     const unsigned long long below = (1ull << lig) - 1ull;
     const uint64_t xlast = xe > cur ? xe - 1 : 0;                      // a valid x index for clamped loads
     uint32_t nh = 0;                                                   // hits waiting in this item's queue
+    tick(0);
 
     auto drain = [&]() {
         if (a.ablate & 4) { nh = 0; return; }
+        tick(1);
         wave_sync_lds();
         // ---- D1: one lane per hit fetches the row extent and cuts the row into units of <= G entries,
         //      written in order (segmented scan of the unit counts when a row can span several units)
@@ -390,6 +396,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
             nu += (G > 1) ? __shfl(incl, G - 1, G) : incl;
         }
         wave_sync_lds();
+        tick(2);
         // ---- D3: units in order.  Two register batches of P units are in flight: while batch A is
         //      applied the entries of batch B are already loading (unconditional, clamped loads; a load
         //      behind a per-lane branch makes hipcc wait vmcnt(0) before each one).  The lanes of a unit
@@ -432,6 +439,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
             apply_batch(B2);
         }
         nh = 0;
+        tick(3);
     };
 
     if (DENSE) {
@@ -501,6 +509,10 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     }
     drain();
     k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0);
+    if (prof) {
+        tick(4);
+        if (lane == 0) { for (int i = 0; i < 5; ++i) atomicAdd(&a.phase[i], t_ph[i]); atomicAdd(&a.phase[5], 1ull); }
+    }
 }
 
 int g_k1_wpb = 1;   // wavefronts per workgroup (tuning knob)
@@ -525,6 +537,16 @@ static void launch_k1_any(KERNEL kernel, K1Args a, int W, size_t lds_wave, hipSt
 
 int g_k1_ablate = 0;
 void k1_set_ablate(int mask) { g_k1_ablate = mask; }
+static unsigned long long* g_phase_buf = nullptr;
+unsigned long long* k1_phase_buffer() {
+    if (!g_phase_buf) { XRL_HIP(hipMalloc(&g_phase_buf, 8 * 8)); XRL_HIP(hipMemset(g_phase_buf, 0, 64)); }
+    return g_phase_buf;
+}
+void k1_phase_read(unsigned long long out[8], bool reset) {
+    XRL_HIP(hipDeviceSynchronize());
+    XRL_HIP(hipMemcpy(out, k1_phase_buffer(), 64, hipMemcpyDeviceToHost));
+    if (reset) XRL_HIP(hipMemset(g_phase_buf, 0, 64));
+}
 
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense) {
     // lanes per item: a 16- or 32-lane group whose NS slices cover the widest tile row
@@ -549,6 +571,7 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
     a.acc_stride = L.max_tile_cols | 1u;
     a.ablate = g_k1_ablate;
+    a.phase = (g_k1_ablate & 64) ? k1_phase_buffer() : nullptr;
     const int ppc = pp_class(P.pp);
 #define XRL_K1(GG, NN) do { \
         const size_t lds = K1Cfg<GG, NN>::lds_bytes(a.acc_stride); \
