@@ -302,7 +302,7 @@ template <int G, int NS> struct K1Cfg {
     static constexpr int U = (G >= 32) ? 2 : (G == 16 ? 4 : 8);   // query features per lane per step
     static constexpr int H = (G > 32) ? 2 * G : 64;       // hit queue depth per item (>= G)
     static constexpr int UH = H * NS;                     // unit queue depth per item
-    static constexpr int P = 4;
+    static constexpr int P = 8;
     static constexpr size_t lds_bytes(uint32_t acc_stride) {
         return (size_t)W * UH * 16 + (size_t)W * H * 8 + (size_t)W * (acc_stride + G) * 4;
     }
@@ -402,28 +402,32 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
         //      behind a per-lane branch makes hipcc wait vmcnt(0) before each one).  The lanes of a unit
         //      hold distinct columns; lanes without an entry add 0 to a private dummy slot.  LDS
         //      operations of one wavefront execute in order, so only a compiler fence separates units.
-        struct Batch { uint4 u[P]; Entry e[P]; };
+        struct Batch { Entry e[P]; };      // unit descriptors are re-read from LDS at apply time (saves VGPRs)
         auto load_batch = [&](uint32_t i0, Batch& B) {
+            uint32_t st[P], cn[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const bool ok = i0 + p < nu;
                 const uint4 d = my_uq[ok ? i0 + p : 0u];
-                B.u[p] = make_uint4(d.x, ok ? d.y : 0u, ok ? d.z : 0u, 0u);
+                st[p] = ok ? d.y : 0u; cn[p] = ok ? d.z : 0u;
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p) B.e[p] = ent[B.u[p].y + ((uint32_t)lig < B.u[p].z ? (uint32_t)lig : 0u)];
+            for (int p = 0; p < P; ++p) B.e[p] = ent[st[p] + ((uint32_t)lig < cn[p] ? (uint32_t)lig : 0u)];
         };
-        auto apply_batch = [&](const Batch& B) {
+        auto apply_batch = [&](uint32_t i0, const Batch& B) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const float v = __uint_as_float(B.u[p].x);
-                const bool valid = (uint32_t)lig < B.u[p].z;
+                const bool ok = i0 + p < nu;
+                const uint4 d = my_uq[ok ? i0 + p : 0u];
+                const uint32_t cnt_u = ok ? d.z : 0u;
+                const float v = __uint_as_float(d.x);
+                const bool valid = (uint32_t)lig < cnt_u;
                 const uint32_t ci = valid ? B.e[p].col : dummy;
                 const float pr = valid ? __fmul_rn(v, B.e[p].val) : 0.0f;      // scalar * val (inference.hpp:512-517)
                 my_acc[ci] = __fadd_rn(my_acc[ci], pr);                        // mul then add, no fma
-                if (__any(B.u[p].z > (uint32_t)G)) {                           // remainder of an over-long last unit
-                    for (uint32_t x = lig + G; x < B.u[p].z; x += G) {
-                        const Entry en = ent[B.u[p].y + x];
+                if (__any(cnt_u > (uint32_t)G)) {                              // remainder of an over-long last unit
+                    for (uint32_t x = lig + G; x < cnt_u; x += G) {
+                        const Entry en = ent[d.y + x];
                         my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(v, en.val));
                     }
                 }
@@ -434,9 +438,9 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
         load_batch(0u, A);
         for (uint32_t i0 = 0; __any(i0 < nu); i0 += 2 * P) {
             load_batch(i0 + P, B2);
-            apply_batch(A);
+            apply_batch(i0, A);
             load_batch(i0 + 2 * P, A);
-            apply_batch(B2);
+            apply_batch(i0 + P, B2);
         }
         nh = 0;
         tick(3);
@@ -463,29 +467,32 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
         k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, false);
         return;
     }
+    uint32_t skip = 0;                 // u-slices of the current step already queued (after an overflow)
     while (__any(cur < xe)) {
-        // ---- load step: U*G consecutive features of the item
-        uint32_t f[U]; float v[U]; BmWord w[U];
+        bool overflow = false;
+        {
+            // ---- load step: U*G consecutive features of the item
+            uint32_t f[U]; float v[U]; BmWord w[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint64_t t = cur + (uint64_t)(u * G + lig);
-            const bool ok = t < xe;
-            const uint64_t tc = ok ? t : xlast;          // clamped: the load itself is unconditional
-            const uint32_t fi = xi[tc];
-            const float vi = xv[tc];
-            f[u] = ok ? fi : 0xFFFFFFFFu;
-            v[u] = vi;
-        }
+            for (int u = 0; u < U; ++u) {
+                const uint64_t t = cur + (uint64_t)(u * G + lig);
+                const bool ok = t < xe;
+                const uint64_t tc = ok ? t : xlast;          // clamped: the load itself is unconditional
+                const uint32_t fi = xi[tc];
+                const float vi = xv[tc];
+                f[u] = ok ? fi : 0xFFFFFFFFu;
+                v[u] = vi;
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool inr = f[u] < a.L.w_rows && !(a.ablate & 1);
-            const BmWord wi = bm[inr ? (f[u] >> 5) : 0u];
-            w[u].bits = inr ? wi.bits : 0u; w[u].rank = wi.rank;
-        }
-        if (cur < xe) cur += (uint64_t)U * G;
-        // ---- push hits into the queue in feature order; when an item's queue is full, drain and resume
-        uint32_t uptr = 0;
-        do {
+            for (int u = 0; u < U; ++u) {
+                const bool inr = f[u] < a.L.w_rows && !(a.ablate & 1);
+                const BmWord wi = bm[inr ? (f[u] >> 5) : 0u];
+                w[u].bits = inr ? wi.bits : 0u; w[u].rank = wi.rank;
+            }
+            // ---- queue the hits in feature order.  If an item's queue fills up the step is abandoned at
+            //      slice `skip`, the queue is drained (outside this scope, so the step's registers are
+            //      dead by then) and the same step is re-loaded and resumed from that slice.
+            uint32_t done = skip;
             bool stopped = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -494,18 +501,20 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
                 const unsigned long long m = __ballot(hit);
                 const unsigned long long gm = (G == 64) ? m : ((m >> (grp * G)) & ((1ull << G) - 1ull));
                 const uint32_t cnt = (uint32_t)__popcll(gm);
-                if ((uint32_t)u >= uptr && !stopped) {
+                if ((uint32_t)u >= done && !stopped) {
                     if (nh + cnt <= (uint32_t)H) {
                         if (hit) my_hq[nh + (uint32_t)__popcll(gm & below)] =
                                      make_uint2(__float_as_uint(v[u]), w[u].rank + __popc(w[u].bits & ((1u << b) - 1u)));
-                        nh += cnt; uptr = u + 1;
+                        nh += cnt; done = u + 1;
                     } else {
                         stopped = true;
                     }
                 }
             }
-            if (__any(uptr < (uint32_t)U)) drain();
-        } while (__any(uptr < (uint32_t)U));
+            if (done == (uint32_t)U) { if (cur < xe) cur += (uint64_t)U * G; skip = 0; }
+            else { skip = done; overflow = true; }
+        }
+        if (__any(overflow)) drain();
     }
     drain();
     k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0);
