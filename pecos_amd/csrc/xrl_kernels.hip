@@ -299,10 +299,10 @@ __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it,
 // P  = units per register batch; two batches are in flight.
 template <int G, int NS> struct K1Cfg {
     static constexpr int W = 64 / G;                      // items per wavefront
-    static constexpr int U = (G >= 32) ? 2 : (G == 16 ? 4 : 8);   // query features per lane per step
+    static constexpr int U = (G >= 16) ? 2 : (G == 8 ? 4 : 8);    // query features per lane per step
     static constexpr int H = (G > 32) ? 2 * G : 64;       // hit queue depth per item (>= G)
     static constexpr int UH = H * NS;                     // unit queue depth per item
-    static constexpr int P = 8;
+    static constexpr int P = 4;
     static constexpr size_t lds_bytes(uint32_t acc_stride) {
         return (size_t)W * UH * 16 + (size_t)W * H * 8 + (size_t)W * (acc_stride + G) * 4;
     }
@@ -324,9 +324,13 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
 
     const int lane = threadIdx.x & 63;
     const int grp = lane / G, lig = lane % G;
+#ifdef XRL_K1_PHASE_PROF   // debug build only: per-phase cycle accounting costs ~12 VGPRs
     const bool prof = a.phase != nullptr;
     unsigned long long t_last = prof ? __builtin_readcyclecounter() : 0ull, t_ph[5] = {0, 0, 0, 0, 0};
     auto tick = [&](int ph) { if (prof) { const unsigned long long t = __builtin_readcyclecounter(); t_ph[ph] += t - t_last; t_last = t; } };
+#else
+    auto tick = [](int) {};
+#endif
     ItemDesc it{0u, kNoTile, 0u, 0.f};
     if (a.n_items) {   // tile-sorted list: every XCD takes a contiguous run of tiles
         const uint32_t n = *a.n_items, nb = (n + W - 1) / W;
@@ -518,10 +522,12 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     }
     drain();
     k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0);
+#ifdef XRL_K1_PHASE_PROF
     if (prof) {
         tick(4);
         if (lane == 0) { for (int i = 0; i < 5; ++i) atomicAdd(&a.phase[i], t_ph[i]); atomicAdd(&a.phase[5], 1ull); }
     }
+#endif
 }
 
 int g_k1_wpb = 1;   // wavefronts per workgroup (tuning knob)
