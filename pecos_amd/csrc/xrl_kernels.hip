@@ -299,7 +299,7 @@ __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it,
 // P  = units per register batch; two batches are in flight.
 template <int G, int NS> struct K1Cfg {
     static constexpr int W = 64 / G;                      // items per wavefront
-    static constexpr int U = (G >= 16) ? 2 : (G == 8 ? 4 : 8);    // query features per lane per step
+    static constexpr int U = (G >= 32) ? 2 : (G == 16 ? 4 : 8);   // query features per lane per step
     static constexpr int H = (G > 32) ? 2 * G : 64;       // hit queue depth per item (>= G)
     static constexpr int UH = H * NS;                     // unit queue depth per item
     static constexpr int P = 4;
@@ -406,32 +406,28 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
         //      behind a per-lane branch makes hipcc wait vmcnt(0) before each one).  The lanes of a unit
         //      hold distinct columns; lanes without an entry add 0 to a private dummy slot.  LDS
         //      operations of one wavefront execute in order, so only a compiler fence separates units.
-        struct Batch { Entry e[P]; };      // unit descriptors are re-read from LDS at apply time (saves VGPRs)
+        struct Batch { uint32_t xv[P], st[P], cn[P]; Entry e[P]; };
         auto load_batch = [&](uint32_t i0, Batch& B) {
-            uint32_t st[P], cn[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const bool ok = i0 + p < nu;
                 const uint4 d = my_uq[ok ? i0 + p : 0u];
-                st[p] = ok ? d.y : 0u; cn[p] = ok ? d.z : 0u;
+                B.xv[p] = d.x; B.st[p] = ok ? d.y : 0u; B.cn[p] = ok ? d.z : 0u;
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p) B.e[p] = ent[st[p] + ((uint32_t)lig < cn[p] ? (uint32_t)lig : 0u)];
+            for (int p = 0; p < P; ++p) B.e[p] = ent[B.st[p] + ((uint32_t)lig < B.cn[p] ? (uint32_t)lig : 0u)];
         };
-        auto apply_batch = [&](uint32_t i0, const Batch& B) {
+        auto apply_batch = [&](uint32_t, const Batch& B) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const bool ok = i0 + p < nu;
-                const uint4 d = my_uq[ok ? i0 + p : 0u];
-                const uint32_t cnt_u = ok ? d.z : 0u;
-                const float v = __uint_as_float(d.x);
-                const bool valid = (uint32_t)lig < cnt_u;
+                const float v = __uint_as_float(B.xv[p]);
+                const bool valid = (uint32_t)lig < B.cn[p];
                 const uint32_t ci = valid ? B.e[p].col : dummy;
                 const float pr = valid ? __fmul_rn(v, B.e[p].val) : 0.0f;      // scalar * val (inference.hpp:512-517)
                 my_acc[ci] = __fadd_rn(my_acc[ci], pr);                        // mul then add, no fma
-                if (__any(cnt_u > (uint32_t)G)) {                              // remainder of an over-long last unit
-                    for (uint32_t x = lig + G; x < cnt_u; x += G) {
-                        const Entry en = ent[d.y + x];
+                if (__any(B.cn[p] > (uint32_t)G)) {                            // remainder of an over-long last unit
+                    for (uint32_t x = lig + G; x < B.cn[p]; x += G) {
+                        const Entry en = ent[B.st[p] + x];
                         my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(v, en.val));
                     }
                 }
@@ -643,23 +639,32 @@ __global__ void __launch_bounds__(64) k2_topk_reg(K2Args a) {   // k <= 64: lane
     const float* __restrict__ cv = a.cand + q * a.cand_stride;
     float lv = -INFINITY, th = -INFINITY;
     uint32_t lp = 0, m = 0;
-    for (uint32_t base = 0; base < n; base += 64) {
-        const uint32_t p = base + lane;
-        const bool valid = p < n;
-        const float v = valid ? cv[p] : 0.f;
-        unsigned long long mask = __ballot(valid && (m < k || v > th));
-        while (mask) {
-            const int l = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const float vv = __shfl(v, l);
-            if (m == k && !(vv > th)) continue;
-            const int r = __popcll(__ballot((uint32_t)lane < m && lv >= vv));
-            const float uv = __shfl_up(lv, 1);
-            const uint32_t up = __shfl_up(lp, 1);
-            if (lane > r) { lv = uv; lp = up; }
-            else if (lane == r) { lv = vv; lp = base + l; }
-            if (m < k) ++m;
-            th = (m == k) ? __shfl(lv, (int)k - 1) : -INFINITY;
+    constexpr int KB = 4;     // candidate batches (64 each) fetched per iteration: KB loads in flight
+    const uint32_t nlast = n ? n - 1 : 0;
+    for (uint32_t base0 = 0; base0 < n; base0 += 64 * KB) {
+        float vb[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) { const uint32_t p = base0 + b * 64 + lane; vb[b] = cv[p < n ? p : nlast]; }   // unconditional, clamped
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            const uint32_t base = base0 + b * 64;
+            const uint32_t p = base + lane;
+            const bool valid = p < n;
+            const float v = vb[b];
+            unsigned long long mask = __ballot(valid && (m < k || v > th));
+            while (mask) {
+                const int l = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const float vv = __shfl(v, l);
+                if (m == k && !(vv > th)) continue;
+                const int r = __popcll(__ballot((uint32_t)lane < m && lv >= vv));
+                const float uv = __shfl_up(lv, 1);
+                const uint32_t up = __shfl_up(lp, 1);
+                if (lane > r) { lv = uv; lp = up; }
+                else if (lane == r) { lv = vv; lp = base + l; }
+                if (m < k) ++m;
+                th = (m == k) ? __shfl(lv, (int)k - 1) : -INFINITY;
+            }
         }
     }
     if ((uint32_t)lane < m) {
