@@ -304,7 +304,7 @@ template <int G, int NS> struct K1Cfg {
     static constexpr int UH = H * NS;                     // unit queue depth per item
     static constexpr int P = 4;
     static constexpr size_t lds_bytes(uint32_t acc_stride) {
-        return (size_t)W * UH * 16 + (size_t)W * H * 8 + (size_t)W * acc_stride * 4;
+        return (size_t)W * UH * 16 + (size_t)W * H * 8 + (size_t)W * (acc_stride + G) * 4;
     }
 };
 
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     uint4* uq = reinterpret_cast<uint4*>(smem);                        // units {x value, entry start, count, -}
     uint2* hq = reinterpret_cast<uint2*>(uq + W * UH);                 // hits  {x value, row slot}
     float* acc = reinterpret_cast<float*>(hq + W * H);
-    const uint32_t acc_item = a.acc_stride;
+    const uint32_t acc_item = a.acc_stride + G;                        // + one private dummy slot per lane
 
     const int lane = threadIdx.x & 63;
     const int grp = lane / G, lig = lane % G;
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     float* __restrict__ my_acc = acc + (size_t)grp * acc_item;
     uint2* __restrict__ my_hq = hq + (size_t)grp * H;
     uint4* __restrict__ my_uq = uq + (size_t)grp * UH;
-    const bool may_long = a.L.max_tile_cols > (uint32_t)(NS * G);      // wave-uniform: can a unit exceed G entries?
+    const uint32_t dummy = a.acc_stride + (uint32_t)lig;
     if (DENSE) {   // dense queries: bias FIRST (inference.hpp:824-830); bias_prod already holds 0.0f + bias*w
         const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
         for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = a.L.has_bias ? bp[c] : 0.0f;
@@ -417,23 +417,21 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
 #pragma unroll
             for (int p = 0; p < P; ++p) B.e[p] = ent[B.st[p] + ((uint32_t)lig < B.cn[p] ? (uint32_t)lig : 0u)];
         };
-        // Accumulation uses the LDS float atomic add (ds_add_f32, no return): it rounds exactly like
-        // v_add_f32 (verified bit-for-bit on 16.7 M pairs incl. denormals and cancellations,
-        // scripts/ds_add_check.hip), needs no read-modify-write round trip, and the LDS executes the DS
-        // operations of one wavefront in issue order, so the units of an item still add up in row order.
         auto apply_batch = [&](uint32_t, const Batch& B) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const float v = __uint_as_float(B.xv[p]);
-                if ((uint32_t)lig < B.cn[p])   // out[col] += scalar * val (inference.hpp:512-517): mul then add, no fma
-                    __hip_atomic_fetch_add(&my_acc[B.e[p].col], __fmul_rn(v, B.e[p].val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (may_long && __any(B.cn[p] > (uint32_t)G)) {               // remainder of an over-long last unit
+                const bool valid = (uint32_t)lig < B.cn[p];
+                const uint32_t ci = valid ? B.e[p].col : dummy;
+                const float pr = valid ? __fmul_rn(v, B.e[p].val) : 0.0f;      // scalar * val (inference.hpp:512-517)
+                my_acc[ci] = __fadd_rn(my_acc[ci], pr);                        // mul then add, no fma
+                if (__any(B.cn[p] > (uint32_t)G)) {                            // remainder of an over-long last unit
                     for (uint32_t x = lig + G; x < B.cn[p]; x += G) {
                         const Entry en = ent[B.st[p] + x];
-                        __hip_atomic_fetch_add(&my_acc[en.col], __fmul_rn(v, en.val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(v, en.val));
                     }
                 }
-                asm volatile("" ::: "memory");   // keep the units' DS operations in program order
+                wave_sync_lds();
             }
         };
         Batch A, B2;
