@@ -71,6 +71,14 @@ void* c_xlinear_load_model_from_disk(const char* model_path);
  * that c_xlinear_get_layer_type answers like the reference. */
 void* c_xlinear_load_model_from_disk_ext(const char* model_path, int weight_matrix_type);
 
+/* libpecos.cpp:128-131: load a memory-mapped model folder (*.mmap_store, param.json with is_mmap).
+ * lazy_load is accepted and ignored: the model is copied to HBM either way. */
+void* c_xlinear_load_mmap_model_from_disk(const char* model_path, const bool lazy_load);
+
+/* libpecos.cpp:133-138: npz model folder -> mmap model folder in the reference's byte layout
+ * (readable by the reference's own loader).  Host-only, needs no GPU. */
+void c_xlinear_compile_mmap_model(const char* model_path, const char* mmap_model_path);
+
 /* libpecos.cpp:140-143 */
 void c_xlinear_destruct_model(void* ptr);
 

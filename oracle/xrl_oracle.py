@@ -228,19 +228,32 @@ def ref_available():
     return os.path.exists(REF_SO)
 
 
+def ref_compile_mmap_model(npz_ranker_folder, mmap_ranker_folder):
+    """c_xlinear_compile_mmap_model of the real reference (libpecos.cpp:133-138)."""
+    lib = C.CDLL(REF_SO)
+    lib.c_xlinear_compile_mmap_model.argtypes = [C.c_char_p, C.c_char_p]
+    lib.c_xlinear_compile_mmap_model.restype = None
+    lib.c_xlinear_compile_mmap_model(npz_ranker_folder.encode(), mmap_ranker_folder.encode())
+
+
 class RefModel:
     """The reference's predict-only model handle (c_xlinear_load_model_from_disk_ext)."""
 
-    def __init__(self, folder, weight_matrix_type="BINARY_SEARCH_CHUNKED"):
+    def __init__(self, folder, weight_matrix_type="BINARY_SEARCH_CHUNKED", mmap=False):
         if os.path.isdir(os.path.join(folder, "ranker")):
             folder = os.path.join(folder, "ranker")
         self.lib = C.CDLL(REF_SO)
+        self.lib.c_xlinear_load_mmap_model_from_disk.restype = C.c_void_p
+        self.lib.c_xlinear_load_mmap_model_from_disk.argtypes = [C.c_char_p, C.c_bool]
         self.lib.c_xlinear_load_model_from_disk_ext.restype = C.c_void_p
         self.lib.c_xlinear_load_model_from_disk_ext.argtypes = [C.c_char_p, C.c_int]
         self.lib.c_xlinear_get_int_attr.restype = C.c_uint32
         self.lib.c_xlinear_get_int_attr.argtypes = [C.c_void_p, C.c_char_p]
         self.lib.c_xlinear_destruct_model.argtypes = [C.c_void_p]
-        self.h = self.lib.c_xlinear_load_model_from_disk_ext(folder.encode(), WEIGHT_TYPES[weight_matrix_type])
+        if mmap:   # libpecos.cpp:128-131
+            self.h = self.lib.c_xlinear_load_mmap_model_from_disk(folder.encode(), False)
+        else:
+            self.h = self.lib.c_xlinear_load_model_from_disk_ext(folder.encode(), WEIGHT_TYPES[weight_matrix_type])
         self.nr_labels = self.lib.c_xlinear_get_int_attr(self.h, b"nr_labels")
 
     def __del__(self):

@@ -172,6 +172,8 @@ class corelib(object):
             "xrl_set_device": (c_int, [c_int]),
             "c_xlinear_load_model_from_disk": (c_void_p, [c_char_p]),
             "c_xlinear_load_model_from_disk_ext": (c_void_p, [c_char_p, c_int]),
+            "c_xlinear_load_mmap_model_from_disk": (c_void_p, [c_char_p, c_bool]),
+            "c_xlinear_compile_mmap_model": (None, [c_char_p, c_char_p]),
             "c_xlinear_destruct_model": (None, [c_void_p]),
             "c_xlinear_get_int_attr": (c_uint32, [c_void_p, c_char_p]),
             "c_xlinear_get_layer_type": (c_int, [c_void_p, c_int]),
@@ -237,7 +239,15 @@ class corelib(object):
         return cmodel
 
     def xlinear_load_mmap(self, folder, lazy_load=False):
-        raise NotImplementedError("mmap model folders are not supported by the MI355X library yet (SURVEY.md N3)")
+        """Load a memory-mapped model folder (base.py:990-1009)."""
+        cmodel = self.clib_float32.c_xlinear_load_mmap_model_from_disk(c_char_p(folder.encode("utf-8")), c_bool(lazy_load))
+        self._check()
+        return cmodel
+
+    def xlinear_compile_mmap_model(self, npz_folder, mmap_folder):
+        """npz model folder -> mmap model folder (base.py:978-988); host-only."""
+        self.clib_float32.c_xlinear_compile_mmap_model(c_char_p(npz_folder.encode("utf-8")), c_char_p(mmap_folder.encode("utf-8")))
+        self._check()
 
     def xlinear_destruct_model(self, c_model):
         if self._lib is not None and c_model:

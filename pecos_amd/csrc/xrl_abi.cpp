@@ -267,6 +267,27 @@ void* c_xlinear_load_model_from_disk(const char* model_path) {
     return c_xlinear_load_model_from_disk_ext(model_path, 2 /* DEFAULT_LAYER_TYPE = BINARY_SEARCH_CHUNKED */);
 }
 
+void* c_xlinear_load_mmap_model_from_disk(const char* model_path, const bool lazy_load) {
+    (void)lazy_load;   // the model is copied to HBM either way
+    void* out = nullptr;
+    guarded([&] {
+        if (!model_path) fail("null model path");
+        require_gpu();
+        use_device(g_device);
+        auto m = load_mmap_model_from_disk(model_path);
+        m->device = g_device;
+        out = m.release();
+    });
+    return out;
+}
+
+void c_xlinear_compile_mmap_model(const char* model_path, const char* mmap_model_path) {
+    guarded([&] {
+        if (!model_path || !mmap_model_path) fail("null path");
+        compile_mmap_model(model_path, mmap_model_path);    // host-only: no GPU needed
+    });
+}
+
 void c_xlinear_destruct_model(void* ptr) {
     guarded([&] {
         if (!ptr) return;

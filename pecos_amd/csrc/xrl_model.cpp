@@ -82,7 +82,8 @@ struct Nz { uint32_t row, col; float val; };
 }  // namespace
 
 std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float bias, uint32_t only_topk,
-                                     const std::string& post_processor) {
+                                     const std::string& post_processor, const std::vector<uint32_t>* perm_inv_override,
+                                     uint32_t orig_rows) {
     auto L = std::make_unique<Layer>();
     L->w_rows = W.rows; L->w_cols = W.cols; L->c_rows = C.rows; L->c_cols = C.cols;
     L->bias = bias; L->only_topk = only_topk; L->pp_name = post_processor;
@@ -230,6 +231,16 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     if (!contiguous) {
         std::vector<uint32_t> perm_inv(C.row_idx.begin(), C.row_idx.begin() + c_nnz);
         L->d_perm_inv.upload(perm_inv);
+    } else if (perm_inv_override) {
+        if (perm_inv_override->size() != c_nnz) fail("layer: perm_inv size does not match C");
+        L->d_perm_inv.upload(*perm_inv_override);
+        L->reordered = true;
+        L->c_rows = orig_rows;          // predictions carry ORIGINAL ids; result CSR has perm.size() columns
+        // host maps in original ids (predict_on_selected_outputs is CSC-only in the reference; mmap models
+        // have no CSC copy, so K4 is unavailable for them, but the maps stay consistent)
+        L->h_parent.assign(orig_rows, 0xFFFFFFFFu);
+        for (uint32_t p = 0; p < P; ++p) for (uint64_t c = C.col_ptr[p]; c < C.col_ptr[p + 1]; ++c) L->h_parent[(*perm_inv_override)[C.row_idx[c]]] = p;
+        for (auto& v : L->h_c_idx) v = (*perm_inv_override)[v];
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
                       L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap;
@@ -237,7 +248,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
     d.bitmap = L->d_bitmap.as<BmWord>(); d.row_ptr = L->d_row_ptr.as<uint32_t>(); d.row_idx = L->d_row_idx.as<uint32_t>();
-    d.entries = L->d_entries.as<Entry>(); d.perm_inv = contiguous ? nullptr : L->d_perm_inv.as<uint32_t>();
+    d.entries = L->d_entries.as<Entry>(); d.perm_inv = (contiguous && !perm_inv_override) ? nullptr : L->d_perm_inv.as<uint32_t>();
     d.chunk_alg_bytes = L->d_chunk_alg.as<float>();
     d.bias_prod = L->d_bias_prod.as<float>();
     d.n_parents = P; d.n_children = L->n_children; d.n_tiles = T; d.nwords = L->nwords; d.w_rows = W.rows;

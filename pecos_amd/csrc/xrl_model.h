@@ -124,11 +124,16 @@ struct Model {
 };
 
 // Build one layer from host CSC W / C (LayerData<chunked>::init, inference.hpp:1849-1883).
+// perm_inv_override / orig_rows: W and C are already in the rearranged (contiguous) child order and the
+// given map takes rearranged -> original ids (mmap model folders, LayerData::init_mmap :1885-1908).
 std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float bias, uint32_t only_topk,
-                                     const std::string& post_processor);
+                                     const std::string& post_processor,
+                                     const std::vector<uint32_t>* perm_inv_override = nullptr, uint32_t orig_rows = 0);
 // Load <path>/param.json + {d}.model/ (HierarchicalMLModel::load, inference.hpp:2616-2655).
 std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_matrix_type);
 void finalize_model(Model& m);
+std::unique_ptr<Model> load_mmap_model_from_disk(const std::string& path);        // xrl_mmap.cpp
+void compile_mmap_model(const std::string& npz_path, const std::string& mmap_path);   // xrl_mmap.cpp
 void ensure_device_csc(Layer& L);   // upload W as CSC (original column ids) if not there yet
 
 }  // namespace xrl

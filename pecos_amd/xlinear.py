@@ -303,6 +303,14 @@ class XLinearModel:
         model = HierarchicalMLModel.load(path.join(model_folder, "ranker"), is_predict_only, **kwargs)
         return cls(model)
 
+    @classmethod
+    def compile_mmap_model(cls, npz_folder, mmap_folder):
+        """npz model folder -> memory-mapped model folder (pecos/xmc/xlinear/model.py:136-152)."""
+        import shutil
+        os.makedirs(mmap_folder, exist_ok=True)
+        shutil.copy(path.join(npz_folder, "param.json"), path.join(mmap_folder, "param.json"))
+        clib.xlinear_compile_mmap_model(path.join(npz_folder, "ranker"), path.join(mmap_folder, "ranker"))
+
     def get_pred_params(self):
         return self.PredParams(hlm_args=self.model.get_pred_params())
 

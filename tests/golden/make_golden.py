@@ -154,6 +154,15 @@ def main():
                 # keep the score-sorted row order: store raw CSR arrays
                 np.savez_compressed(os.path.join(preds, fn), indptr=P.indptr, indices=P.indices, data=P.data, shape=P.shape)
                 manifest["synth"].append(dict(model=c["name"], layers=ks, kwargs=kwargs, x=kind, pred=fn))
+    # memory-mapped model folders COMPILED BY THE REFERENCE (XLinearModel.compile_mmap_model,
+    # pecos/xmc/xlinear/model.py:136-152 -> c_xlinear_compile_mmap_model) for the mmap reader tests
+    mmap_dir = os.path.join(HERE, "mmap")
+    if os.path.exists(mmap_dir):
+        shutil.rmtree(mmap_dir)
+    manifest["mmap"] = []
+    for kind, name in (("models", "splits2"), ("models", "mls10"), ("synth", "s_eurlex"), ("synth", "s_pruned"), ("synth", "s_contig")):
+        ref_xlm.compile_mmap_model(os.path.join(HERE, kind, name), os.path.join(mmap_dir, name))
+        manifest["mmap"].append(dict(kind=kind, model=name))
     json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1)
     os.system(f"du -sh {HERE}")
 

@@ -226,6 +226,32 @@ def test_predict_on_selected_outputs(manifest, XLM, oracle_mod):
         m.predict(X, selected_outputs_csr=dup)
 
 
+def test_mmap_models(manifest, XLM, clib, tmp_path):
+    # N3: memory-mapped model folders compiled BY THE REFERENCE load through c_xlinear_load_mmap_model_from_disk
+    # and predict bit-identically to the npz model; our own compile -> load round trip does too
+    for c in manifest["mmap"]:
+        npz = os.path.join(GOLDEN, c["kind"], c["model"])
+        X = load_X(os.path.join(GOLDEN, "ref_fixtures", "Xt.npz") if c["kind"] == "models" else os.path.join(GOLDEN, "synth", c["model"] + "__X.npz"))
+        m_npz = XLM.load(npz)
+        m_map = XLM.load(os.path.join(GOLDEN, "mmap", c["model"]))
+        out = str(tmp_path / c["model"])
+        XLM.compile_mmap_model(npz, out)
+        m_rt = XLM.load(out)
+        for kw in (dict(), dict(beam_size=3, only_topk=5, post_processor="sigmoid")):
+            for Xq in (X, np.ascontiguousarray(X.toarray())):
+                a = m_npz.predict(Xq, **kw)
+                for other in (m_map, m_rt):
+                    b = other.predict(Xq, **kw)
+                    assert a.shape == b.shape
+                    assert_same_topk(b, a, exact_scores=True, what=f"{c} {kw}")
+        assert (m_map.depth, m_map.nr_features, m_map.nr_labels, m_map.nr_codes, m_map.nr_pred_cols) == \
+               (m_npz.depth, m_npz.nr_features, m_npz.nr_labels, m_npz.nr_codes, m_npz.nr_pred_cols)
+    with pytest.raises(RuntimeError, match="npz model"):
+        clib.xlinear_load_mmap(os.path.join(GOLDEN, "synth", "s_eurlex", "ranker"))
+    with pytest.raises(RuntimeError, match="mmap model"):
+        clib.xlinear_load_predict_only(os.path.join(GOLDEN, "mmap", "s_eurlex", "ranker"))
+
+
 def test_full_size_properties(XLM, clib, tmp_path):
     # BASELINE.json configs[1] (Eurlex-4K shape) at FULL size through size-independent properties
     import xrl_synth

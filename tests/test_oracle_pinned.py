@@ -90,3 +90,32 @@ def test_oracle_selected_outputs(manifest, oracle_mod):
             for Xq in (X, np.ascontiguousarray(X.toarray())):
                 assert_same_topk(om.predict_on_selected_outputs(Xq, S, pp), rm.predict_on_selected_outputs(Xq, S, pp),
                                  exact_scores=True, what=f"{name} {pp}")
+
+
+def test_mmap_writer_is_readable_by_the_reference(oracle_mod, tmp_path):
+    # c_xlinear_compile_mmap_model of libxrl_amd.so (host-only) writes the reference's byte layout: the REAL
+    # reference loads our folders and predicts exactly what it predicts from the npz model; file sizes equal the
+    # reference's own compile output, C/perm stores are byte-identical (W holds stale pointers in the reference's)
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built")
+    from pecos_amd import clib
+    for kind, name in (("models", "splits2"), ("synth", "s_eurlex"), ("synth", "s_pruned"), ("synth", "s_flat")):
+        src = os.path.join(GOLDEN, kind, name)
+        X = load_X(os.path.join(GOLDEN, "ref_fixtures", "Xt.npz") if kind == "models" else os.path.join(GOLDEN, "synth", name + "__X.npz"))
+        ours, ref = str(tmp_path / (name + "_ours")), str(tmp_path / (name + "_ref"))
+        clib.xlinear_compile_mmap_model(src + "/ranker", ours)
+        oracle_mod.ref_compile_mmap_model(src + "/ranker", ref)
+        a = oracle_mod.RefModel(src).predict(X, beam_size=5, only_topk=6)
+        b = oracle_mod.RefModel(ours, mmap=True).predict(X, beam_size=5, only_topk=6)
+        assert a.shape == b.shape
+        assert_same_topk(b, a, exact_scores=True, what=name)
+        for layer in sorted(os.listdir(ref)):
+            if not layer.endswith(".model"):
+                continue
+            for f in os.listdir(os.path.join(ref, layer)):
+                fo, fr = os.path.join(ours, layer, f), os.path.join(ref, layer, f)
+                assert os.path.getsize(fo) == os.path.getsize(fr), (name, layer, f)
+                if f in ("C.mmap_store", "perm.mmap_store"):
+                    assert open(fo, "rb").read() == open(fr, "rb").read(), (name, layer, f)
+    with pytest.raises(RuntimeError):
+        clib.xlinear_compile_mmap_model(str(tmp_path / "nope"), str(tmp_path / "out"))
