@@ -129,6 +129,16 @@ void c_xlinear_single_layer_predict_drm_f32(const ScipyDrmF32* input_x, const Sc
                                             const int num_threads, const float bias,
                                             py_sparse_allocator_t pred_alloc);
 
+/* libpecos.cpp:237-274 (C_XLINEAR_SINGLE_LAYER_PREDICT_ON_SELECTED_OUTPUTS) */
+void c_xlinear_single_layer_predict_on_selected_outputs_csr_f32(const ScipyCsrF32* input_x, const ScipyCsrF32* selected_outputs_csr,
+                                                                const ScipyCsrF32* csr_codes, ScipyCscF32* W, ScipyCscF32* C,
+                                                                const char* post_processor_str, const int num_threads,
+                                                                const float bias, py_sparse_allocator_t pred_alloc);
+void c_xlinear_single_layer_predict_on_selected_outputs_drm_f32(const ScipyDrmF32* input_x, const ScipyCsrF32* selected_outputs_csr,
+                                                                const ScipyCsrF32* csr_codes, ScipyCscF32* W, ScipyCscF32* C,
+                                                                const char* post_processor_str, const int num_threads,
+                                                                const float bias, py_sparse_allocator_t pred_alloc);
+
 /* libpecos.cpp:337-355 (C_SPARSE_INNER_PRODUCTS): val[i] = <X[X_row_idx[i],:], W[:,W_col_idx[i]]>,
  * `val` is caller-allocated f32[len] (pecos/core/utils/matrix.hpp:1049-1060). */
 void c_sparse_inner_products_csr2csc_f32(const ScipyCsrF32* pX, const ScipyCscF32* pW, uint64_t len,

@@ -183,6 +183,8 @@ class corelib(object):
             "c_xlinear_predict_on_selected_outputs_drm_f32": (None, [c_void_p, POINTER(ScipyDrmF32), POINTER(ScipyCsrF32), c_char_p, c_int, alloc_t]),
             "c_xlinear_single_layer_predict_csr_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyCsrF32), POINTER(ScipyCscF32), POINTER(ScipyCscF32), c_char_p, c_uint32, c_int, c_float, alloc_t]),
             "c_xlinear_single_layer_predict_drm_f32": (None, [POINTER(ScipyDrmF32), POINTER(ScipyCsrF32), POINTER(ScipyCscF32), POINTER(ScipyCscF32), c_char_p, c_uint32, c_int, c_float, alloc_t]),
+            "c_xlinear_single_layer_predict_on_selected_outputs_csr_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyCsrF32), POINTER(ScipyCsrF32), POINTER(ScipyCscF32), POINTER(ScipyCscF32), c_char_p, c_int, c_float, alloc_t]),
+            "c_xlinear_single_layer_predict_on_selected_outputs_drm_f32": (None, [POINTER(ScipyDrmF32), POINTER(ScipyCsrF32), POINTER(ScipyCsrF32), POINTER(ScipyCscF32), POINTER(ScipyCscF32), c_char_p, c_int, c_float, alloc_t]),
             "c_sparse_inner_products_csr2csc_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyCscF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
             "c_sparse_inner_products_drm2csc_f32": (None, [POINTER(ScipyDrmF32), POINTER(ScipyCscF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
             "c_sparse_inner_products_csr2dcm_f32": (None, [POINTER(ScipyCsrF32), POINTER(ScipyDcmF32), c_uint64, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_float), c_int]),
@@ -332,6 +334,39 @@ class corelib(object):
         cb = pred_alloc.cfunc
         c_predict(byref(X), byref(codes) if codes is not None else None, byref(W),
                   byref(C) if C is not None else None, post_processor_str, only_topk, num_threads, bias, cb)
+        self._check()
+
+    def xlinear_single_layer_predict_on_selected_outputs(self, X, selected_outputs_csr, csr_codes, W, C, post_processor_str,
+                                                         num_threads, bias, pred_alloc):
+        """One layer from python-owned W / C on a given output pattern (base.py:1227-1303)."""
+        clib = self.clib_float32
+        post_processor_str = post_processor_str.encode("utf-8")
+        W = ScipyCscF32.init_from(W)
+        S = ScipyCsrF32.init_from(selected_outputs_csr.astype(np.float32))
+        if isinstance(X, smat.csr_matrix):
+            if not X.has_sorted_indices:
+                raise ValueError("Query matrix does not have sorted indices!")
+            X = ScipyCsrF32.init_from(X)
+        elif isinstance(X, np.ndarray):
+            X = ScipyDrmF32.init_from(X)
+        if isinstance(X, ScipyCsrF32):
+            fn = clib.c_xlinear_single_layer_predict_on_selected_outputs_csr_f32
+        elif isinstance(X, ScipyDrmF32):
+            fn = clib.c_xlinear_single_layer_predict_on_selected_outputs_drm_f32
+        else:
+            raise NotImplementedError("type(X) = {} not implemented".format(type(X)))
+        if C is None:
+            C = smat.csc_matrix(np.ones((W.shape[1], 1), dtype=np.float32))
+        C = ScipyCscF32.init_from(C)
+        if csr_codes is not None:
+            if csr_codes.shape[0] != X.shape[0]:
+                raise ValueError("Instance dimension of query and csr_codes matrix do not match")
+            if csr_codes.shape[1] != C.shape[1]:
+                raise ValueError("Label dimension of csr_codes and C matrix do not match")
+            csr_codes = ScipyCsrF32.init_from(csr_codes)
+        cb = pred_alloc.cfunc
+        fn(byref(X), byref(S), byref(csr_codes) if csr_codes is not None else None, byref(W), byref(C), post_processor_str,
+           num_threads, bias, cb)
         self._check()
 
     def sparse_inner_products(self, X, W, X_row_idx, W_col_idx, pred_values=None, threads=-1):

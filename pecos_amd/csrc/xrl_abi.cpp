@@ -197,6 +197,34 @@ void selected_host(void* ptr, const XT* input_x, bool is_csr, const ScipyCsrF32*
     if (!oi.empty()) { std::memcpy(o_idx, oi.data(), oi.size() * 4); std::memcpy(o_val, ov.data(), ov.size() * 4); }
 }
 
+template <class XT>
+void single_layer_selected(const XT* input_x, bool is_csr, const ScipyCsrF32* S, const ScipyCsrF32* csr_codes, ScipyCscF32* W,
+                           ScipyCscF32* C, const char* pp, float bias, py_sparse_allocator_t alloc) {
+    // libpecos.cpp:237-274: a temporary one-layer model around caller-owned W / C, selected outputs only
+    require_gpu();
+    use_device(g_device);
+    if (!alloc) fail("null allocator callback");
+    if (!S) fail("null selected_outputs_csr");
+    const ScipyCscF32* Wp = W; const ScipyCscF32* Cp = C;
+    const char* pps = pp ? pp : "noop";
+    const uint32_t topk = 0;
+    auto m = model_from_arrays(1, &Wp, &Cp, &bias, &topk, &pps);
+    m->ws = std::make_unique<Workspace>();
+    QueriesDev X{};
+    if (is_csr) upload_csr(reinterpret_cast<const ScipyCsrF32*>(input_x), m->ws->x_ptr, m->ws->x_idx, m->ws->x_val, X);
+    else upload_drm(reinterpret_cast<const ScipyDrmF32*>(input_x), m->ws->x_val, X);
+    ScipyCsrF32View cv{};
+    SelectedInit init{nullptr, true};
+    if (csr_codes) { cv = ScipyCsrF32View{csr_codes->rows, csr_codes->cols, csr_codes->row_ptr, csr_codes->col_idx, csr_codes->val}; init.codes = &cv; init.no_prev_pred = false; }
+    std::vector<uint32_t> oi; std::vector<float> ov;
+    predict_selected(*m, X, S->rows, S->cols, S->row_ptr, S->col_idx, pps, oi, ov, &init);
+    uint32_t* o_idx = nullptr; uint64_t* o_ptr = nullptr; float* o_val = nullptr;
+    alloc(false, S->rows, S->cols, oi.size(), &o_idx, &o_ptr, &o_val);
+    if (!o_ptr || (!oi.empty() && (!o_idx || !o_val))) fail("allocator callback returned null buffers");
+    std::memcpy(o_ptr, S->row_ptr, ((size_t)S->rows + 1) * 8);
+    if (!oi.empty()) { std::memcpy(o_idx, oi.data(), oi.size() * 4); std::memcpy(o_val, ov.data(), ov.size() * 4); }
+}
+
 template <class XT, class WT>
 void inner_products(const XT* pX, bool x_csr, const WT* pW, bool w_csc, uint64_t len, uint32_t* rows, uint32_t* cols, float* out) {
     require_gpu();
@@ -365,6 +393,22 @@ void c_xlinear_single_layer_predict_drm_f32(const ScipyDrmF32* input_x, const Sc
                                             const int num_threads, const float bias, py_sparse_allocator_t pred_alloc) {
     (void)num_threads;
     guarded([&] { single_layer_predict(input_x, false, csr_codes, W, C, post_processor_str, only_topk, bias, pred_alloc); });
+}
+
+void c_xlinear_single_layer_predict_on_selected_outputs_csr_f32(const ScipyCsrF32* input_x, const ScipyCsrF32* selected_outputs_csr,
+                                                                const ScipyCsrF32* csr_codes, ScipyCscF32* W, ScipyCscF32* C,
+                                                                const char* post_processor_str, const int num_threads,
+                                                                const float bias, py_sparse_allocator_t pred_alloc) {
+    (void)num_threads;
+    guarded([&] { single_layer_selected(input_x, true, selected_outputs_csr, csr_codes, W, C, post_processor_str, bias, pred_alloc); });
+}
+
+void c_xlinear_single_layer_predict_on_selected_outputs_drm_f32(const ScipyDrmF32* input_x, const ScipyCsrF32* selected_outputs_csr,
+                                                                const ScipyCsrF32* csr_codes, ScipyCscF32* W, ScipyCscF32* C,
+                                                                const char* post_processor_str, const int num_threads,
+                                                                const float bias, py_sparse_allocator_t pred_alloc) {
+    (void)num_threads;
+    guarded([&] { single_layer_selected(input_x, false, selected_outputs_csr, csr_codes, W, C, post_processor_str, bias, pred_alloc); });
 }
 
 void c_sparse_inner_products_csr2csc_f32(const ScipyCsrF32* pX, const ScipyCscF32* pW, uint64_t len, uint32_t* r, uint32_t* c, float* val, int threads) {

@@ -26,9 +26,11 @@ struct PredictOpts {
 uint32_t effective_topk(const Model& m, uint32_t only_topk);
 void resolve_profile(Model& m);
 // predict_on_selected_outputs (xrl_select.cpp): values for the pattern (s_ptr, s_idx), in the reference's walk order
+struct ScipyCsrF32View { uint32_t rows, cols; const uint64_t* row_ptr; const uint32_t* col_idx; const float* val; };
+struct SelectedInit { const ScipyCsrF32View* codes; bool no_prev_pred; };   // explicit predictions entering layer 0
 void predict_selected(Model& m, const QueriesDev& X, uint32_t s_rows, uint32_t s_cols, const uint64_t* s_ptr,
                       const uint32_t* s_idx, const char* post_processor, std::vector<uint32_t>& out_idx,
-                      std::vector<float>& out_val);   // synchronise and fold pending hipEvent pairs into m.profile
+                      std::vector<float>& out_val, const SelectedInit* init = nullptr);   // synchronise and fold pending hipEvent pairs into m.profile
 
 // Enqueue the whole beam search on `stream`; results land in fixed-stride device buffers.
 void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_t* d_out_idx, float* d_out_val,

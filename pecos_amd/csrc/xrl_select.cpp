@@ -16,7 +16,7 @@ namespace xrl {
 
 void predict_selected(Model& m, const QueriesDev& X, uint32_t s_rows, uint32_t s_cols, const uint64_t* s_ptr,
                       const uint32_t* s_idx, const char* post_processor, std::vector<uint32_t>& out_idx,
-                      std::vector<float>& out_val) {
+                      std::vector<float>& out_val, const SelectedInit* init) {
     const size_t T = m.layers.size();
     const Layer& last = *m.layers.back();
     const uint32_t out_cols = last.reordered ? last.c_rows : last.w_cols;
@@ -57,6 +57,25 @@ void predict_selected(Model& m, const QueriesDev& X, uint32_t s_rows, uint32_t s
     // ---- traversal order, top-down (prolongate_sparse_predictions)
     std::vector<std::vector<uint32_t>> node(T), ppos(T), pair_q(T);
     std::vector<uint32_t> mark;
+    // previous-layer predictions entering layer 0: the implicit root (ones(N x 1)), explicit csr_codes, or
+    // ones(N x C.cols) without combine (single-layer API, libpecos.cpp:237-274)
+    std::vector<uint64_t> init_ptr; std::vector<uint32_t> init_node; std::vector<float> init_val;
+    const bool has_init = init != nullptr;
+    if (has_init) {
+        const uint32_t P0 = m.layers[0]->c_cols;
+        init_ptr.assign(N + 1, 0);
+        if (init->codes) {
+            if (init->codes->rows != N) fail("Instance dimension of query and prev_layer_pred matrix do not match");
+            if (init->codes->cols != P0) fail("Label dimension of prev_layer_pred and C matrix do not match");
+            const uint64_t cn = init->codes->row_ptr[N];
+            init_ptr.assign(init->codes->row_ptr, init->codes->row_ptr + N + 1);
+            init_node.assign(init->codes->col_idx, init->codes->col_idx + cn);
+            init_val.assign(init->codes->val, init->codes->val + cn);
+        } else {
+            init_node.resize((size_t)N * P0); init_val.assign((size_t)N * P0, 1.0f);
+            for (uint32_t q = 0; q < N; ++q) { init_ptr[q + 1] = (uint64_t)(q + 1) * P0; for (uint32_t p = 0; p < P0; ++p) init_node[(size_t)q * P0 + p] = p; }
+        }
+    }
     for (size_t l = 0; l < T; ++l) {
         const Layer& L = *m.layers[l];
         mark.assign((size_t)L.c_rows + 1, 0u);
@@ -65,9 +84,9 @@ void predict_selected(Model& m, const QueriesDev& X, uint32_t s_rows, uint32_t s
             const uint32_t stamp = q + 1;
             for (uint64_t i = pat_ptr[l][q]; i < pat_ptr[l][q + 1]; ++i) mark[pat[l][i]] = stamp;
             const uint64_t before = node[l].size();
-            const uint64_t pb = l ? pat_ptr[l - 1][q] : 0, pe = l ? pat_ptr[l - 1][q + 1] : 1;
+            const uint64_t pb = l ? pat_ptr[l - 1][q] : (has_init ? init_ptr[q] : 0), pe = l ? pat_ptr[l - 1][q + 1] : (has_init ? init_ptr[q + 1] : 1);
             for (uint64_t i = pb; i < pe; ++i) {
-                const uint32_t parent = l ? node[l - 1][i] : 0u;   // previous layer's ORDERED list
+                const uint32_t parent = l ? node[l - 1][i] : (has_init ? init_node[i] : 0u);   // previous layer's ORDERED list
                 if (parent >= L.c_cols) fail("selected-output walk left the tree");
                 for (uint64_t c = L.h_c_ptr[parent]; c < L.h_c_ptr[parent + 1]; ++c) {
                     const uint32_t j = L.h_c_idx[c];
@@ -82,6 +101,7 @@ void predict_selected(Model& m, const QueriesDev& X, uint32_t s_rows, uint32_t s
     if (!m.ws) m.ws = std::make_unique<Workspace>();
     hipStream_t stream = m.stream;
     DevBuf d_node, d_ppos, d_q, d_off[2], d_val[2];
+    if (has_init) { d_off[1].upload(init_ptr); d_val[1].upload(init_val); }   // plays "layer -1" (prv of layer 0)
     for (size_t l = 0; l < T; ++l) {
         Layer& L = *m.layers[l];
         ensure_device_csc(L);
@@ -93,8 +113,8 @@ void predict_selected(Model& m, const QueriesDev& X, uint32_t s_rows, uint32_t s
         const PostProc pp = post_processor ? parse_post_processor(post_processor) : L.pp;
         launch_k4_selected(L.d_csc_ptr.as<uint64_t>(), L.d_csc_idx.as<uint32_t>(), L.d_csc_val.as<float>(), L.w_rows, L.bias, X,
                            d_q.as<uint32_t>(), d_node.as<uint32_t>(), d_ppos.as<uint32_t>(),
-                           l ? d_off[prv].as<uint64_t>() : nullptr, l ? d_val[prv].as<float>() : nullptr,
-                           d_val[cur].as<float>(), np, pp, l == 0 ? 1 : 0, stream);
+                           (l || has_init) ? d_off[prv].as<uint64_t>() : nullptr, (l || has_init) ? d_val[prv].as<float>() : nullptr,
+                           d_val[cur].as<float>(), np, pp, (l == 0 && (!has_init || init->no_prev_pred)) ? 1 : 0, stream);
         XRL_HIP(hipStreamSynchronize(stream));   // the upload buffers are reused by the next layer
     }
     out_idx = std::move(node[T - 1]);

@@ -226,6 +226,31 @@ def test_predict_on_selected_outputs(manifest, XLM, oracle_mod):
         m.predict(X, selected_outputs_csr=dup)
 
 
+def test_single_layer_predict_on_selected_outputs(clib, oracle_mod):
+    # libpecos.cpp:237-274: layer-by-layer selected prediction chained through csr_codes equals the
+    # whole-model selected prediction (values and order), which is pinned on the real reference
+    from pecos_amd.core import ScipyCompressedSparseAllocator
+    folder = os.path.join(GOLDEN, "synth", "s_eurlex")
+    layers = oracle_mod.load_model_folder(folder)
+    X = load_X(os.path.join(GOLDEN, "synth", "s_eurlex__X.npz"))
+    om = oracle_mod.OracleModel.load(folder)
+    S2 = om.predict(X, beam_size=5, only_topk=6)
+    full = om.predict_on_selected_outputs(X, S2)
+    # per-layer patterns bottom-up (parents of the selected nodes)
+    pats = [None, None, smat.csr_matrix(S2)]
+    for l in (2, 1):
+        Cl = smat.csr_matrix(layers[l]["C"])                 # child x parent
+        P = (smat.csr_matrix((np.ones_like(pats[l].data), pats[l].indices, pats[l].indptr), shape=pats[l].shape) @ Cl).tocsr()
+        P.sort_indices(); pats[l - 1] = P
+    codes = None
+    for l in range(3):
+        alloc = ScipyCompressedSparseAllocator()
+        clib.xlinear_single_layer_predict_on_selected_outputs(X, pats[l].astype(np.float32), codes, layers[l]["W"], layers[l]["C"],
+                                                              "l3-hinge", -1, layers[l]["bias"], alloc)
+        codes = smat.csr_matrix(alloc.get(), dtype=np.float32)
+    assert_same_topk(codes, full, exact_scores=True, what="chained single-layer selected == whole-model selected")
+
+
 def test_mmap_models(manifest, XLM, clib, tmp_path):
     # N3: memory-mapped model folders compiled BY THE REFERENCE load through c_xlinear_load_mmap_model_from_disk
     # and predict bit-identically to the npz model; our own compile -> load round trip does too
