@@ -148,6 +148,12 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     L->nnz = nnz;
 
     const uint64_t bm_words = (uint64_t)T * L->nwords;
+    {   // the rank-bitmap costs rows/4 bytes per tile; refuse layouts that cannot fit the device
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bm_words * 8 + nnz * 8 > (uint64_t)(free_b * 0.9))
+            fail("layer: rank-bitmap layout needs " + std::to_string((bm_words * 8 + nnz * 8) >> 20) + " MiB (" + std::to_string(T) +
+                 " tiles x " + std::to_string(W.rows) + " features) but only " + std::to_string(free_b >> 20) + " MiB of HBM are free");
+    }
     std::vector<Entry> entries(nnz);
     std::vector<BmWord> bitmap(bm_words, BmWord{0, 0});
     std::vector<std::vector<uint32_t>> t_rows(T), t_rptr(T);

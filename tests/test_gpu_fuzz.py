@@ -1,0 +1,96 @@
+"""GPU (-m gpu): randomized parity fuzz.  Irregular trees (empty parents, pruned children, permuted child
+order, chunks wider than a tile), ragged queries (empty rows, explicit zeros, one very long row), random
+beam / top-k / post-processor, sparse and dense X -- every case bit-exact against the oracle (which is
+pinned on the real reference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as smat
+
+from conftest import assert_same_topk
+
+pytestmark = pytest.mark.gpu
+
+
+def random_model(folder, rng, D, depth, bias):
+    os.makedirs(os.path.join(folder, "ranker"), exist_ok=True)
+    prev_k = 1
+    sizes = []
+    for d in range(depth):
+        K = int(rng.integers(max(2, prev_k), max(3, prev_k * int(rng.integers(2, 40)))))
+        if d == depth - 1 and rng.random() < 0.3:
+            K = int(rng.integers(150, 400))          # wide chunks -> column tiles
+        sizes.append(K)
+        lf = os.path.join(folder, "ranker", f"{d}.model"); os.makedirs(lf, exist_ok=True)
+        # children -> parents: random, some parents empty; child order inside a parent random; some pruned
+        parent = rng.integers(0, prev_k, K)
+        if prev_k > 2:
+            parent[parent == rng.integers(0, prev_k)] = (rng.integers(0, prev_k))   # likely empties one parent
+        keep = rng.random(K) >= (0.15 if (d > 0 and rng.random() < 0.4) else 0.0)
+        order = rng.permutation(K) if rng.random() < 0.7 else np.arange(K)
+        order = order[keep[order]]
+        order = order[np.argsort(parent[order], kind="stable")]
+        cptr = np.zeros(prev_k + 1, np.int64); np.cumsum(np.bincount(parent[order], minlength=prev_k), out=cptr[1:])
+        C = smat.csc_matrix((np.ones(len(order), np.float32), order.astype(np.int32), cptr), shape=(K, prev_k))
+        rows = D + 1 if bias > 0 else D
+        dens = rng.choice([0.02, 0.1, 0.4])
+        W = smat.random(rows, K, density=dens, format="csc", dtype=np.float32, random_state=int(rng.integers(1 << 30)),
+                        data_rvs=lambda n: rng.standard_normal(n).astype(np.float32))
+        W.sort_indices()
+        if rng.random() < 0.3:
+            W.data[rng.random(W.nnz) < 0.05] = 0.0   # explicit zero weights
+        smat.save_npz(os.path.join(lf, "W.npz"), W, compressed=False)
+        smat.save_npz(os.path.join(lf, "C.npz"), C, compressed=False)
+        json.dump({"model": "MLModel", "bias": bias, "pred_kwargs": {"only_topk": int(rng.integers(1, 30)),
+                   "post_processor": str(rng.choice(["l3-hinge", "noop", "log-l2-hinge", "l1-hinge"]))}},
+                  open(os.path.join(lf, "param.json"), "w"))
+        prev_k = K
+    json.dump({"model": "HierarchicalMLModel", "depth": depth}, open(os.path.join(folder, "ranker", "param.json"), "w"))
+    json.dump({"model": "XLinearModel"}, open(os.path.join(folder, "param.json"), "w"))
+    return sizes
+
+
+def random_queries(rng, N, D):
+    dens = rng.choice([0.01, 0.08, 0.5])
+    X = smat.random(N, D, density=dens, format="csr", dtype=np.float32, random_state=int(rng.integers(1 << 30)))
+    X = X.tolil()
+    X[0, :] = 0
+    if N > 2:
+        X[1, :] = rng.standard_normal(D).astype(np.float32)      # one fully dense row (forces queue overflow drains)
+    X = X.tocsr().astype(np.float32)
+    if X.nnz:
+        X.data[rng.random(X.nnz) < 0.03] = 0.0                   # explicit zeros stay stored
+    X.sort_indices()
+    return X
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz(seed, tmp_path, oracle_mod):
+    from pecos_amd import XLinearModel, clib
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([37, 300, 2500]))
+    depth = int(rng.integers(1, 5))
+    bias = float(rng.choice([1.0, -1.0, 0.5]))
+    folder = str(tmp_path / "m")
+    sizes = random_model(folder, rng, D, depth, bias)
+    m = XLinearModel.load(folder)
+    om = oracle_mod.OracleModel.load(folder)
+    X = random_queries(rng, int(rng.integers(1, 70)), D)
+    for trial in range(4):
+        beam = int(rng.choice([1, 2, 5, 10, 33, 70, 200]))
+        topk = int(rng.choice([1, 3, 10, 64, 65, 150]))
+        pp = rng.choice([None, "noop", "l2-hinge", "log-l4-hinge", "l3-hinge"])
+        kw = dict(beam_size=beam, only_topk=topk)
+        if pp is not None:
+            kw["post_processor"] = str(pp)
+        clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
+        for Xq in (X, np.ascontiguousarray(X.toarray())):
+            a = m.predict(Xq, **kw)
+            b = om.predict(Xq, **kw)
+            assert a.shape == b.shape
+            assert_same_topk(a, b, exact_scores=True, what=f"seed={seed} sizes={sizes} D={D} bias={bias} {kw} dense={not smat.issparse(Xq)}")
+    clib.set_option(m.model.model_chain, "k1_group", 0)
+    # model defaults (per-layer only_topk / post-processor from param.json)
+    assert_same_topk(m.predict(X), om.predict(X), exact_scores=True, what=f"seed={seed} defaults")
