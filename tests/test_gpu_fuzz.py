@@ -66,7 +66,7 @@ def random_queries(rng, N, D):
     return X
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(48))
 def test_fuzz(seed, tmp_path, oracle_mod):
     from pecos_amd import XLinearModel, clib
     rng = np.random.default_rng(1000 + seed)
