@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--k1-group", type=int, default=0)
+    ap.add_argument("--opt", action="append", default=[], help="library option key=int (xrl_set_option), repeatable")
     args = ap.parse_args()
 
     import numpy as np
@@ -103,6 +104,9 @@ def main():
     h = model.model.model_chain
     if args.k1_group:
         clib.set_option(h, "k1_group", args.k1_group)
+    for kv in args.opt:
+        key, val = kv.split("=")
+        clib.set_option(h, key, int(val))
     if rank == 0:
         log(f"model on GPU: {clib.model_device_bytes(h) / 1e9:.2f} GB in {time.time() - t0:.1f}s")
 

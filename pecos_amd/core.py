@@ -23,7 +23,8 @@ import scipy.sparse as smat
 
 XLINEAR_INFERENCE_MODEL_TYPES = {"CSC": 0, "HASH_CHUNKED": 1, "BINARY_SEARCH_CHUNKED": 2}  # base.py:49
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libxrl_amd.so")
+# PECOS_XRL_AMD_SO selects another build of the same library (kernel-tuning variants)
+_LIB_PATH = os.environ.get("PECOS_XRL_AMD_SO") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libxrl_amd.so")
 
 
 class _MatView(ctypes.Structure):

@@ -31,6 +31,7 @@ struct LayerPlan {
     PostProc pp;
     int first_layer;            // no combine (no_prev_pred)
     int implicit_root;          // previous beam is the implicit all-ones root
+    int layer;                  // index in the chain (profiling only)
 };
 
 // K0  prolongate: per query, offsets of every beam parent's child block + candidate count, and one

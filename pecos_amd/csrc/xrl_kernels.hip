@@ -294,23 +294,33 @@ __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it,
 // hits are compacted IN FEATURE ORDER into a small per-item LDS FIFO (segmented ballot/popcount),
 // then one lane per hit fetches the row extent and its first two entries (all hits of all items at
 // once), and finally the rows are applied in order with the G lanes on distinct columns.
-// NS = number of G-wide UNITS a tile row can span (NS*G >= widest tile in the tuned configurations;
-// with a forced smaller G the last unit carries the remainder through an in-loop path).
-// P  = units per register batch; two batches are in flight.
+// NS = number of G-wide UNITS a tile row can span (NS*G >= widest tile of the layer).
 template <int G, int NS> struct K1Cfg {
     static constexpr int W = 64 / G;                      // items per wavefront
     static constexpr int U = (G >= 32) ? 2 : (G == 16 ? 4 : 8);   // query features per lane per step
     static constexpr int H = (G > 32) ? 2 * G : 64;       // hit queue depth per item (>= G)
     static constexpr int UH = H * NS;                     // unit queue depth per item
-    static constexpr int P = 4;
+#ifndef XRL_K1_P
+#define XRL_K1_P 4
+#endif
+#ifndef XRL_K1_CLAMP
+#define XRL_K1_CLAMP 1
+#endif
+#ifndef XRL_K1_NB
+#define XRL_K1_NB 2
+#endif
+    static constexpr int P = XRL_K1_P;                    // units per register batch
+    static constexpr int NB = XRL_K1_NB;                  // batches in the ring: NB-1 are loading while one is applied
+    static constexpr int TAIL = (2 * NB - 1) * P;         // empty units readable past the longest queue
     static constexpr size_t lds_bytes(uint32_t acc_stride) {
-        return (size_t)W * UH * 16 + (size_t)W * H * 8 + (size_t)W * (acc_stride + G) * 4;
+        return (size_t)W * (UH + TAIL) * 16 + (size_t)W * H * 8 + (size_t)W * (acc_stride + G) * 4;
     }
 };
 
 template <int G, int NS, int PPC, bool DENSE>
 __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
-    constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, UH = K1Cfg<G, NS>::UH, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U;
+    constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, UH = K1Cfg<G, NS>::UH, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U,
+                  NB = K1Cfg<G, NS>::NB, TAIL = K1Cfg<G, NS>::TAIL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     // the wavefronts of a block are fully independent: each owns a slice of the dynamic LDS
     const uint32_t wave = threadIdx.x >> 6;
@@ -318,7 +328,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     if (vblock >= a.n_vblocks) return;
     unsigned char* smem = smem_all + (size_t)wave * a.lds_per_wave;
     uint4* uq = reinterpret_cast<uint4*>(smem);                        // units {x value, entry start, count, -}
-    uint2* hq = reinterpret_cast<uint2*>(uq + W * UH);                 // hits  {x value, row slot}
+    uint2* hq = reinterpret_cast<uint2*>(uq + W * (UH + TAIL));                 // hits  {x value, row slot}
     float* acc = reinterpret_cast<float*>(hq + W * H);
     const uint32_t acc_item = a.acc_stride + G;                        // + one private dummy slot per lane
 
@@ -351,7 +361,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     const Entry* __restrict__ ent = a.L.entries + td.ent_base;
     float* __restrict__ my_acc = acc + (size_t)grp * acc_item;
     uint2* __restrict__ my_hq = hq + (size_t)grp * H;
-    uint4* __restrict__ my_uq = uq + (size_t)grp * UH;
+    uint4* __restrict__ my_uq = uq + (size_t)grp * (UH + TAIL);
     const uint32_t dummy = a.acc_stride + (uint32_t)lig;
     if (DENSE) {   // dense queries: bias FIRST (inference.hpp:824-830); bias_prod already holds 0.0f + bias*w
         const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
@@ -399,48 +409,56 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
                 }
             nu += (G > 1) ? __shfl(incl, G - 1, G) : incl;
         }
+        // every item's queue is read up to the longest queue of the wavefront (+ the prefetch distance):
+        // fill the difference with empty units
+        uint32_t nu_max = nu;
+#pragma unroll
+        for (int d = G; d < 64; d <<= 1) nu_max = max(nu_max, (uint32_t)__shfl_xor((int)nu_max, d, 64));
+        nu_max = __builtin_amdgcn_readfirstlane(nu_max);
+        for (uint32_t j = nu + lig; j < nu_max + (uint32_t)TAIL; j += G) my_uq[j] = make_uint4(0u, 0u, 0u, 0u);
         wave_sync_lds();
         tick(2);
         // ---- D3: units in order.  Two register batches of P units are in flight: while batch A is
-        //      applied the entries of batch B are already loading (unconditional, clamped loads; a load
-        //      behind a per-lane branch makes hipcc wait vmcnt(0) before each one).  The lanes of a unit
-        //      hold distinct columns; lanes without an entry add 0 to a private dummy slot.  LDS
-        //      operations of one wavefront execute in order, so only a compiler fence separates units.
-        struct Batch { uint32_t xv[P], st[P], cn[P]; Entry e[P]; };
-        auto load_batch = [&](uint32_t i0, Batch& B) {
+        //      applied the entries of batch B are already loading.  Every load is unconditional and
+        //      unclamped (a load behind a per-lane branch makes hipcc wait vmcnt(0) before each one): the
+        //      queue ends with 2P empty units and lanes past a unit's end read whatever follows the row
+        //      (the entry array is padded) and add it to a private dummy slot.  The lanes of a unit hold
+        //      distinct columns.  LDS operations of one wavefront execute in order, so only a compiler
+        //      fence separates units.
+        const uint4* __restrict__ uqp = my_uq;
+        struct Batch { uint32_t xv[P], cn[P]; Entry e[P]; };
+        auto load_batch = [&](const uint4* q, Batch& B) {
+            uint32_t st[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) { const uint4 d = q[p]; B.xv[p] = d.x; st[p] = d.y; B.cn[p] = d.z; }
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const bool ok = i0 + p < nu;
-                const uint4 d = my_uq[ok ? i0 + p : 0u];
-                B.xv[p] = d.x; B.st[p] = ok ? d.y : 0u; B.cn[p] = ok ? d.z : 0u;
+#if XRL_K1_CLAMP   // lanes past the unit's end re-read its first entry (no extra cache lines) instead of running on
+                B.e[p] = ent[st[p] + ((uint32_t)lig < B.cn[p] ? (uint32_t)lig : 0u)];
+#else
+                B.e[p] = ent[st[p] + (uint32_t)lig];
+#endif
             }
-#pragma unroll
-            for (int p = 0; p < P; ++p) B.e[p] = ent[B.st[p] + ((uint32_t)lig < B.cn[p] ? (uint32_t)lig : 0u)];
         };
-        auto apply_batch = [&](uint32_t, const Batch& B) {
+        auto apply_batch = [&](const Batch& B) {
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const float v = __uint_as_float(B.xv[p]);
-                const bool valid = (uint32_t)lig < B.cn[p];
-                const uint32_t ci = valid ? B.e[p].col : dummy;
-                const float pr = valid ? __fmul_rn(v, B.e[p].val) : 0.0f;      // scalar * val (inference.hpp:512-517)
-                my_acc[ci] = __fadd_rn(my_acc[ci], pr);                        // mul then add, no fma
-                if (__any(B.cn[p] > (uint32_t)G)) {                            // remainder of an over-long last unit
-                    for (uint32_t x = lig + G; x < B.cn[p]; x += G) {
-                        const Entry en = ent[B.st[p] + x];
-                        my_acc[en.col] = __fadd_rn(my_acc[en.col], __fmul_rn(v, en.val));
-                    }
-                }
+                const uint32_t ci = (uint32_t)lig < B.cn[p] ? B.e[p].col : dummy;
+                my_acc[ci] = __fadd_rn(my_acc[ci], __fmul_rn(v, B.e[p].val));   // scalar * val, then add: no fma (inference.hpp:512-517)
                 wave_sync_lds();
             }
         };
-        Batch A, B2;
-        load_batch(0u, A);
-        for (uint32_t i0 = 0; __any(i0 < nu); i0 += 2 * P) {
-            load_batch(i0 + P, B2);
-            apply_batch(i0, A);
-            load_batch(i0 + 2 * P, A);
-            apply_batch(i0 + P, B2);
+        Batch ring[NB];
+#pragma unroll
+        for (int b = 0; b < NB - 1; ++b) load_batch(uqp + b * P, ring[b]);
+        for (uint32_t i0 = 0; i0 < nu_max; i0 += NB * P) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                load_batch(uqp + (b + NB - 1) * P, ring[(b + NB - 1) % NB]);
+                apply_batch(ring[b]);
+            }
+            uqp += NB * P;
         }
         nh = 0;
         tick(3);
@@ -581,23 +599,28 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     a.n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
     a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
     a.acc_stride = L.max_tile_cols | 1u;
-    a.ablate = g_k1_ablate;
-    a.phase = (g_k1_ablate & 64) ? k1_phase_buffer() : nullptr;
+    a.ablate = g_k1_ablate & 0xFF;
+    // debug: bit 6 = per-phase cycle accounting; bits 8.. select one layer (value layer+1, 0 = every layer)
+    a.phase = ((g_k1_ablate & 64) && ((g_k1_ablate >> 8) == 0 || (g_k1_ablate >> 8) == P.layer + 1)) ? k1_phase_buffer() : nullptr;
     const int ppc = pp_class(P.pp);
 #define XRL_K1(GG, NN) do { \
         const size_t lds = K1Cfg<GG, NN>::lds_bytes(a.acc_stride); \
         if (X.dense) { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, true>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, true>, a, 64 / GG, lds, s); } \
         else { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, false>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, false>, a, 64 / GG, lds, s); } } while (0)
-    const uint32_t ns = (L.max_tile_cols + (uint32_t)group - 1) / (uint32_t)group;
+    // a tile row must fit NS units of `group` lanes; widen a (forced) group that is too narrow
+    if (group < 1 || group > 64 || (group & (group - 1))) fail("k1: lanes-per-item must be a power of two in [1, 64]");
+    auto max_ns = [](int g) { return g < 8 ? 1u : (g == 32 ? 4u : 2u); };
+    auto units = [&](int g) { return (L.max_tile_cols + (uint32_t)g - 1) / (uint32_t)g; };
+    while (group < 64 && units(group) > max_ns(group)) group <<= 1;
+    const uint32_t ns = units(group);
     switch (group) {
     case 1: XRL_K1(1, 1); break;
     case 2: XRL_K1(2, 1); break;
     case 4: XRL_K1(4, 1); break;
-    case 8: XRL_K1(8, 1); break;
-    case 16: XRL_K1(16, 1); break;
+    case 8: if (ns <= 1) XRL_K1(8, 1); else XRL_K1(8, 2); break;
+    case 16: if (ns <= 1) XRL_K1(16, 1); else XRL_K1(16, 2); break;
     case 32: if (ns <= 1) XRL_K1(32, 1); else if (ns == 2) XRL_K1(32, 2); else if (ns == 3) XRL_K1(32, 3); else XRL_K1(32, 4); break;
-    case 64: if (ns <= 1) XRL_K1(64, 1); else XRL_K1(64, 2); break;
-    default: fail("k1: lanes-per-item must be a power of two in [1, 64]");
+    default: if (ns <= 1) XRL_K1(64, 1); else XRL_K1(64, 2); break;
     }
 #undef XRL_K1
 }

@@ -228,8 +228,9 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
                 if (W.row_idx[e] == W.rows - 1) { volatile float pr = bias * W.val[e]; bias_prod[c] = 0.0f + pr; }
         }
     }
-    // kernels issue unconditional, index-clamped loads: keep one readable element past the end
-    row_ptr.push_back(0u); row_ptr.push_back(0u); entries.push_back(Entry{0u, 0.0f}); row_idx.push_back(0u);
+    // kernels issue unconditional loads (index-clamped, or a full wavefront past a row's start): keep
+    // readable elements past the end
+    row_ptr.push_back(0u); row_ptr.push_back(0u); entries.resize(entries.size() + 64, Entry{0u, 0.0f}); row_idx.push_back(0u);
     L->d_bias_prod.upload(bias_prod);
     L->d_tiles.upload(tiles); L->d_ptile.upload(ptile); L->d_chunk_col.upload(chunk_col);
     L->d_bitmap.upload(bitmap); L->d_row_ptr.upload(row_ptr); L->d_row_idx.upload(row_idx);

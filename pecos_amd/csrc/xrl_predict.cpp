@@ -111,6 +111,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         for (size_t l = 0; l < T; ++l) {
             const Layer& L = *m.layers[l];
             LayerPlan P{};
+            P.layer = (int)l;
             P.row0 = (uint32_t)row0; P.nrows = nrows; P.beam_in = beam_in[l]; P.k = k[l];
             P.cand_stride = cstride[l]; P.pp = pp[l];
             P.first_layer = (l == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;   // no_prev_pred

@@ -15,11 +15,14 @@ def dmalloc(n):
     p = ctypes.c_void_p(); assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n)) == 0; return p.value
 k = 10; di, dv, dc = dmalloc(X.shape[0]*k*4), dmalloc(X.shape[0]*k*4), dmalloc(X.shape[0]*4)
 clib.predict_device(h, q, 10, None, k, di, dv, dc, k, sync=True)
-clib.set_option(h, "k1_ablate", 64)
-clib.debug_k1_phases(True)
-clib.predict_device(h, q, 10, None, k, di, dv, dc, k, sync=True)
-ph = clib.debug_k1_phases(True)
 names = ["prologue", "fill", "D1", "D3", "epilogue"]
-tot = sum(ph[:5])
-print("waves", ph[5], "cycles/wave", tot / max(1, ph[5]))
-for n, v in zip(names, ph[:5]): print(f"  {n:9s} {v/tot*100:5.1f}%  {v/max(1,ph[5]):9.0f} cyc/wave")
+depth = clib.xlinear_get_int_attr(h, "depth")
+for extra in sys.argv[1:]:
+    key, val = extra.split("="); clib.set_option(h, key, int(val))
+for layer in range(depth):
+    clib.set_option(h, "k1_ablate", 64 | ((layer + 1) << 8))
+    clib.debug_k1_phases(True)
+    clib.predict_device(h, q, 10, None, k, di, dv, dc, k, sync=True)
+    ph = clib.debug_k1_phases(True)
+    tot = sum(ph[:5])
+    print(f"layer {layer}: waves {ph[5]} cycles/wave {tot / max(1, ph[5]):.0f}  " + "  ".join(f"{n} {v / max(1, ph[5]):.0f} ({v / tot * 100:.0f}%)" for n, v in zip(names, ph[:5])))
