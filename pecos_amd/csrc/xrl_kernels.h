@@ -46,6 +46,10 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
 void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, void* sorted, uint32_t* H,
                        uint32_t* start, hipStream_t s);
 uint32_t sort_max_tiles();
+// K1T tile-stationary K1 (sparse queries, tile-sorted items, tile image held in LDS)
+int k1t_waves(const LayerDev& L);   // wavefronts per workgroup, 0 = a tile image does not fit in LDS
+void launch_k1t(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
+                float* cand, uint32_t items_per_block, hipStream_t s);
 size_t sort_hist_bytes(uint64_t n_slots, uint32_t n_tiles);
 // K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
@@ -62,6 +66,7 @@ void launch_k3_inner_products(const uint64_t* x_ptr, const uint32_t* x_idx, cons
 
 void k1_set_ablate(int mask);   // debug only
 void k1_set_wpb(int waves_per_block);
+void k1_set_lds_pad(int bytes);   // debug only
 unsigned long long* k1_phase_buffer();
 void k1_phase_read(unsigned long long out[8], bool reset);   // debug: per-phase cycle totals of K1
 // K4  predict_on_selected_outputs: one layer of (query, node) pairs against CSC W

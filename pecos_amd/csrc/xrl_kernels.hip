@@ -313,12 +313,15 @@ template <int G, int NS> struct K1Cfg {
     static constexpr int NB = XRL_K1_NB;                  // batches in the ring: NB-1 are loading while one is applied
     static constexpr int TAIL = (2 * NB - 1) * P;         // empty units readable past the longest queue
     static constexpr size_t lds_bytes(uint32_t acc_stride) {
-        return (size_t)W * (UH + TAIL) * 16 + (size_t)W * H * 8 + (size_t)W * (acc_stride + G) * 4;
+        return (size_t)W * (UH + TAIL) * 8 + (size_t)W * H * 8 + (size_t)W * (acc_stride + G) * 4;
     }
 };
 
+#ifndef XRL_K1_WPE
+#define XRL_K1_WPE 5
+#endif
 template <int G, int NS, int PPC, bool DENSE>
-__global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1_WPE, 8))) k1_kernel(K1Args a) {
     constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, UH = K1Cfg<G, NS>::UH, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U,
                   NB = K1Cfg<G, NS>::NB, TAIL = K1Cfg<G, NS>::TAIL;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
@@ -327,7 +330,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     const uint32_t vblock = blockIdx.x * (blockDim.x >> 6) + wave;
     if (vblock >= a.n_vblocks) return;
     unsigned char* smem = smem_all + (size_t)wave * a.lds_per_wave;
-    uint4* uq = reinterpret_cast<uint4*>(smem);                        // units {x value, entry start, count, -}
+    uint2* uq = reinterpret_cast<uint2*>(smem);                        // units {x value, entry start | count << 25}
     uint2* hq = reinterpret_cast<uint2*>(uq + W * (UH + TAIL));                 // hits  {x value, row slot}
     float* acc = reinterpret_cast<float*>(hq + W * H);
     const uint32_t acc_item = a.acc_stride + G;                        // + one private dummy slot per lane
@@ -361,7 +364,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
     const Entry* __restrict__ ent = a.L.entries + td.ent_base;
     float* __restrict__ my_acc = acc + (size_t)grp * acc_item;
     uint2* __restrict__ my_hq = hq + (size_t)grp * H;
-    uint4* __restrict__ my_uq = uq + (size_t)grp * (UH + TAIL);
+    uint2* __restrict__ my_uq = uq + (size_t)grp * (UH + TAIL);
     const uint32_t dummy = a.acc_stride + (uint32_t)lig;
     if (DENSE) {   // dense queries: bias FIRST (inference.hpp:824-830); bias_prod already holds 0.0f + bias*w
         const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
             for (int k = 0; k < NS; ++k)
                 if ((uint32_t)k < cnt) {
                     const uint32_t n_k = (k == NS - 1) ? len - (uint32_t)k * G : min(len - (uint32_t)k * G, (uint32_t)G);
-                    my_uq[base + k] = make_uint4(hv.x, rs + (uint32_t)k * G, n_k, 0u);
+                    my_uq[base + k] = make_uint2(hv.x, (rs + (uint32_t)k * G) | (n_k << 25));   // offsets < 2^25: xrl_model.cpp max_tile_entries
                 }
             nu += (G > 1) ? __shfl(incl, G - 1, G) : incl;
         }
@@ -415,7 +418,7 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
 #pragma unroll
         for (int d = G; d < 64; d <<= 1) nu_max = max(nu_max, (uint32_t)__shfl_xor((int)nu_max, d, 64));
         nu_max = __builtin_amdgcn_readfirstlane(nu_max);
-        for (uint32_t j = nu + lig; j < nu_max + (uint32_t)TAIL; j += G) my_uq[j] = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t j = nu + lig; j < nu_max + (uint32_t)TAIL; j += G) my_uq[j] = make_uint2(0u, 0u);
         wave_sync_lds();
         tick(2);
         // ---- D3: units in order.  Two register batches of P units are in flight: while batch A is
@@ -425,12 +428,12 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
         //      (the entry array is padded) and add it to a private dummy slot.  The lanes of a unit hold
         //      distinct columns.  LDS operations of one wavefront execute in order, so only a compiler
         //      fence separates units.
-        const uint4* __restrict__ uqp = my_uq;
+        const uint2* __restrict__ uqp = my_uq;
         struct Batch { uint32_t xv[P], cn[P]; Entry e[P]; };
-        auto load_batch = [&](const uint4* q, Batch& B) {
+        auto load_batch = [&](const uint2* q, Batch& B) {
             uint32_t st[P];
 #pragma unroll
-            for (int p = 0; p < P; ++p) { const uint4 d = q[p]; B.xv[p] = d.x; st[p] = d.y; B.cn[p] = d.z; }
+            for (int p = 0; p < P; ++p) { const uint2 d = q[p]; B.xv[p] = d.x; st[p] = d.y & 0x1FFFFFFu; B.cn[p] = d.y >> 25; }
 #pragma unroll
             for (int p = 0; p < P; ++p) {
 #if XRL_K1_CLAMP   // lanes past the unit's end re-read its first entry (no extra cache lines) instead of running on
@@ -545,11 +548,13 @@ __global__ void __launch_bounds__(256) k1_kernel(K1Args a) {
 }
 
 int g_k1_wpb = 1;   // wavefronts per workgroup (tuning knob)
+int g_k1_lds_pad = 0;   // debug: extra LDS bytes per wavefront (lowers occupancy, for latency-sensitivity experiments)
+void k1_set_lds_pad(int b) { g_k1_lds_pad = b < 0 ? 0 : b; }
 void k1_set_wpb(int w) { g_k1_wpb = (w == 2 || w == 4) ? w : 1; }
 
 template <class KERNEL>
 static void launch_k1_any(KERNEL kernel, K1Args a, int W, size_t lds_wave, hipStream_t s) {
-    lds_wave = (lds_wave + 15) & ~(size_t)15;
+    lds_wave = (lds_wave + (size_t)g_k1_lds_pad + 15) & ~(size_t)15;
     int wpb = g_k1_wpb;
     while (wpb > 1 && lds_wave * wpb > 160 * 1024) wpb >>= 1;
     const size_t lds = lds_wave * wpb;
@@ -623,6 +628,257 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     default: if (ns <= 1) XRL_K1(64, 1); else XRL_K1(64, 2); break;
     }
 #undef XRL_K1
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1T: tile-stationary K1 for sparse queries.  The items of a layer are tile-sorted (counting sort
+// above); a 16-wavefront workgroup takes a run of `ch` consecutive items, copies the run's tile
+// -- entries, row_ptr, row feature ids, bias products -- into LDS ONCE and keeps it there while
+// its wavefronts stream the run's items through it.  Everything K1 fetches per item from L2/HBM
+// (one bitmap word per query feature, one row extent per hit, ~3 cache lines per row) becomes LDS
+// traffic: per item only the descriptor, the query row and the output block touch global memory.
+// The row lookup is a branch-free binary search over the tile's sorted row ids (the reference's
+// own lookup, inference.hpp:786-803) -- log2(R) LDS reads, all lanes in lock step.
+// Arithmetic and its order are K1's: hits in feature order, a row's entries on distinct lanes.
+// Used when a tile image fits in LDS next to the wavefronts' scratch and a tile serves enough
+// items to pay for the copy; otherwise the layer runs K1.
+// ---------------------------------------------------------------------------------------------
+struct K1TArgs {
+    LayerDev L;
+    QueriesDev X;
+    const ItemDesc* items;       // tile-sorted, all active
+    const uint32_t* start;       // [n_tiles+1] first sorted item of every tile; start[n_tiles] = #items
+    float* cand;
+    uint32_t row0, acc_stride, ch;
+    uint32_t tile_cap;           // bytes of LDS reserved for the tile image
+    uint32_t scratch_per_wave;   // bytes of LDS per wavefront (hit queue + accumulators)
+    int pp_kind, pp_p, first_layer;
+};
+
+template <int G> struct K1TCfg {
+    static constexpr int W = 64 / G;
+    static constexpr int U = (G >= 32) ? 3 : (G == 16 ? 4 : 8);   // query features per lane per step
+    static constexpr int H = (G > 32) ? 2 * G : 64;               // hit queue depth per item (>= G)
+    static constexpr int P = 4;                                   // hits per drain batch
+    static constexpr size_t scratch(uint32_t acc_stride) { return ((size_t)W * H * 8 + (size_t)W * (acc_stride + G) * 4 + 15) & ~(size_t)15; }
+};
+
+template <int G, int NS, int PPC>
+__global__ void __launch_bounds__(1024) k1t_kernel(K1TArgs a) {
+    constexpr int W = K1TCfg<G>::W, U = K1TCfg<G>::U, H = K1TCfg<G>::H, P = K1TCfg<G>::P;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const uint32_t n = a.start[a.L.n_tiles];
+    const uint32_t b0 = blockIdx.x * a.ch;
+    if (b0 >= n) return;
+    const uint32_t b1 = min(n, b0 + a.ch);
+    const uint32_t nthreads = blockDim.x, nw = blockDim.x >> 6;
+    const uint32_t wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, grp = lane / G, lig = lane % G;
+    unsigned char* sw = smem_all + a.tile_cap + (size_t)wave * a.scratch_per_wave;
+    const uint32_t acc_item = a.acc_stride + G;                        // + one private dummy slot per lane
+    uint2* __restrict__ my_hq = reinterpret_cast<uint2*>(sw) + (size_t)grp * H;
+    float* __restrict__ my_acc = reinterpret_cast<float*>(sw + (size_t)W * H * 8) + (size_t)grp * acc_item;
+    const uint32_t dummy = a.acc_stride + (uint32_t)lig;
+    const unsigned long long below = (1ull << lig) - 1ull;
+    const uint32_t* __restrict__ xi = a.X.col_idx;
+    const float* __restrict__ xv = a.X.val;
+
+    uint32_t pos = b0;
+    while (pos < b1) {
+        // ---- the run's next tile -> LDS
+        const uint32_t t = __builtin_amdgcn_readfirstlane(a.items[pos].tile);
+        const uint32_t seg_end = __builtin_amdgcn_readfirstlane(min(b1, a.start[t + 1]));
+        const TileDesc td = a.L.tiles[t];
+        const uint32_t R = td.nrows;
+        const uint32_t* __restrict__ g_rp = a.L.row_ptr + td.rowptr_base;
+        const uint32_t E = __builtin_amdgcn_readfirstlane(g_rp[R]);
+        Entry* __restrict__ t_ent = reinterpret_cast<Entry*>(smem_all);
+        uint32_t* __restrict__ t_rp = reinterpret_cast<uint32_t*>(smem_all + (size_t)E * 8);
+        uint32_t* __restrict__ t_ridx = t_rp + (R + 1);
+        float* __restrict__ t_bias = reinterpret_cast<float*>(t_ridx + R);
+        __syncthreads();                                               // the previous tile's readers are done
+        {
+            const uint2* __restrict__ ge = reinterpret_cast<const uint2*>(a.L.entries + td.ent_base);
+            uint2* le = reinterpret_cast<uint2*>(t_ent);
+            for (uint32_t i = threadIdx.x; i < E; i += nthreads) le[i] = ge[i];
+            const uint32_t* __restrict__ g_ridx = a.L.row_idx + (td.rowptr_base - t);
+            for (uint32_t i = threadIdx.x; i <= R; i += nthreads) t_rp[i] = g_rp[i];
+            for (uint32_t i = threadIdx.x; i < R; i += nthreads) t_ridx[i] = g_ridx[i];
+            const float* __restrict__ gb = a.L.bias_prod + td.col_begin;
+            for (uint32_t i = threadIdx.x; i < td.ncols; i += nthreads) t_bias[i] = gb[i];
+        }
+        __syncthreads();
+
+        for (uint32_t i0 = pos + wave * W; i0 < seg_end; i0 += nw * W) {
+            ItemDesc it{0u, kNoTile, 0u, 0.f};
+            if (i0 + grp < seg_end) it = a.items[i0 + grp];
+            const bool active = it.tile != kNoTile;
+            uint64_t xe = 0, cur = 0;
+            if (active) {
+                const uint64_t qg = (uint64_t)a.row0 + it.q;
+                cur = a.X.row_ptr[qg]; xe = a.X.row_ptr[qg + 1];
+            }
+            for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = 0.0f;   // std::fill(..., 0.0), inference.hpp:964
+            const uint64_t xlast = xe > cur ? xe - 1 : 0;                    // a valid x index for clamped loads
+            uint32_t nh = 0;
+            wave_sync_lds();
+
+            auto drain = [&]() {
+                wave_sync_lds();
+                uint32_t nh_max = nh;
+#pragma unroll
+                for (int d = G; d < 64; d <<= 1) nh_max = max(nh_max, (uint32_t)__shfl_xor((int)nh_max, d, 64));
+                nh_max = __builtin_amdgcn_readfirstlane(nh_max);
+                // P hits per batch: descriptors, then row extents, then first-unit entries are read back to
+                // back (three dependent LDS round trips per batch instead of per hit); the rows are then
+                // applied in order.  Lanes past a row's end add to a private dummy slot.
+                for (uint32_t h0 = 0; h0 < nh_max; h0 += P) {
+                    uint32_t hx[P], hs[P], rs[P], len[P];
+                    Entry e0[P];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const bool ok = h0 + p < nh;
+                        const uint2 hv = my_hq[ok ? h0 + p : 0u];
+                        hx[p] = hv.x; hs[p] = ok ? hv.y : 0u; len[p] = ok ? 1u : 0u;
+                    }
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        rs[p] = t_rp[hs[p]];
+                        const uint32_t re = t_rp[hs[p] + 1];
+                        len[p] = len[p] ? re - rs[p] : 0u;
+                    }
+#pragma unroll
+                    for (int p = 0; p < P; ++p) e0[p] = t_ent[rs[p] + (uint32_t)lig];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float v = __uint_as_float(hx[p]);
+                        {
+                            const uint32_t ci = (uint32_t)lig < len[p] ? e0[p].col : dummy;
+                            my_acc[ci] = __fadd_rn(my_acc[ci], __fmul_rn(v, e0[p].val));   // scalar * val, then add: no fma (inference.hpp:512-517)
+                        }
+#pragma unroll
+                        for (int k = 1; k < NS; ++k) {
+                            if (__any(len[p] > (uint32_t)(k * G))) {
+                                const Entry e = t_ent[rs[p] + (uint32_t)(k * G + lig)];
+                                const uint32_t ci = (uint32_t)(k * G + lig) < len[p] ? e.col : dummy;
+                                my_acc[ci] = __fadd_rn(my_acc[ci], __fmul_rn(v, e.val));
+                            }
+                        }
+                        wave_sync_lds();
+                    }
+                }
+                nh = 0;
+            };
+
+            uint32_t skip = 0;                 // u-slices of the current step already queued (after an overflow)
+            while (__any(cur < xe)) {
+                bool overflow = false;
+                {
+                    uint32_t f[U], slot[U]; float v[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint64_t tt = cur + (uint64_t)(u * G + lig);
+                        const bool ok = tt < xe;
+                        const uint64_t tc = ok ? tt : xlast;         // clamped: the load itself is unconditional
+                        const uint32_t fi = xi[tc];
+                        v[u] = xv[tc];
+                        f[u] = (ok && fi < a.L.w_rows) ? fi : 0xFFFFFFFFu;
+                        slot[u] = 0u;
+                    }
+                    // branch-free binary search, all slices in lock step: slot = last row with id <= f
+                    for (uint32_t nn = R; nn > 1;) {
+                        const uint32_t half = nn >> 1;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) { const uint32_t r = t_ridx[slot[u] + half]; slot[u] = (r <= f[u]) ? slot[u] + half : slot[u]; }
+                        nn -= half;
+                    }
+                    bool hit[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) hit[u] = R > 0u && t_ridx[slot[u]] == f[u];
+                    uint32_t done = skip;
+                    bool stopped = false;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const unsigned long long m = __ballot(hit[u]);
+                        const unsigned long long gm = (G == 64) ? m : ((m >> (grp * G)) & ((1ull << G) - 1ull));
+                        const uint32_t cnt = (uint32_t)__popcll(gm);
+                        if ((uint32_t)u >= done && !stopped) {
+                            if (nh + cnt <= (uint32_t)H) {
+                                if (hit[u]) my_hq[nh + (uint32_t)__popcll(gm & below)] = make_uint2(__float_as_uint(v[u]), slot[u]);
+                                nh += cnt; done = u + 1;
+                            } else {
+                                stopped = true;
+                            }
+                        }
+                    }
+                    if (done == (uint32_t)U) { if (cur < xe) cur += (uint64_t)U * G; skip = 0; }
+                    else { skip = done; overflow = true; }
+                }
+                if (__any(overflow)) drain();
+            }
+            drain();
+            // bias LAST (inference.hpp:806-811), transform, combine, write the child block
+            if (active) {
+                float* __restrict__ out = a.cand + it.out_off;
+                for (uint32_t c = lig; c < td.ncols; c += G) {
+                    float acc = my_acc[c];
+                    if (a.L.has_bias) acc = __fadd_rn(acc, t_bias[c]);
+                    float vv = pp_transform<PPC>(a.pp_kind, a.pp_p, acc);
+                    if (!a.first_layer) vv = pp_combine(a.pp_kind, vv, it.pscore);
+                    out[c] = vv;
+                }
+            }
+            wave_sync_lds();
+        }
+        pos = seg_end;
+    }
+}
+
+static size_t k1t_tile_cap(const LayerDev& L) { return ((size_t)L.max_tile_img + 15) & ~(size_t)15; }
+
+int k1t_group(const LayerDev& L) { return L.max_tile_cols <= 8 ? 8 : (L.max_tile_cols <= 16 ? 16 : 32); }
+
+// waves per workgroup K1T would run with on this layer, or 0 if a tile image does not fit
+int k1t_waves(const LayerDev& L) {
+    if (L.max_tile_img == 0 || L.max_tile_cols > 128) return 0;
+    const int g = k1t_group(L);
+    const uint32_t acc_stride = L.max_tile_cols | 1u;
+    const size_t sc = g == 8 ? K1TCfg<8>::scratch(acc_stride) : g == 16 ? K1TCfg<16>::scratch(acc_stride) : K1TCfg<32>::scratch(acc_stride);
+    for (int nw = 16; nw >= 8; nw >>= 1)
+        if (k1t_tile_cap(L) + (size_t)nw * sc <= 160 * 1024) return nw;
+    return 0;
+}
+
+void launch_k1t(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
+                float* cand, uint32_t items_per_block, hipStream_t s) {
+    if (P.nrows == 0) return;
+    const int nw = k1t_waves(L);
+    if (nw == 0 || X.dense) fail("k1t: layer not eligible");
+    K1TArgs a;
+    a.L = L; a.X = X; a.items = static_cast<const ItemDesc*>(items_sorted); a.start = start; a.cand = cand;
+    a.row0 = P.row0; a.acc_stride = L.max_tile_cols | 1u; a.ch = items_per_block;
+    a.tile_cap = (uint32_t)k1t_tile_cap(L);
+    a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
+    const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
+    const uint64_t blocks = (n_slots + items_per_block - 1) / items_per_block;
+    if (blocks > 0x7FFFFFFFull) fail("k1t: grid too large; lower max_batch_rows");
+    const int ppc = pp_class(P.pp);
+    const int g = k1t_group(L);
+#define XRL_K1T(GG, NN) do { \
+        a.scratch_per_wave = (uint32_t)K1TCfg<GG>::scratch(a.acc_stride); \
+        const size_t lds = (size_t)a.tile_cap + (size_t)nw * a.scratch_per_wave; \
+        auto kern = ppc ? &k1t_kernel<GG, NN, 1> : &k1t_kernel<GG, NN, 0>; \
+        XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(64 * nw), lds, s, a); } while (0)
+    const uint32_t ns = (L.max_tile_cols + (uint32_t)g - 1) / (uint32_t)g;
+    if (g == 8) XRL_K1T(8, 1);
+    else if (g == 16) XRL_K1T(16, 1);
+    else if (ns <= 1) XRL_K1T(32, 1);
+    else if (ns == 2) XRL_K1T(32, 2);
+    else if (ns == 3) XRL_K1T(32, 3);
+    else XRL_K1T(32, 4);
+#undef XRL_K1T
+    XRL_LAUNCH_CHECK();
 }
 
 // ---------------------------------------------------------------------------------------------

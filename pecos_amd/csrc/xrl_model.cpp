@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -81,6 +82,19 @@ template <class F> void parallel_for(size_t n, F&& fn) {
 struct Nz { uint32_t row, col; float val; };
 }  // namespace
 
+// K1 packs {entry offset, count} of a row unit into 32 bits: tile-relative entry offsets stay below 2^25.
+// XRL_MAX_TILE_ENTRIES lowers the limit (tests of the tile splitter).
+static uint64_t max_tile_entries() {
+    static const uint64_t v = [] {
+        const char* e = std::getenv("XRL_MAX_TILE_ENTRIES");
+        const uint64_t lim = (1ull << 25) - 64;
+        if (!e) return lim;
+        const uint64_t x = std::strtoull(e, nullptr, 10);
+        return x >= 2 && x < lim ? x : lim;
+    }();
+    return v;
+}
+
 std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float bias, uint32_t only_topk,
                                      const std::string& post_processor, const std::vector<uint32_t>* perm_inv_override,
                                      uint32_t orig_rows) {
@@ -113,7 +127,26 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         const uint32_t n = ce - cb;
         L->chunk_sizes_desc.push_back(n);
         L->max_chunk_cols = std::max(L->max_chunk_cols, n);
-        const uint32_t nt = (n + kMaxTileCols - 1) / kMaxTileCols;
+        // column tiles: at most kMaxTileCols children and fewer than max_tile_entries() weights each (K1 packs a
+        // tile-relative entry offset into 25 bits); an even split, refined until every tile fits
+        uint32_t nt = (n + kMaxTileCols - 1) / kMaxTileCols;
+        if (n > 0) {
+            std::vector<uint64_t> cum(n + 1, 0);
+            for (uint32_t c = 0; c < n; ++c) {
+                const uint32_t oc = contiguous ? cb + c : C.row_idx[cb + c];
+                if (oc >= W.cols) fail("layer: C row index out of range of W's columns");
+                cum[c + 1] = cum[c] + (W.col_ptr[oc + 1] - W.col_ptr[oc]);
+            }
+            auto fits = [&](uint32_t k) {
+                for (uint32_t t = 0; t < k; ++t)
+                    if (cum[(uint64_t)n * (t + 1) / k] - cum[(uint64_t)n * t / k] >= max_tile_entries()) return false;
+                return true;
+            };
+            while (!fits(nt)) {
+                if (nt >= n) fail("layer: one weight column holds " + std::to_string(max_tile_entries()) + " or more entries");
+                nt = std::min<uint32_t>(n, nt + std::max<uint32_t>(1, nt / 4));
+            }
+        }
         for (uint32_t t = 0; t < nt; ++t) {
             TileDesc td{};
             const uint32_t b = cb + (uint32_t)((uint64_t)n * t / nt), e = cb + (uint32_t)((uint64_t)n * (t + 1) / nt);
@@ -140,7 +173,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
             const uint32_t oc = orig_col(c);
             n += W.col_ptr[oc + 1] - W.col_ptr[oc];
         }
-        if (n > 0xFFFFFFF0ull) fail("layer: a tile holds more than 2^32 entries");
+        if (n >= max_tile_entries()) fail("layer: internal error, tile over the entry limit");
         tile_nnz[t] = n;
     }
     uint64_t nnz = 0;
@@ -194,6 +227,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     uint64_t total_rows = 0;
     for (uint32_t t = 0; t < T; ++t) { tiles[t].rowptr_base = total_rows + t; total_rows += tiles[t].nrows; }
     L->total_rows = total_rows;
+    for (uint32_t t = 0; t < T; ++t)   // LDS image of a tile (K1T): entries, row_ptr, row ids, bias products
+        L->max_tile_img = std::max<uint64_t>(L->max_tile_img, tile_nnz[t] * 8 + ((uint64_t)tiles[t].nrows * 2 + 1) * 4 + (uint64_t)tiles[t].ncols * 4);
     std::vector<uint32_t> row_ptr(total_rows + T), row_idx(total_rows);
     parallel_for(T, [&](size_t t) {
         std::memcpy(row_ptr.data() + tiles[t].rowptr_base, t_rptr[t].data(), t_rptr[t].size() * 4);
@@ -260,6 +295,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     d.bias_prod = L->d_bias_prod.as<float>();
     d.n_parents = P; d.n_children = L->n_children; d.n_tiles = T; d.nwords = L->nwords; d.w_rows = W.rows;
     d.max_tiles_per_parent = L->max_tiles_per_parent; d.max_tile_cols = L->max_tile_cols;
+    d.max_tile_img = (uint32_t)std::min<uint64_t>(L->max_tile_img, 0xFFFFFFFFull);
     d.bias = bias; d.has_bias = has_bias ? 1 : 0;
     return L;
 }

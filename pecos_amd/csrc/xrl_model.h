@@ -58,6 +58,7 @@ struct LayerDev {
     const float* bias_prod;      // [n_children] fl32(bias * W[bias_row, child]) or +0.0 (no explicit entry / no bias)
     uint32_t n_parents, n_children, n_tiles, nwords, w_rows;
     uint32_t max_tiles_per_parent, max_tile_cols;
+    uint32_t max_tile_img;       // bytes of the largest tile image (entries + row_ptr + row ids + bias products), 0 = unknown
     float bias;
     int has_bias;
 };
@@ -72,6 +73,7 @@ struct Layer {
     bool reordered = false;
     uint32_t n_children = 0;               // nnz(C)
     uint32_t n_tiles = 0, nwords = 0, max_tiles_per_parent = 0, max_tile_cols = 0, max_chunk_cols = 0;
+    uint64_t max_tile_img = 0;
     uint64_t nnz = 0, total_rows = 0;
     std::vector<uint32_t> chunk_sizes_desc;  // chunk sizes sorted descending (cand stride bound)
     // predict_on_selected_outputs (inference.hpp:2507-2571): host copy of C's pattern, child -> parent,
@@ -114,6 +116,8 @@ struct Model {
     // options
     int k1_group = 0;                       // 0 = auto
     int64_t max_batch_rows = 0;             // 0 = auto
+    int k1t_min_items = 0;                  // run a layer tile-stationary (K1T) once a tile serves at least this many items on average (0 = never)
+    int k1t_items_per_block = 1024;
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
     bool profiling = false;
     std::vector<ProfileSlot> profile;

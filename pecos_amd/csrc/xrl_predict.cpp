@@ -76,11 +76,21 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     uint64_t slots_max = 1;
     for (size_t l = 0; l < T; ++l) slots_max = std::max<uint64_t>(slots_max, nb * beam_in[l] * m.layers[l]->max_tiles_per_parent);
     ws.items.reserve(slots_max * k0_item_bytes());
+    // per layer: 0 = K1 on the items in natural order, 1 = K1 on tile-sorted items, 2 = K1T (tile-stationary:
+    // tile-sorted items, tile image in LDS) -- chosen when a tile image fits and a tile serves enough items
+    auto layer_mode = [&](size_t l, uint64_t rows) -> int {
+        const Layer& L = *m.layers[l];
+        if (L.n_tiles > sort_max_tiles()) return 0;
+        const uint64_t slots = rows * beam_in[l] * L.max_tiles_per_parent;
+        if (!X.dense && m.k1t_min_items > 0 && k1t_waves(L.dev) > 0 && slots / L.n_tiles >= (uint64_t)m.k1t_min_items) return 2;
+        if (m.sort_min_tiles > 0 && L.n_tiles >= (uint32_t)m.sort_min_tiles) return 1;
+        return 0;
+    };
     {
         size_t hist_max = 0; uint32_t tiles_max = 0; bool any = false;
         for (size_t l = 0; l < T; ++l) {
             const Layer& L = *m.layers[l];
-            if (m.sort_min_tiles > 0 && L.n_tiles >= (uint32_t)m.sort_min_tiles && L.n_tiles <= sort_max_tiles()) {
+            if (layer_mode(l, nb) != 0 || (X.rows % nb && layer_mode(l, X.rows % nb) != 0)) {
                 any = true;
                 hist_max = std::max(hist_max, sort_hist_bytes(nb * beam_in[l] * L.max_tiles_per_parent, L.n_tiles));
                 tiles_max = std::max(tiles_max, L.n_tiles);
@@ -130,12 +140,15 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
 
             int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
             timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.items.p, stream); });
-            const bool sorted = m.sort_min_tiles > 0 && L.n_tiles >= (uint32_t)m.sort_min_tiles && L.n_tiles <= sort_max_tiles();
+            const int mode = layer_mode(l, nrows);
             const uint64_t n_slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
-            if (sorted) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, ws.items.p, ws.items_sorted.p, ws.sort_hist.as<uint32_t>(), ws.sort_start.as<uint32_t>(), stream); });
-            timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] {
-                launch_k1(L.dev, P, X, sorted ? ws.items_sorted.p : ws.items.p, sorted ? ws.sort_start.as<uint32_t>() + L.n_tiles : nullptr,
-                          ws.cand.as<float>(), g, stream); });
+            if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, ws.items.p, ws.items_sorted.p, ws.sort_hist.as<uint32_t>(), ws.sort_start.as<uint32_t>(), stream); });
+            if (mode == 2)
+                timed("k1t_sparse", (uint32_t)l, [&] { launch_k1t(L.dev, P, X, ws.items_sorted.p, ws.sort_start.as<uint32_t>(), ws.cand.as<float>(), (uint32_t)std::max(64, m.k1t_items_per_block), stream); });
+            else
+                timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] {
+                    launch_k1(L.dev, P, X, mode == 1 ? ws.items_sorted.p : ws.items.p, mode == 1 ? ws.sort_start.as<uint32_t>() + L.n_tiles : nullptr,
+                              ws.cand.as<float>(), g, stream); });
             timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.cand.as<float>(), oi, ov, oc, os, stream); });
             if (o.stats_out) launch_stats(L.dev, P, prev, ws.ncand.as<uint32_t>(), ws.stats.as<double>() + 2 * l, stream);
         }

@@ -86,11 +86,15 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         if pp is not None:
             kw["post_processor"] = str(pp)
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
+        # tile-stationary kernel: off / forced for every layer whose tiles fit in LDS, short and long item runs
+        clib.set_option(m.model.model_chain, "k1t_min_items", int(rng.choice([0, 1, 1])))
+        clib.set_option(m.model.model_chain, "k1t_items_per_block", int(rng.choice([64, 128, 1024])))
         for Xq in (X, np.ascontiguousarray(X.toarray())):
             a = m.predict(Xq, **kw)
             b = om.predict(Xq, **kw)
             assert a.shape == b.shape
             assert_same_topk(a, b, exact_scores=True, what=f"seed={seed} sizes={sizes} D={D} bias={bias} {kw} dense={not smat.issparse(Xq)}")
     clib.set_option(m.model.model_chain, "k1_group", 0)
+    clib.set_option(m.model.model_chain, "k1t_min_items", 1)
     # model defaults (per-layer only_topk / post-processor from param.json)
     assert_same_topk(m.predict(X), om.predict(X), exact_scores=True, what=f"seed={seed} defaults")

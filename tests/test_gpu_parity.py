@@ -72,9 +72,16 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
         G = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"]))
         for g in (0, 1, 2, 8, 64):
             clib.set_option(m.model.model_chain, "k1_group", g)
+            clib.set_option(m.model.model_chain, "k1t_min_items", 0)
             P = m.predict(X, **c["kwargs"])
             assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} G={g}")
         clib.set_option(m.model.model_chain, "k1_group", 0)
+        # tile-stationary kernel forced on every layer whose tiles fit in LDS
+        for ipb in (64, 1024):
+            clib.set_option(m.model.model_chain, "k1t_min_items", 1)
+            clib.set_option(m.model.model_chain, "k1t_items_per_block", ipb)
+            P = m.predict(X, **c["kwargs"])
+            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1T ipb={ipb}")
 
 
 @pytest.mark.parametrize("name,scale", [("eurlex-4k", 0.5), ("wiki10-31k", 0.1), ("amazon-670k", 0.02)])
@@ -92,6 +99,11 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} {pp}")
     # model defaults (no overrides), max_pred_chunk slicing, dense queries
     assert_same_topk(m.predict(X), ref.predict(X), exact_scores=True, what="defaults")
+    for k1t in (0, 1):   # K1 everywhere / tile-stationary K1T wherever a tile image fits in LDS
+        clib.set_option(m.model.model_chain, "k1t_min_items", k1t)
+        assert_same_topk(m.predict(X, beam_size=cfg["beam"], only_topk=10), ref.predict(X, beam_size=cfg["beam"], only_topk=10),
+                         exact_scores=True, what=f"{name} k1t_min_items={k1t}")
+    clib.set_option(m.model.model_chain, "k1t_min_items", 64)
     assert_same_topk(m.predict(X, beam_size=5, only_topk=3, max_pred_chunk=37), ref.predict(X, beam_size=5, only_topk=3),
                      exact_scores=True, what="max_pred_chunk")
     if X.shape[1] <= 6000:
