@@ -36,7 +36,7 @@ struct LayerPlan {
 
 // K0  prolongate: per query, offsets of every beam parent's child block + candidate count, and one
 //     16-byte item descriptor per (query, beam slot, tile-in-parent) for K1.
-void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, BeamDev prev, uint32_t* cand_off,
+void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, uint32_t* cand_off,
                           uint32_t* ncand, void* items, hipStream_t s);
 size_t k0_item_bytes();
 // K1  (query, tile) inner products + bias + post-processor + combine, one item per G lanes.

@@ -95,6 +95,11 @@ static uint64_t max_tile_entries() {
     return v;
 }
 
+static bool k1t_images_enabled() {
+    const char* e = std::getenv("XRL_K1T");
+    return e && e[0] && e[0] != '0';
+}
+
 std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float bias, uint32_t only_topk,
                                      const std::string& post_processor, const std::vector<uint32_t>* perm_inv_override,
                                      uint32_t orig_rows) {
@@ -227,13 +232,57 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     uint64_t total_rows = 0;
     for (uint32_t t = 0; t < T; ++t) { tiles[t].rowptr_base = total_rows + t; total_rows += tiles[t].nrows; }
     L->total_rows = total_rows;
-    for (uint32_t t = 0; t < T; ++t)   // LDS image of a tile (K1T): entries, row_ptr, row ids, bias products
-        L->max_tile_img = std::max<uint64_t>(L->max_tile_img, tile_nnz[t] * 8 + ((uint64_t)tiles[t].nrows * 2 + 1) * 4 + (uint64_t)tiles[t].ncols * 4);
     std::vector<uint32_t> row_ptr(total_rows + T), row_idx(total_rows);
     parallel_for(T, [&](size_t t) {
         std::memcpy(row_ptr.data() + tiles[t].rowptr_base, t_rptr[t].data(), t_rptr[t].size() * 4);
         if (!t_rows[t].empty()) std::memcpy(row_idx.data() + (tiles[t].rowptr_base - t), t_rows[t].data(), t_rows[t].size() * 4);
     });
+
+    // ---- tile images for the tile-stationary kernel K1T: one self-contained blob per tile, copied verbatim into
+    //      LDS.  The row lookup is a bucket table over feature-id ranges followed by a few binary-search steps.
+    //      words: [E, R, ncols, levels] entries[E]{col*4, val} rp[R+1] ridx[R] bucket[NBK+1] (u16) bias[ncols] pad-to-4
+    std::vector<uint32_t> img; std::vector<uint64_t> img_off;
+    {
+        uint32_t shift = 0;
+        while ((((uint64_t)W.rows - 1) >> shift) + 1 > 4096) ++shift;
+        const uint32_t NBK = W.rows ? (uint32_t)((((uint64_t)W.rows - 1) >> shift) + 1) : 1;
+        const uint64_t bkw = (NBK + 1 + 1) / 2;   // u16 bucket table, in words
+        auto words_of = [&](uint64_t E, uint64_t R, uint64_t nc) { return (4 + 2 * E + (R + 1) + R + bkw + nc + 3) & ~3ull; };
+        uint64_t max_words = 0, total = 0; uint32_t max_rows = 0;
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint64_t w = words_of(tile_nnz[t], tiles[t].nrows, tiles[t].ncols);
+            max_words = std::max(max_words, w); total += w; max_rows = std::max(max_rows, tiles[t].nrows);
+        }
+        L->max_tile_img = max_words * 4;
+        // the images cost about as much HBM as the entries themselves: built only when K1T is asked for (XRL_K1T=1)
+        if (k1t_images_enabled() && T > 0 && max_words * 4 <= kMaxTileImageBytes && max_rows < 65536) {
+            img.assign(total, 0u); img_off.assign((size_t)T + 1, 0);
+            for (uint32_t t = 0; t < T; ++t) img_off[t + 1] = img_off[t] + words_of(tile_nnz[t], tiles[t].nrows, tiles[t].ncols);
+            parallel_for(T, [&](size_t t) {
+                const TileDesc& td = tiles[t];
+                const uint32_t E = (uint32_t)tile_nnz[t], R = td.nrows;
+                uint32_t* b = img.data() + img_off[t];
+                uint32_t* ents = b + 4; uint32_t* rp = ents + 2 * (size_t)E;
+                uint32_t* ridx = rp + (R + 1); uint16_t* bk = reinterpret_cast<uint16_t*>(ridx + R);
+                const Entry* ent = entries.data() + td.ent_base;
+                for (uint32_t e = 0; e < E; ++e) { ents[2 * e] = ent[e].col * 4u; std::memcpy(&ents[2 * e + 1], &ent[e].val, 4); }
+                std::memcpy(rp, t_rptr[t].data(), ((size_t)R + 1) * 4);
+                if (R) std::memcpy(ridx, t_rows[t].data(), (size_t)R * 4);
+                uint32_t maxlen = 0, r0 = 0;
+                for (uint32_t k = 0; k < NBK; ++k) {
+                    while (r0 < R && (ridx[r0] >> shift) < k) ++r0;
+                    bk[k] = (uint16_t)r0;
+                    if (k > 0) maxlen = std::max<uint32_t>(maxlen, bk[k] - bk[k - 1]);
+                }
+                bk[NBK] = (uint16_t)R;
+                maxlen = std::max<uint32_t>(maxlen, R - bk[NBK - 1]);
+                uint32_t levels = 0;
+                while ((1u << levels) < maxlen) ++levels;      // search steps of 2^(levels-1) .. 1 cover maxlen rows
+                b[0] = E; b[1] = R; b[2] = td.ncols; b[3] = levels;
+            });
+            L->img_mw = (uint32_t)bkw; L->img_shift = shift; L->img_nbk = NBK;
+        }
+    }
 
     // algorithmic bytes of the REFERENCE chunk layout per parent:
     // 8*E_p (entries) + 4*R_p (row_idx) + 4*(R_p+1) (row_ptr as u32)
@@ -263,6 +312,14 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
                 if (W.row_idx[e] == W.rows - 1) { volatile float pr = bias * W.val[e]; bias_prod[c] = 0.0f + pr; }
         }
     }
+    if (!img.empty()) {
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t E = (uint32_t)tile_nnz[t], R = tiles[t].nrows;
+            uint32_t* bias_w = img.data() + img_off[t] + 4 + 2 * (size_t)E + (R + 1) + R + L->img_mw;
+            std::memcpy(bias_w, bias_prod.data() + tiles[t].col_begin, (size_t)tiles[t].ncols * 4);
+        }
+        L->d_img.upload(img); L->d_img_off.upload(img_off);
+    }
     // kernels issue unconditional loads (index-clamped, or a full wavefront past a row's start): keep
     // readable elements past the end
     row_ptr.push_back(0u); row_ptr.push_back(0u); entries.resize(entries.size() + 64, Entry{0u, 0.0f}); row_idx.push_back(0u);
@@ -285,7 +342,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         for (auto& v : L->h_c_idx) v = (*perm_inv_override)[v];
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
-                      L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap;
+                      L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap +
+                      L->d_img.cap + L->d_img_off.cap;
 
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
@@ -296,6 +354,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     d.n_parents = P; d.n_children = L->n_children; d.n_tiles = T; d.nwords = L->nwords; d.w_rows = W.rows;
     d.max_tiles_per_parent = L->max_tiles_per_parent; d.max_tile_cols = L->max_tile_cols;
     d.max_tile_img = (uint32_t)std::min<uint64_t>(L->max_tile_img, 0xFFFFFFFFull);
+    d.img = img.empty() ? nullptr : L->d_img.as<uint32_t>(); d.img_off = img.empty() ? nullptr : L->d_img_off.as<uint64_t>();
+    d.img_mw = L->img_mw; d.img_shift = L->img_shift; d.img_nbk = L->img_nbk;
     d.bias = bias; d.has_bias = has_bias ? 1 : 0;
     return L;
 }

@@ -27,6 +27,7 @@ namespace xrl {
 
 constexpr uint32_t kMaxTileCols = 128;       // accumulators per (query, tile) item held in LDS
 constexpr uint32_t kNoBias = 0xFFFFFFFFu;
+constexpr uint64_t kMaxTileImageBytes = 136 * 1024;   // K1T: largest tile image kept in LDS (160 KiB minus wavefront scratch)
 
 enum PPKind : int { PP_NOOP = 0, PP_SIGMOID = 1, PP_LOG_SIGMOID = 2, PP_LP_HINGE = 3, PP_LOG_LP_HINGE = 4 };
 struct PostProc { int kind = PP_NOOP; int p = 0; };
@@ -58,7 +59,10 @@ struct LayerDev {
     const float* bias_prod;      // [n_children] fl32(bias * W[bias_row, child]) or +0.0 (no explicit entry / no bias)
     uint32_t n_parents, n_children, n_tiles, nwords, w_rows;
     uint32_t max_tiles_per_parent, max_tile_cols;
-    uint32_t max_tile_img;       // bytes of the largest tile image (entries + row_ptr + row ids + bias products), 0 = unknown
+    uint32_t max_tile_img;       // bytes of the largest K1T tile image
+    const uint32_t* img;         // K1T tile images (nullptr: a tile does not fit in LDS), image t at img + img_off[t] (u32 words)
+    const uint64_t* img_off;
+    uint32_t img_mw, img_shift, img_nbk;   // words of the (u16) bucket table, feature-id shift, number of buckets
     float bias;
     int has_bias;
 };
@@ -74,6 +78,7 @@ struct Layer {
     uint32_t n_children = 0;               // nnz(C)
     uint32_t n_tiles = 0, nwords = 0, max_tiles_per_parent = 0, max_tile_cols = 0, max_chunk_cols = 0;
     uint64_t max_tile_img = 0;
+    uint32_t img_mw = 0, img_shift = 0, img_nbk = 0;
     uint64_t nnz = 0, total_rows = 0;
     std::vector<uint32_t> chunk_sizes_desc;  // chunk sizes sorted descending (cand stride bound)
     // predict_on_selected_outputs (inference.hpp:2507-2571): host copy of C's pattern, child -> parent,
@@ -83,6 +88,7 @@ struct Layer {
     DevBuf d_csc_ptr, d_csc_idx, d_csc_val; bool csc_ready = false;
     // device storage
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
+    DevBuf d_img, d_img_off;
     LayerDev dev{};
     uint64_t device_bytes = 0;
     // sum of the `beam` largest chunks: upper bound on candidates per query entering this layer

@@ -139,7 +139,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             else { const int b = (int)(l & 1); oi = ws.beam_idx[b].as<uint32_t>(); ov = ws.beam_val[b].as<float>(); oc = ws.beam_cnt[b].as<uint32_t>(); os = beam_stride; }
 
             int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
-            timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.items.p, stream); });
+            timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.items.p, stream); });
             const int mode = layer_mode(l, nrows);
             const uint64_t n_slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
             if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, ws.items.p, ws.items_sorted.p, ws.sort_hist.as<uint32_t>(), ws.sort_start.as<uint32_t>(), stream); });

@@ -15,7 +15,7 @@ def dmalloc(n):
     p = ctypes.c_void_p(); assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n)) == 0; return p.value
 k = 10; di, dv, dc = dmalloc(X.shape[0]*k*4), dmalloc(X.shape[0]*k*4), dmalloc(X.shape[0]*4)
 clib.predict_device(h, q, 10, None, k, di, dv, dc, k, sync=True)
-names = ["prologue", "fill", "D1", "D3", "epilogue"]
+names = ["prologue|copy", "fill|prefetch", "D1|fill", "D3|drain", "epilogue"]   # K1 | K1T phase names
 depth = clib.xlinear_get_int_attr(h, "depth")
 for extra in sys.argv[1:]:
     key, val = extra.split("="); clib.set_option(h, key, int(val))

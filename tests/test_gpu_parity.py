@@ -103,7 +103,15 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         clib.set_option(m.model.model_chain, "k1t_min_items", k1t)
         assert_same_topk(m.predict(X, beam_size=cfg["beam"], only_topk=10), ref.predict(X, beam_size=cfg["beam"], only_topk=10),
                          exact_scores=True, what=f"{name} k1t_min_items={k1t}")
-    clib.set_option(m.model.model_chain, "k1t_min_items", 64)
+    # the forced run really went through the tile-stationary kernel
+    clib.set_option(m.model.model_chain, "k1t_min_items", 1)
+    clib.profile_enable(m.model.model_chain, True); clib.profile_reset(m.model.model_chain)
+    m.predict(X, beam_size=cfg["beam"], only_topk=10)
+    names = {r["name"] for r in clib.profile_get(m.model.model_chain)}
+    clib.profile_enable(m.model.model_chain, False)
+    if name != "wiki10-31k":   # its scaled-down leaf tiles (101938 features) do not fit in LDS: K1 serves every layer
+        assert "k1t_sparse" in names, names
+    clib.set_option(m.model.model_chain, "k1t_min_items", 0)
     assert_same_topk(m.predict(X, beam_size=5, only_topk=3, max_pred_chunk=37), ref.predict(X, beam_size=5, only_topk=3),
                      exact_scores=True, what="max_pred_chunk")
     if X.shape[1] <= 6000:
