@@ -304,9 +304,14 @@ __device__ __forceinline__ void k1_epilogue(const K1Args& a, const ItemDesc& it,
 // then one lane per hit fetches the row extent and its first two entries (all hits of all items at
 // once), and finally the rows are applied in order with the G lanes on distinct columns.
 // NS = number of G-wide UNITS a tile row can span (NS*G >= widest tile of the layer).
+struct __attribute__((packed, aligned(4))) RowExt { uint32_t start, end; };
+
 template <int G, int NS> struct K1Cfg {
     static constexpr int W = 64 / G;                      // items per wavefront
-    static constexpr int U = (G >= 32) ? 2 : (G == 16 ? 4 : 8);   // query features per lane per step
+#ifndef XRL_K1_FEAT
+#define XRL_K1_FEAT 64
+#endif
+    static constexpr int U = (G >= 16) ? XRL_K1_FEAT / G : 8;     // query features per lane per step (XRL_K1_FEAT per item)
     static constexpr int H = (G > 32) ? 2 * G : 64;       // hit queue depth per item (>= G)
     static constexpr int UH = H * NS;                     // unit queue depth per item
 #ifndef XRL_K1_P
@@ -403,7 +408,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
             const bool ok = h < nh;
             const uint2 hv = my_hq[ok ? h : 0u];
             const uint32_t s = ok ? hv.y : 0u;
-            const uint32_t rs = rp[s], re = rp[s + 1];                 // unconditional (slot 0 when idle)
+            // row extent {start, end}: ONE 8-byte load at a 4-byte aligned address (the two words share a cache
+            // line all but 1/32 of the time; as two loads they cost the L1 two line look-ups per lane)
+            const RowExt rx = *reinterpret_cast<const RowExt*>(rp + s);        // unconditional (slot 0 when idle)
+            const uint32_t rs = rx.start, re = rx.end;
             const uint32_t len = ok ? re - rs : 0u;
             uint32_t cnt = (NS == 1) ? (len ? 1u : 0u) : min((len + G - 1) / G, (uint32_t)NS);
             uint32_t incl = cnt;
