@@ -568,6 +568,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         if (!std::strcmp(key, "k1_group")) m.k1_group = (int)value;
         else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
         else if (!std::strcmp(key, "sort_min_tiles")) m.sort_min_tiles = (int)value;
+        else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
         else if (!std::strcmp(key, "k1t_min_items")) m.k1t_min_items = (int)value;
         else if (!std::strcmp(key, "k1t_items_per_block")) m.k1t_items_per_block = (int)value;
         else if (!std::strcmp(key, "k1_wpb")) k1_set_wpb((int)value);

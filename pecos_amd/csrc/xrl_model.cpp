@@ -48,6 +48,8 @@ uint64_t Layer::cand_bound(uint32_t beam) const {
 
 Model::Model() {}
 Model::~Model() {
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    if (aux_stream) (void)hipStreamDestroy(aux_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 uint64_t Model::device_bytes() const {

@@ -99,10 +99,14 @@ struct ProfileSlot { std::string name; uint32_t layer; uint32_t launches = 0; do
 struct PendingEvent { hipEvent_t a, b; size_t slot; };
 
 // predict scratch, grow-only, owned by the model handle
-struct Workspace {
+struct LaneWs {      // scratch of one row batch in flight
     DevBuf beam_idx[2], beam_val[2], beam_cnt[2];
-    DevBuf cand_off, ncand, cand, stats;
+    DevBuf cand_off, ncand, cand;
     DevBuf items, items_sorted, sort_hist, sort_start;   // item descriptors (K0) and their tile-sorted copy
+};
+struct Workspace {
+    LaneWs lane[2];      // two row batches are in flight on two streams (xrl_predict.cpp)
+    DevBuf stats;
     // host-ABI predict: uploaded X + result staging
     DevBuf x_ptr, x_idx, x_val;
     DevBuf out_idx, out_val, out_cnt;
@@ -117,11 +121,15 @@ struct Model {
     std::vector<std::unique_ptr<Layer>> layers;
     uint32_t nr_features = 0, nr_labels = 0, nr_codes = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;       // second lane of the batch pipeline
+    std::vector<hipEvent_t> events;         // cross-stream ordering (timing disabled), reused across predicts
     std::mutex mu;                          // one predict at a time per handle
     std::unique_ptr<Workspace> ws;
     // options
     int k1_group = 0;                       // 0 = auto
     int64_t max_batch_rows = 0;             // 0 = auto
+    int overlap_min_rows = 16384;           // split a predict of at least this many rows into two half batches on two streams so that one
+                                            // half's K0/K2 (VALU-heavy) run under the other half's K1 (memory-bound); 0 = never
     int k1t_min_items = 0;                  // run a layer tile-stationary (K1T) once a tile serves at least this many items on average (0 = never)
     int k1t_items_per_block = 1024;
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)

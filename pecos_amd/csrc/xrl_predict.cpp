@@ -67,15 +67,22 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     nb = std::min<uint64_t>(nb, 1u << 22);
     if (m.max_batch_rows > 0) nb = std::min<uint64_t>(nb, (uint64_t)m.max_batch_rows);
     nb = std::min<uint64_t>(nb, std::max<uint32_t>(1, X.rows));
+    // two lanes: the row batches alternate between the caller's stream and an auxiliary one.  K1 launches are chained
+    // across the lanes (one K1 at a time owns the memory system); a lane's K0 / sort / K2 run under the other lane's K1.
+    const int lanes = (m.overlap_min_rows > 0 && !o.stats_out && !m.profiling && X.rows >= (uint64_t)m.overlap_min_rows) ? 2 : 1;
+    if (lanes == 2) nb = std::min<uint64_t>(nb, ((uint64_t)X.rows + 1) / 2);
 
-    for (int i = 0; i < 2; ++i) {
-        ws.beam_idx[i].reserve(nb * beam_stride * 4);
-        ws.beam_val[i].reserve(nb * beam_stride * 4);
-        ws.beam_cnt[i].reserve(nb * 4);
+    for (int ln = 0; ln < lanes; ++ln) {
+        LaneWs& lw = ws.lane[ln];
+        for (int i = 0; i < 2; ++i) {
+            lw.beam_idx[i].reserve(nb * beam_stride * 4);
+            lw.beam_val[i].reserve(nb * beam_stride * 4);
+            lw.beam_cnt[i].reserve(nb * 4);
+        }
     }
     uint64_t slots_max = 1;
     for (size_t l = 0; l < T; ++l) slots_max = std::max<uint64_t>(slots_max, nb * beam_in[l] * m.layers[l]->max_tiles_per_parent);
-    ws.items.reserve(slots_max * k0_item_bytes());
+    for (int ln = 0; ln < lanes; ++ln) ws.lane[ln].items.reserve(slots_max * k0_item_bytes());
     // per layer: 0 = K1 on the items in natural order, 1 = K1 on tile-sorted items, 2 = K1T (tile-stationary:
     // tile-sorted items, tile image in LDS) -- chosen when a tile image fits and a tile serves enough items
     auto layer_mode = [&](size_t l, uint64_t rows) -> int {
@@ -96,28 +103,45 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 tiles_max = std::max(tiles_max, L.n_tiles);
             }
         }
-        if (any) { ws.items_sorted.reserve(slots_max * k0_item_bytes()); ws.sort_hist.reserve(hist_max); ws.sort_start.reserve(((size_t)tiles_max + 1) * 4); }
+        if (any) for (int ln = 0; ln < lanes; ++ln) { LaneWs& lw = ws.lane[ln]; lw.items_sorted.reserve(slots_max * k0_item_bytes()); lw.sort_hist.reserve(hist_max); lw.sort_start.reserve(((size_t)tiles_max + 1) * 4); }
     }
-    ws.cand_off.reserve(nb * bin_max * 4);
-    ws.ncand.reserve(nb * 4);
-    ws.cand.reserve(nb * (uint64_t)cs_max * 4);
+    for (int ln = 0; ln < lanes; ++ln) { LaneWs& lw = ws.lane[ln]; lw.cand_off.reserve(nb * bin_max * 4); lw.ncand.reserve(nb * 4); lw.cand.reserve(nb * (uint64_t)cs_max * 4); }
     if (o.stats_out) {
         ws.stats.reserve(T * 2 * sizeof(double));
         XRL_HIP(hipMemsetAsync(ws.stats.p, 0, T * 2 * sizeof(double), stream));
     }
 
-    auto timed = [&](const char* name, uint32_t layer, auto&& fn) {
-        if (!m.profiling) { fn(); return; }
-        PendingEvent ev; ev.slot = profile_slot(m, name, layer);
-        XRL_HIP(hipEventCreate(&ev.a)); XRL_HIP(hipEventCreate(&ev.b));
-        XRL_HIP(hipEventRecord(ev.a, stream));
-        fn();
-        XRL_HIP(hipEventRecord(ev.b, stream));
-        m.pending.push_back(ev);
+    // ---- streams and cross-stream ordering
+    hipStream_t lane_stream[2] = {stream, stream};
+    size_t ev_next = 0;
+    auto next_event = [&]() -> hipEvent_t {
+        if (ev_next == m.events.size()) { hipEvent_t e; XRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m.events.push_back(e); }
+        return m.events[ev_next++];
     };
+    if (lanes == 2) {
+        if (!m.aux_stream) XRL_HIP(hipStreamCreateWithFlags(&m.aux_stream, hipStreamNonBlocking));
+        lane_stream[1] = m.aux_stream;
+        hipEvent_t e = next_event();                                   // the auxiliary lane starts after everything queued so far
+        XRL_HIP(hipEventRecord(e, stream));
+        XRL_HIP(hipStreamWaitEvent(m.aux_stream, e, 0));
+    }
+    hipEvent_t k1_done = nullptr;                                      // the most recent K1 launch (either lane)
 
-    for (uint64_t row0 = 0; row0 < X.rows; row0 += nb) {
+    uint64_t batch = 0;
+    for (uint64_t row0 = 0; row0 < X.rows; row0 += nb, ++batch) {
         const uint32_t nrows = (uint32_t)std::min<uint64_t>(nb, X.rows - row0);
+        const int ln = (int)(batch % (uint64_t)lanes);
+        LaneWs& lw = ws.lane[ln];
+        hipStream_t S = lane_stream[ln];
+        auto timed = [&](const char* name, uint32_t layer, auto&& fn) {
+            if (!m.profiling) { fn(); return; }
+            PendingEvent ev; ev.slot = profile_slot(m, name, layer);
+            XRL_HIP(hipEventCreate(&ev.a)); XRL_HIP(hipEventCreate(&ev.b));
+            XRL_HIP(hipEventRecord(ev.a, S));
+            fn();
+            XRL_HIP(hipEventRecord(ev.b, S));
+            m.pending.push_back(ev);
+        };
         for (size_t l = 0; l < T; ++l) {
             const Layer& L = *m.layers[l];
             LayerPlan P{};
@@ -132,26 +156,33 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 prev.idx += row0 * prev.stride; prev.val += row0 * prev.stride; prev.cnt += row0;
             } else if (l > 0) {
                 const int b = (int)((l - 1) & 1);
-                prev = BeamDev{ws.beam_idx[b].as<uint32_t>(), ws.beam_val[b].as<float>(), ws.beam_cnt[b].as<uint32_t>(), beam_stride};
+                prev = BeamDev{lw.beam_idx[b].as<uint32_t>(), lw.beam_val[b].as<float>(), lw.beam_cnt[b].as<uint32_t>(), beam_stride};
             }
             uint32_t *oi, *oc; float* ov; uint32_t os;
             if (l == T - 1) { oi = d_out_idx + row0 * out_stride; ov = d_out_val + row0 * out_stride; oc = d_out_cnt + row0; os = out_stride; }
-            else { const int b = (int)(l & 1); oi = ws.beam_idx[b].as<uint32_t>(); ov = ws.beam_val[b].as<float>(); oc = ws.beam_cnt[b].as<uint32_t>(); os = beam_stride; }
+            else { const int b = (int)(l & 1); oi = lw.beam_idx[b].as<uint32_t>(); ov = lw.beam_val[b].as<float>(); oc = lw.beam_cnt[b].as<uint32_t>(); os = beam_stride; }
 
             int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
-            timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.items.p, stream); });
+            timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
             const int mode = layer_mode(l, nrows);
             const uint64_t n_slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
-            if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, ws.items.p, ws.items_sorted.p, ws.sort_hist.as<uint32_t>(), ws.sort_start.as<uint32_t>(), stream); });
+            if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
+            if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));   // K1 launches take turns across the lanes
             if (mode == 2)
-                timed("k1t_sparse", (uint32_t)l, [&] { launch_k1t(L.dev, P, X, ws.items_sorted.p, ws.sort_start.as<uint32_t>(), ws.cand.as<float>(), (uint32_t)std::max(64, m.k1t_items_per_block), stream); });
+                timed("k1t_sparse", (uint32_t)l, [&] { launch_k1t(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.cand.as<float>(), (uint32_t)std::max(64, m.k1t_items_per_block), S); });
             else
                 timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] {
-                    launch_k1(L.dev, P, X, mode == 1 ? ws.items_sorted.p : ws.items.p, mode == 1 ? ws.sort_start.as<uint32_t>() + L.n_tiles : nullptr,
-                              ws.cand.as<float>(), g, stream); });
-            timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, ws.cand_off.as<uint32_t>(), ws.ncand.as<uint32_t>(), ws.cand.as<float>(), oi, ov, oc, os, stream); });
-            if (o.stats_out) launch_stats(L.dev, P, prev, ws.ncand.as<uint32_t>(), ws.stats.as<double>() + 2 * l, stream);
+                    launch_k1(L.dev, P, X, mode == 1 ? lw.items_sorted.p : lw.items.p, mode == 1 ? lw.sort_start.as<uint32_t>() + L.n_tiles : nullptr,
+                              lw.cand.as<float>(), g, S); });
+            if (lanes == 2) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
+            timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S); });
+            if (o.stats_out) launch_stats(L.dev, P, prev, lw.ncand.as<uint32_t>(), ws.stats.as<double>() + 2 * l, S);
         }
+    }
+    if (lanes == 2) {                                                   // the caller's stream continues after the auxiliary lane
+        hipEvent_t e = next_event();
+        XRL_HIP(hipEventRecord(e, m.aux_stream));
+        XRL_HIP(hipStreamWaitEvent(stream, e, 0));
     }
 
     if (o.stats_out) {

@@ -89,6 +89,9 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         # tile-stationary kernel: off / forced for every layer whose tiles fit in LDS, short and long item runs
         clib.set_option(m.model.model_chain, "k1t_min_items", int(rng.choice([0, 1, 1])))
         clib.set_option(m.model.model_chain, "k1t_items_per_block", int(rng.choice([64, 128, 1024])))
+        # one or two row batches in flight (two streams), whole or ragged batches
+        clib.set_option(m.model.model_chain, "overlap_min_rows", int(rng.choice([0, 2])))
+        clib.set_option(m.model.model_chain, "max_batch_rows", int(rng.choice([0, 0, 7, 32])))
         for Xq in (X, np.ascontiguousarray(X.toarray())):
             a = m.predict(Xq, **kw)
             b = om.predict(Xq, **kw)
@@ -96,5 +99,6 @@ def test_fuzz(seed, tmp_path, oracle_mod):
             assert_same_topk(a, b, exact_scores=True, what=f"seed={seed} sizes={sizes} D={D} bias={bias} {kw} dense={not smat.issparse(Xq)}")
     clib.set_option(m.model.model_chain, "k1_group", 0)
     clib.set_option(m.model.model_chain, "k1t_min_items", 1)
+    clib.set_option(m.model.model_chain, "max_batch_rows", 0)
     # model defaults (per-layer only_topk / post-processor from param.json)
     assert_same_topk(m.predict(X), om.predict(X), exact_scores=True, what=f"seed={seed} defaults")

@@ -99,6 +99,14 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} {pp}")
     # model defaults (no overrides), max_pred_chunk slicing, dense queries
     assert_same_topk(m.predict(X), ref.predict(X), exact_scores=True, what="defaults")
+    # two row batches in flight on two streams (default only for large X): same results, also with a ragged tail batch
+    for rows in (2, 150):
+        clib.set_option(m.model.model_chain, "overlap_min_rows", 2)
+        clib.set_option(m.model.model_chain, "max_batch_rows", rows if rows > 2 else 0)
+        assert_same_topk(m.predict(X, beam_size=cfg["beam"], only_topk=10), ref.predict(X, beam_size=cfg["beam"], only_topk=10),
+                         exact_scores=True, what=f"{name} two lanes, max_batch_rows={rows}")
+    clib.set_option(m.model.model_chain, "max_batch_rows", 0)
+    clib.set_option(m.model.model_chain, "overlap_min_rows", 16384)
     for k1t in (0, 1):   # K1 everywhere / tile-stationary K1T wherever a tile image fits in LDS
         clib.set_option(m.model.model_chain, "k1t_min_items", k1t)
         assert_same_topk(m.predict(X, beam_size=cfg["beam"], only_topk=10), ref.predict(X, beam_size=cfg["beam"], only_topk=10),
