@@ -338,6 +338,12 @@ uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
             const Layer& last = *m.layers.back();
             v = last.reordered ? last.c_rows : last.w_cols;
         }
+        else if (!std::strcmp(attr, "nr_bucket_layers")) {   // additive: layers using the bucket row lookup instead of rank-bitmaps
+            for (auto& l : m.layers) v += l->dev.bucket ? 1u : 0u;
+        }
+        else if (!std::strcmp(attr, "nr_k1t_layers")) {      // additive: layers that carry K1T tile images
+            for (auto& l : m.layers) v += l->dev.img ? 1u : 0u;
+        }
         else fail(std::string(attr) + " is not implemented in get_int_attr.");
     });
     return v;

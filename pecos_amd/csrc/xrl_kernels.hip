@@ -334,7 +334,7 @@ template <int G, int NS> struct K1Cfg {
 #ifndef XRL_K1_WPE
 #define XRL_K1_WPE 5
 #endif
-template <int G, int NS, int PPC, bool DENSE>
+template <int G, int NS, int PPC, bool DENSE, bool BUCKET>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1_WPE, 8))) k1_kernel(K1Args a) {
     constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, UH = K1Cfg<G, NS>::UH, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U,
                   NB = K1Cfg<G, NS>::NB, TAIL = K1Cfg<G, NS>::TAIL;
@@ -390,7 +390,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
 
     const uint32_t* __restrict__ xi = a.X.col_idx;
     const float* __restrict__ xv = a.X.val;
-    const BmWord* __restrict__ bm = a.L.bitmap + (uint64_t)(active ? it.tile : 0u) * a.L.nwords;
+    const BmWord* __restrict__ bm = a.L.bitmap + (BUCKET ? 0ull : (uint64_t)(active ? it.tile : 0u) * a.L.nwords);
+    const uint32_t* __restrict__ bkt = BUCKET ? a.L.bucket + (uint64_t)(active ? it.tile : 0u) * (a.L.bk_n + 1u) : nullptr;   // tile-relative row slots
+    const uint32_t* __restrict__ ridx_t = a.L.row_idx + (td.rowptr_base - (active ? it.tile : 0u));                          // the tile's sorted row ids
     const unsigned long long below = (1ull << lig) - 1ull;
     const uint64_t xlast = xe > cur ? xe - 1 : 0;                      // a valid x index for clamped loads
     uint32_t nh = 0;                                                   // hits waiting in this item's queue
@@ -509,7 +511,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
         bool overflow = false;
         {
             // ---- load step: U*G consecutive features of the item
-            uint32_t f[U]; float v[U]; BmWord w[U];
+            uint32_t f[U]; float v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const uint64_t t = cur + (uint64_t)(u * G + lig);
@@ -517,14 +519,44 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
                 const uint64_t tc = ok ? t : xlast;          // clamped: the load itself is unconditional
                 const uint32_t fi = xi[tc];
                 const float vi = xv[tc];
-                f[u] = ok ? fi : 0xFFFFFFFFu;
+                f[u] = (ok && fi < a.L.w_rows) ? fi : 0xFFFFFFFFu;
                 v[u] = vi;
             }
+            // ---- row lookup: is feature f a row of the tile, and which slot
+            bool hit[U]; uint32_t slot[U];
+            if (!BUCKET) {
+                // rank-bitmap: one 8-byte load per probe
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool inr = f[u] < a.L.w_rows && !(a.ablate & 1);
-                const BmWord wi = bm[inr ? (f[u] >> 5) : 0u];
-                w[u].bits = inr ? wi.bits : 0u; w[u].rank = wi.rank;
+                for (int u = 0; u < U; ++u) {
+                    const bool inr = f[u] != 0xFFFFFFFFu && !(a.ablate & 1);
+                    const BmWord wi = bm[inr ? (f[u] >> 5) : 0u];
+                    const uint32_t b = f[u] & 31u;
+                    hit[u] = inr && ((wi.bits >> b) & 1u);
+                    slot[u] = wi.rank + (uint32_t)__popc(wi.bits & ((1u << b) - 1u));
+                }
+            } else {
+                // layers whose bitmaps would not fit in HBM: bucket table over feature-id ranges (one 8-byte load), then
+                // `bk_levels` branch-free binary-search steps over the tile's sorted row ids (the reference's lookup is a
+                // binary search too, inference.hpp:786-803) and one load to confirm the match
+                uint32_t hi[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool inr = f[u] != 0xFFFFFFFFu;
+                    const RowExt be = *reinterpret_cast<const RowExt*>(bkt + (inr ? (f[u] >> a.L.bk_shift) : 0u));
+                    slot[u] = be.start; hi[u] = inr ? be.end : be.start;
+                }
+                for (uint32_t lv = a.L.bk_levels; lv > 0; --lv) {
+                    const uint32_t stp = 1u << (lv - 1);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const uint32_t np = slot[u] + stp;
+                        const bool in = np < hi[u];
+                        const uint32_t r = ridx_t[in ? np : slot[u]];
+                        slot[u] = (in && r <= f[u]) ? np : slot[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) hit[u] = slot[u] < hi[u] && ridx_t[slot[u]] == f[u];
             }
             // ---- queue the hits in feature order.  If an item's queue fills up the step is abandoned at
             //      slice `skip`, the queue is drained (outside this scope, so the step's registers are
@@ -533,15 +565,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
             bool stopped = false;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const uint32_t b = f[u] & 31u;
-                const bool hit = (f[u] < a.L.w_rows) && ((w[u].bits >> b) & 1u);
-                const unsigned long long m = __ballot(hit);
+                const unsigned long long m = __ballot(hit[u]);
                 const unsigned long long gm = (G == 64) ? m : ((m >> (grp * G)) & ((1ull << G) - 1ull));
                 const uint32_t cnt = (uint32_t)__popcll(gm);
                 if ((uint32_t)u >= done && !stopped) {
                     if (nh + cnt <= (uint32_t)H) {
-                        if (hit) my_hq[nh + (uint32_t)__popcll(gm & below)] =
-                                     make_uint2(__float_as_uint(v[u]), w[u].rank + __popc(w[u].bits & ((1u << b) - 1u)));
+                        if (hit[u]) my_hq[nh + (uint32_t)__popcll(gm & below)] = make_uint2(__float_as_uint(v[u]), slot[u]);
                         nh += cnt; done = u + 1;
                     } else {
                         stopped = true;
@@ -626,8 +655,9 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     const int ppc = pp_class(P.pp);
 #define XRL_K1(GG, NN) do { \
         const size_t lds = K1Cfg<GG, NN>::lds_bytes(a.acc_stride); \
-        if (X.dense) { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, true>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, true>, a, 64 / GG, lds, s); } \
-        else { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, false>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, false>, a, 64 / GG, lds, s); } } while (0)
+        if (X.dense) { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, true, false>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, true, false>, a, 64 / GG, lds, s); } \
+        else if (L.bucket) { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, false, true>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, false, true>, a, 64 / GG, lds, s); } \
+        else { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, false, false>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, false, false>, a, 64 / GG, lds, s); } } while (0)
     // a tile row must fit NS units of `group` lanes; widen a (forced) group that is too narrow
     if (group < 1 || group > 64 || (group & (group - 1))) fail("k1: lanes-per-item must be a power of two in [1, 64]");
     auto max_ns = [](int g) { return g < 8 ? 1u : (g == 32 ? 4u : 2u); };

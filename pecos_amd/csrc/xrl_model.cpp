@@ -187,11 +187,22 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     for (uint32_t t = 0; t < T; ++t) { tiles[t].ent_base = nnz; nnz += tile_nnz[t]; }
     L->nnz = nnz;
 
-    const uint64_t bm_words = (uint64_t)T * L->nwords;
-    {   // the rank-bitmap costs rows/4 bytes per tile; refuse layouts that cannot fit the device
+    // ---- row lookup structure.  The rank-bitmap costs rows/4 bytes per tile (one load per probe); when that would
+    //      take more than a quarter of the device's free HBM (many tiles x many features, e.g. 32768 leaf tiles over
+    //      337k features = 2.8 TB) the layer uses a bucket table + binary search over the tile's row ids instead
+    //      (O(rows of the tile) memory).  XRL_LOOKUP=bitmap|bucket forces one (tests).
+    uint64_t bm_words = (uint64_t)T * L->nwords;
+    bool use_bucket = false;
+    {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bm_words * 8 + nnz * 8 > (uint64_t)(free_b * 0.9))
-            fail("layer: rank-bitmap layout needs " + std::to_string((bm_words * 8 + nnz * 8) >> 20) + " MiB (" + std::to_string(T) +
+        const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+        const char* lk = std::getenv("XRL_LOOKUP");
+        if (lk && !std::strcmp(lk, "bucket")) use_bucket = true;
+        else if (lk && !std::strcmp(lk, "bitmap")) use_bucket = false;
+        else use_bucket = have ? bm_words * 8 > (uint64_t)(free_b / 4) : bm_words * 8 > (48ull << 30);
+        if (use_bucket) bm_words = 0;
+        if (have && bm_words * 8 + nnz * 8 > (uint64_t)(free_b * 0.9))
+            fail("layer: the device layout needs " + std::to_string((bm_words * 8 + nnz * 8) >> 20) + " MiB (" + std::to_string(T) +
                  " tiles x " + std::to_string(W.rows) + " features) but only " + std::to_string(free_b >> 20) + " MiB of HBM are free");
     }
     std::vector<Entry> entries(nnz);
@@ -213,20 +224,20 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         // rows ascending; inside a row the column order (ascending) is kept: stable
         std::stable_sort(nz.begin(), nz.end(), [](const Nz& a, const Nz& b) { return a.row < b.row; });
         auto& rows = t_rows[t]; auto& rptr = t_rptr[t];
-        BmWord* bm = bitmap.data() + t * (uint64_t)L->nwords;
+        BmWord* bm = use_bucket ? nullptr : bitmap.data() + t * (uint64_t)L->nwords;
         Entry* ent = entries.data() + td.ent_base;
         for (size_t i = 0; i < nz.size(); ++i) {
             if (i == 0 || nz[i].row != nz[i - 1].row) {
                 rows.push_back(nz[i].row);
                 rptr.push_back((uint32_t)i);
-                bm[nz[i].row >> 5].bits |= 1u << (nz[i].row & 31);
+                if (bm) bm[nz[i].row >> 5].bits |= 1u << (nz[i].row & 31);
             }
             ent[i] = Entry{nz[i].col, nz[i].val};
         }
         rptr.push_back((uint32_t)nz.size());
         td.nrows = (uint32_t)rows.size();
         uint32_t run = 0;
-        for (uint32_t w = 0; w < L->nwords; ++w) { bm[w].rank = run; run += (uint32_t)__builtin_popcount(bm[w].bits); }
+        if (bm) for (uint32_t w = 0; w < L->nwords; ++w) { bm[w].rank = run; run += (uint32_t)__builtin_popcount(bm[w].bits); }
         // check_bias_explicit, inference.hpp:500-502: last row of the chunk is W's last row
         td.bias_slot = (has_bias && td.nrows > 0 && rows.back() == W.rows - 1) ? td.nrows - 1 : kNoBias;
     });
@@ -239,6 +250,38 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         std::memcpy(row_ptr.data() + tiles[t].rowptr_base, t_rptr[t].data(), t_rptr[t].size() * 4);
         if (!t_rows[t].empty()) std::memcpy(row_idx.data() + (tiles[t].rowptr_base - t), t_rows[t].data(), t_rows[t].size() * 4);
     });
+
+    // ---- bucket lookup (see above): per tile, first row slot of every feature-id range of 2^bk_shift ids
+    std::vector<uint32_t> bucket;
+    if (use_bucket) {
+        uint32_t max_rows = 1;
+        for (uint32_t t = 0; t < T; ++t) max_rows = std::max(max_rows, tiles[t].nrows);
+        uint32_t want = 16;                                        // ~4 rows per bucket on the fullest tile
+        while (want < 4096 && want * 4 < max_rows) want <<= 1;
+        uint32_t shift = 0;
+        while ((((uint64_t)W.rows - 1) >> shift) + 1 > want) ++shift;
+        const uint32_t NBK = W.rows ? (uint32_t)((((uint64_t)W.rows - 1) >> shift) + 1) : 1;
+        bucket.assign((size_t)T * (NBK + 1) + 1, 0u);             // + one readable element past the end
+        std::vector<uint32_t> tile_maxlen(T, 0);
+        parallel_for(T, [&](size_t t) {
+            const std::vector<uint32_t>& rows = t_rows[t];
+            uint32_t* bk = bucket.data() + t * (size_t)(NBK + 1);
+            const uint32_t R = (uint32_t)rows.size();
+            uint32_t r0 = 0, mx = 0;
+            for (uint32_t k = 0; k < NBK; ++k) {
+                while (r0 < R && (rows[r0] >> shift) < k) ++r0;
+                bk[k] = r0;
+                if (k > 0) mx = std::max(mx, bk[k] - bk[k - 1]);
+            }
+            bk[NBK] = R;
+            tile_maxlen[t] = std::max(mx, R - bk[NBK - 1]);
+        });
+        uint32_t maxlen = 1;
+        for (uint32_t t = 0; t < T; ++t) maxlen = std::max(maxlen, tile_maxlen[t]);
+        uint32_t levels = 0;
+        while ((1u << levels) < maxlen) ++levels;                  // steps of 2^(levels-1) .. 1 cover the longest bucket
+        L->bk_shift = shift; L->bk_n = NBK; L->bk_levels = levels;
+    }
 
     // ---- tile images for the tile-stationary kernel K1T: one self-contained blob per tile, copied verbatim into
     //      LDS.  The row lookup is a bucket table over feature-id ranges followed by a few binary-search steps.
@@ -327,7 +370,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     row_ptr.push_back(0u); row_ptr.push_back(0u); entries.resize(entries.size() + 64, Entry{0u, 0.0f}); row_idx.push_back(0u);
     L->d_bias_prod.upload(bias_prod);
     L->d_tiles.upload(tiles); L->d_ptile.upload(ptile); L->d_chunk_col.upload(chunk_col);
-    L->d_bitmap.upload(bitmap); L->d_row_ptr.upload(row_ptr); L->d_row_idx.upload(row_idx);
+    if (!use_bucket) L->d_bitmap.upload(bitmap); else L->d_bucket.upload(bucket);
+    L->d_row_ptr.upload(row_ptr); L->d_row_idx.upload(row_idx);
     L->d_entries.upload(entries); L->d_chunk_alg.upload(chunk_alg);
     if (!contiguous) {
         std::vector<uint32_t> perm_inv(C.row_idx.begin(), C.row_idx.begin() + c_nnz);
@@ -345,11 +389,13 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
                       L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap +
-                      L->d_img.cap + L->d_img_off.cap;
+                      L->d_img.cap + L->d_img_off.cap + L->d_bucket.cap;
 
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
-    d.bitmap = L->d_bitmap.as<BmWord>(); d.row_ptr = L->d_row_ptr.as<uint32_t>(); d.row_idx = L->d_row_idx.as<uint32_t>();
+    d.bitmap = use_bucket ? nullptr : L->d_bitmap.as<BmWord>();
+    d.bucket = use_bucket ? L->d_bucket.as<uint32_t>() : nullptr; d.bk_shift = L->bk_shift; d.bk_n = L->bk_n; d.bk_levels = L->bk_levels;
+    d.row_ptr = L->d_row_ptr.as<uint32_t>(); d.row_idx = L->d_row_idx.as<uint32_t>();
     d.entries = L->d_entries.as<Entry>(); d.perm_inv = (contiguous && !perm_inv_override) ? nullptr : L->d_perm_inv.as<uint32_t>();
     d.chunk_alg_bytes = L->d_chunk_alg.as<float>();
     d.bias_prod = L->d_bias_prod.as<float>();

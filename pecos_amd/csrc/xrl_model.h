@@ -50,7 +50,9 @@ struct LayerDev {
     const TileDesc* tiles;
     const uint32_t* ptile;       // [n_parents+1] tiles of parent p = [ptile[p], ptile[p+1])
     const uint32_t* chunk_col;   // [n_parents+1] child-column range of parent p (rearranged space)
-    const BmWord* bitmap;        // [n_tiles * nwords]
+    const BmWord* bitmap;        // [n_tiles * nwords], or nullptr when the layer uses the bucket lookup
+    const uint32_t* bucket;      // [n_tiles * (bk_n+1)] first row slot of every feature-id bucket (bitmap too large for HBM), else nullptr
+    uint32_t bk_shift, bk_n, bk_levels;   // bucket = feature >> bk_shift; binary-search steps that cover the longest bucket
     const uint32_t* row_ptr;     // [sum(nrows) + n_tiles], tile-relative entry offsets
     const uint32_t* row_idx;     // [sum(nrows)] feature id of every tile row (dense-query path)
     const Entry* entries;        // [nnz]
@@ -88,7 +90,8 @@ struct Layer {
     DevBuf d_csc_ptr, d_csc_idx, d_csc_val; bool csc_ready = false;
     // device storage
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
-    DevBuf d_img, d_img_off;
+    DevBuf d_img, d_img_off, d_bucket;
+    uint32_t bk_shift = 0, bk_n = 0, bk_levels = 0;
     LayerDev dev{};
     uint64_t device_bytes = 0;
     // sum of the `beam` largest chunks: upper bound on candidates per query entering this layer
@@ -128,8 +131,8 @@ struct Model {
     // options
     int k1_group = 0;                       // 0 = auto
     int64_t max_batch_rows = 0;             // 0 = auto
-    int overlap_min_rows = 16384;           // split a predict of at least this many rows into two half batches on two streams so that one
-                                            // half's K0/K2 (VALU-heavy) run under the other half's K1 (memory-bound); 0 = never
+    int overlap_min_rows = 0;               // split a predict of at least this many rows into two half batches on two streams so that one half's
+                                            // K0/K2 run under the other half's K1; 0 = never (measured on Amazon-670K: 25.9 vs 25.5 ms, no gain)
     int k1t_min_items = 0;                  // run a layer tile-stationary (K1T) once a tile serves at least this many items on average (0 = never)
     int k1t_items_per_block = 1024;
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)

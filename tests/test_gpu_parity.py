@@ -106,7 +106,7 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         assert_same_topk(m.predict(X, beam_size=cfg["beam"], only_topk=10), ref.predict(X, beam_size=cfg["beam"], only_topk=10),
                          exact_scores=True, what=f"{name} two lanes, max_batch_rows={rows}")
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)
-    clib.set_option(m.model.model_chain, "overlap_min_rows", 16384)
+    clib.set_option(m.model.model_chain, "overlap_min_rows", 0)
     for k1t in (0, 1):   # K1 everywhere / tile-stationary K1T wherever a tile image fits in LDS
         clib.set_option(m.model.model_chain, "k1t_min_items", k1t)
         assert_same_topk(m.predict(X, beam_size=cfg["beam"], only_topk=10), ref.predict(X, beam_size=cfg["beam"], only_topk=10),
@@ -122,6 +122,17 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
     clib.set_option(m.model.model_chain, "k1t_min_items", 0)
     assert_same_topk(m.predict(X, beam_size=5, only_topk=3, max_pred_chunk=37), ref.predict(X, beam_size=5, only_topk=3),
                      exact_scores=True, what="max_pred_chunk")
+    # the same model with the bucket row lookup (what layers too large for rank-bitmaps use)
+    os.environ["XRL_LOOKUP"] = "bucket"
+    try:
+        mb = XLM.load(folder)
+    finally:
+        os.environ.pop("XRL_LOOKUP", None)
+    assert clib.xlinear_get_int_attr(mb.model.model_chain, "nr_bucket_layers") == len(ks)
+    for pp in (None, "sigmoid"):
+        kw = dict(beam_size=cfg["beam"], only_topk=10, **({"post_processor": pp} if pp else {}))
+        assert_same_topk(mb.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} bucket lookup {pp}")
+    del mb
     if X.shape[1] <= 6000:
         Xd = np.ascontiguousarray(X[:64].toarray())
         assert_same_topk(m.predict(Xd, beam_size=4, only_topk=6), ref.predict(Xd, beam_size=4, only_topk=6),
