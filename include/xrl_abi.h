@@ -82,7 +82,9 @@ void c_xlinear_compile_mmap_model(const char* model_path, const char* mmap_model
 /* libpecos.cpp:140-143 */
 void c_xlinear_destruct_model(void* ptr);
 
-/* libpecos.cpp:147-150; attr in {depth, nr_features, nr_labels, nr_codes} (inference.hpp:2367-2379) */
+/* libpecos.cpp:147-150; attr in {depth, nr_features, nr_labels, nr_codes} (inference.hpp:2367-2379).
+ * Additive attrs: nr_pred_cols (columns of predict()'s CSR), nr_bucket_layers (layers on the bucket row lookup),
+ * nr_k1t_layers (layers carrying K1T tile images). */
 uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr);
 
 /* libpecos.cpp:152-156 */
@@ -212,7 +214,18 @@ uint32_t xrl_profile_get(void* model, xrl_profile_rec_t* out, uint32_t cap);
 int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char* post_processor,
                       uint32_t only_topk, double* stats_out, uint32_t stats_cap);
 
-/* Tuning knobs (benchmark / tests only): key in {"k1_group", "max_batch_rows", "sort_min_tiles"} */
+/* Tuning knobs (benchmark / tests only).  Results never depend on them.
+ *   "k1_group"            lanes per (query, tile) item in K1: 0 = auto, else a power of two <= 64
+ *   "max_batch_rows"      rows of X per internal batch (0 = auto: candidate buffer <= 6 GiB)
+ *   "sort_min_tiles"      tile-sort the items of layers with at least this many tiles (0 = never)
+ *   "k1t_min_items"       run a layer with the tile-stationary kernel K1T once a tile serves this many items on
+ *                         average (0 = never); needs the tile images, i.e. XRL_K1T=1 in the environment at load
+ *   "k1t_items_per_block" items per K1T workgroup run
+ *   "overlap_min_rows"    split predicts of at least this many rows into two batches on two streams (0 = never)
+ *   "k1_wpb", "k1_lds_pad", "k1_ablate"   debug: wavefronts per K1 workgroup, extra LDS per wavefront, phase ablation
+ * Environment read at model load: XRL_K1T=1 (build K1T tile images), XRL_LOOKUP=bitmap|bucket (force the row lookup
+ * structure; default: rank-bitmaps unless they would take more than a quarter of the free HBM),
+ * XRL_MAX_TILE_ENTRIES (lower the tile splitter's limit; tests). */
 int xrl_set_option(void* model, const char* key, int64_t value);
 
 /* Debug: with option k1_ablate bit 6 set, K1 accumulates per-phase shader cycles

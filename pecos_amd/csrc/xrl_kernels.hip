@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
         td = a.L.tiles[it.tile];
         cur = it.x_begin; xe = it.x_begin + it.x_len;   // CSR queries; unused for dense ones
     }
-    const uint32_t* __restrict__ rp = a.L.row_ptr + td.rowptr_base;
+    const uint32_t* __restrict__ rp = a.L.row_ext + td.rowptr_base;
     const Entry* __restrict__ ent = a.L.entries + td.ent_base;
     float* __restrict__ my_acc = acc + (size_t)grp * acc_item;
     uint2* __restrict__ my_hq = hq + (size_t)grp * H;
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
     const float* __restrict__ xv = a.X.val;
     const BmWord* __restrict__ bm = a.L.bitmap + (BUCKET ? 0ull : (uint64_t)(active ? it.tile : 0u) * a.L.nwords);
     const uint32_t* __restrict__ bkt = BUCKET ? a.L.bucket + (uint64_t)(active ? it.tile : 0u) * (a.L.bk_n + 1u) : nullptr;   // tile-relative row slots
-    const uint32_t* __restrict__ ridx_t = a.L.row_idx + (td.rowptr_base - (active ? it.tile : 0u));                          // the tile's sorted row ids
+    const uint32_t* __restrict__ ridx_t = a.L.row_idx + td.rowptr_base;                          // the tile's sorted row ids
     const unsigned long long below = (1ull << lig) - 1ull;
     const uint64_t xlast = xe > cur ? xe - 1 : 0;                      // a valid x index for clamped loads
     uint32_t nh = 0;                                                   // hits waiting in this item's queue
@@ -410,11 +410,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
             const bool ok = h < nh;
             const uint2 hv = my_hq[ok ? h : 0u];
             const uint32_t s = ok ? hv.y : 0u;
-            // row extent {start, end}: ONE 8-byte load at a 4-byte aligned address (the two words share a cache
-            // line all but 1/32 of the time; as two loads they cost the L1 two line look-ups per lane)
-            const RowExt rx = *reinterpret_cast<const RowExt*>(rp + s);        // unconditional (slot 0 when idle)
-            const uint32_t rs = rx.start, re = rx.end;
-            const uint32_t len = ok ? re - rs : 0u;
+            const uint32_t rx = rp[s];                                 // unconditional (slot 0 when idle): packed {offset, length - 1}
+            const uint32_t rs = rx & 0x1FFFFFFu;
+            const uint32_t len = ok ? (rx >> 25) + 1u : 0u;
             uint32_t cnt = (NS == 1) ? (len ? 1u : 0u) : min((len + G - 1) / G, (uint32_t)NS);
             uint32_t incl = cnt;
             if (G > 1) {
@@ -489,7 +487,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
         // chunk_ops<drm, bin_search>, inference.hpp:815-839: EVERY tile row (except the bias row, which is
         // the last one) is a hit with x value x[row feature]; rows go through the same unit queue.
         const float* __restrict__ xd = a.X.val + ((uint64_t)a.row0 + it.q) * a.X.cols;
-        const uint32_t* __restrict__ ridx = a.L.row_idx + (td.rowptr_base - (active ? it.tile : 0u));
+        const uint32_t* __restrict__ ridx = a.L.row_idx + td.rowptr_base;
         uint32_t nr = active ? td.nrows : 0u;
         if (active && td.bias_slot != kNoBias) nr -= 1;
         for (uint32_t s0 = 0; __any(s0 < nr); s0 += H) {

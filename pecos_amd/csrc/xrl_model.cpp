@@ -243,12 +243,11 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     });
 
     uint64_t total_rows = 0;
-    for (uint32_t t = 0; t < T; ++t) { tiles[t].rowptr_base = total_rows + t; total_rows += tiles[t].nrows; }
+    for (uint32_t t = 0; t < T; ++t) { tiles[t].rowptr_base = total_rows; total_rows += tiles[t].nrows; }
     L->total_rows = total_rows;
-    std::vector<uint32_t> row_ptr(total_rows + T), row_idx(total_rows);
+    std::vector<uint32_t> row_idx(total_rows);
     parallel_for(T, [&](size_t t) {
-        std::memcpy(row_ptr.data() + tiles[t].rowptr_base, t_rptr[t].data(), t_rptr[t].size() * 4);
-        if (!t_rows[t].empty()) std::memcpy(row_idx.data() + (tiles[t].rowptr_base - t), t_rows[t].data(), t_rows[t].size() * 4);
+        if (!t_rows[t].empty()) std::memcpy(row_idx.data() + tiles[t].rowptr_base, t_rows[t].data(), t_rows[t].size() * 4);
     });
 
     // ---- bucket lookup (see above): per tile, first row slot of every feature-id range of 2^bk_shift ids
@@ -365,13 +364,52 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         }
         L->d_img.upload(img); L->d_img_off.upload(img_off);
     }
-    // kernels issue unconditional loads (index-clamped, or a full wavefront past a row's start): keep
-    // readable elements past the end
-    row_ptr.push_back(0u); row_ptr.push_back(0u); entries.resize(entries.size() + 64, Entry{0u, 0.0f}); row_idx.push_back(0u);
+    // ---- device layout of rows: {start, length} per row, and the entries re-laid so that NO ROW TOUCHES MORE
+    //      128-BYTE LINES THAN ITS LENGTH REQUIRES (a row that would straddle an extra line starts at the next
+    //      16-entry boundary).  K1 is bound by the number of cache lines its 8-byte gathers request from the L2;
+    //      unaligned, a 27-entry row costs 2.7 lines on average instead of 2.  XRL_ROW_ALIGN=0 keeps rows packed.
+    std::vector<uint32_t> row_ext(total_rows + 2, 0u);
+    {
+        const char* ra = std::getenv("XRL_ROW_ALIGN");
+        bool align = !(ra && ra[0] == '0');
+        auto lay_out = [&](size_t t, uint32_t* ext) -> uint64_t {   // returns the tile's padded entry count (multiple of 16)
+            const uint32_t* trp = t_rptr[t].data();
+            uint64_t cur = 0;
+            for (uint32_t r = 0; r < tiles[t].nrows; ++r) {
+                const uint32_t len = trp[r + 1] - trp[r];
+                if (align && ((cur & 15) + len + 15) / 16 > ((uint64_t)len + 15) / 16) cur = (cur + 15) & ~15ull;
+                if (len == 0 || len > kMaxTileCols) fail("layer: internal error, tile row length");
+                if (ext) ext[r] = pack_row_extent((uint32_t)(cur & 0x1FFFFFFu), len);
+                cur += len;
+            }
+            return (cur + 15) & ~15ull;
+        };
+        std::vector<uint64_t> dev_base((size_t)T + 1, 0);
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<uint64_t> padded(T, 0);
+            parallel_for(T, [&](size_t t) { padded[t] = lay_out(t, nullptr); });
+            bool fits = true;
+            for (uint32_t t = 0; t < T; ++t) { dev_base[t + 1] = dev_base[t] + padded[t]; fits = fits && padded[t] < (1ull << 25); }
+            if (fits || !align) break;
+            align = false;                                         // a tile would leave the 25-bit offset range: keep this layer packed
+        }
+        std::vector<Entry> dev_entries(dev_base[T] + 64, Entry{0u, 0.0f});   // + readable elements past the end (unconditional loads)
+        parallel_for(T, [&](size_t t) {
+            uint32_t* ext = row_ext.data() + tiles[t].rowptr_base;
+            lay_out(t, ext);
+            const Entry* src = entries.data() + tiles[t].ent_base;
+            Entry* dst = dev_entries.data() + dev_base[t];
+            const uint32_t* trp = t_rptr[t].data();
+            for (uint32_t r = 0; r < tiles[t].nrows; ++r) std::memcpy(dst + (ext[r] & 0x1FFFFFFu), src + trp[r], (size_t)((ext[r] >> 25) + 1u) * sizeof(Entry));
+        });
+        for (uint32_t t = 0; t < T; ++t) tiles[t].ent_base = dev_base[t];
+        entries.swap(dev_entries);
+    }
+    row_idx.push_back(0u);
     L->d_bias_prod.upload(bias_prod);
     L->d_tiles.upload(tiles); L->d_ptile.upload(ptile); L->d_chunk_col.upload(chunk_col);
     if (!use_bucket) L->d_bitmap.upload(bitmap); else L->d_bucket.upload(bucket);
-    L->d_row_ptr.upload(row_ptr); L->d_row_idx.upload(row_idx);
+    L->d_row_ptr.upload(row_ext); L->d_row_idx.upload(row_idx);
     L->d_entries.upload(entries); L->d_chunk_alg.upload(chunk_alg);
     if (!contiguous) {
         std::vector<uint32_t> perm_inv(C.row_idx.begin(), C.row_idx.begin() + c_nnz);
@@ -395,7 +433,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
     d.bitmap = use_bucket ? nullptr : L->d_bitmap.as<BmWord>();
     d.bucket = use_bucket ? L->d_bucket.as<uint32_t>() : nullptr; d.bk_shift = L->bk_shift; d.bk_n = L->bk_n; d.bk_levels = L->bk_levels;
-    d.row_ptr = L->d_row_ptr.as<uint32_t>(); d.row_idx = L->d_row_idx.as<uint32_t>();
+    d.row_ext = L->d_row_ptr.as<uint32_t>(); d.row_idx = L->d_row_idx.as<uint32_t>();
     d.entries = L->d_entries.as<Entry>(); d.perm_inv = (contiguous && !perm_inv_override) ? nullptr : L->d_perm_inv.as<uint32_t>();
     d.chunk_alg_bytes = L->d_chunk_alg.as<float>();
     d.bias_prod = L->d_bias_prod.as<float>();

@@ -13,7 +13,8 @@
 //     one 8-byte {bits, rank} word per 32 features, i.e. ONE load per probe instead of the
 //     reference's ~log2(R) binary-search steps (:786-803).  It costs rows/4 bytes per tile,
 //     which is what 288 GB of HBM3E is for;
-//   * row_ptr is 32-bit and tile-relative; entries stay {u32 col_offset, f32 val} (8 B).
+//   * rows are {start, length} packed in 32 bits, tile-relative, laid out so that no row touches more 128-byte
+//     lines than its length requires; entries stay {u32 col_offset, f32 val} (8 B).
 #pragma once
 #include <memory>
 #include <mutex>
@@ -38,12 +39,14 @@ struct TileDesc {            // 32 bytes, device
     uint32_t ncols;
     uint32_t nrows;          // distinct non-zero rows R_t
     uint32_t bias_slot;      // row slot holding W's bias row (== rows-1), or kNoBias
-    uint64_t rowptr_base;    // index of this tile's row_ptr[0]; its row_idx[0] is rowptr_base - tile_id
+    uint64_t rowptr_base;    // index of this tile's first row in row_ext[] and row_idx[]
     uint64_t ent_base;       // index of this tile's first entry
 };
 
 struct Entry { uint32_t col; float val; };          // 8 bytes, == chunk_entry_t
 struct BmWord { uint32_t bits; uint32_t rank; };    // 8 bytes per 32 features
+// one tile row in 4 bytes: tile-relative entry offset (25 bits, < max_tile_entries) | (length - 1) << 25 (rows hold 1..128 entries)
+inline uint32_t pack_row_extent(uint32_t start, uint32_t len) { return start | ((len - 1u) << 25); }
 
 // Plain-pointer view handed to kernels (all device pointers).
 struct LayerDev {
@@ -53,7 +56,7 @@ struct LayerDev {
     const BmWord* bitmap;        // [n_tiles * nwords], or nullptr when the layer uses the bucket lookup
     const uint32_t* bucket;      // [n_tiles * (bk_n+1)] first row slot of every feature-id bucket (bitmap too large for HBM), else nullptr
     uint32_t bk_shift, bk_n, bk_levels;   // bucket = feature >> bk_shift; binary-search steps that cover the longest bucket
-    const uint32_t* row_ptr;     // [sum(nrows) + n_tiles], tile-relative entry offsets
+    const uint32_t* row_ext;     // [sum(nrows)] packed {entry offset, length} of every tile row (pack_row_extent)
     const uint32_t* row_idx;     // [sum(nrows)] feature id of every tile row (dense-query path)
     const Entry* entries;        // [nnz]
     const uint32_t* perm_inv;    // [n_children] rearranged -> original child id, or nullptr
