@@ -225,7 +225,8 @@ int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char
  *   "k1_wpb", "k1_lds_pad", "k1_ablate"   debug: wavefronts per K1 workgroup, extra LDS per wavefront, phase ablation
  * Environment read at model load: XRL_K1T=1 (build K1T tile images), XRL_LOOKUP=bitmap|bucket (force the row lookup
  * structure; default: rank-bitmaps unless they would take more than a quarter of the free HBM),
- * XRL_MAX_TILE_ENTRIES (lower the tile splitter's limit; tests). */
+ * XRL_ROW_ALIGN=0 (keep tile rows packed instead of line-aligned), XRL_MAX_TILE_ENTRIES (lower the tile splitter's
+ * limit; tests). */
 int xrl_set_option(void* model, const char* key, int64_t value);
 
 /* Debug: with option k1_ablate bit 6 set, K1 accumulates per-phase shader cycles
