@@ -83,7 +83,7 @@ void c_xlinear_compile_mmap_model(const char* model_path, const char* mmap_model
 void c_xlinear_destruct_model(void* ptr);
 
 /* libpecos.cpp:147-150; attr in {depth, nr_features, nr_labels, nr_codes} (inference.hpp:2367-2379).
- * Additive attrs: nr_pred_cols (columns of predict()'s CSR), nr_bucket_layers (layers on the bucket row lookup),
+ * Additive attrs: nr_pred_cols (columns of predict()'s CSR), nr_bucket_layers / nr_bitmap64_layers (layers on the bucket / 64-feature-word row lookup),
  * nr_k1t_layers (layers carrying K1T tile images). */
 uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr);
 
@@ -223,8 +223,9 @@ int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char
  *   "k1t_items_per_block" items per K1T workgroup run
  *   "overlap_min_rows"    split predicts of at least this many rows into two batches on two streams (0 = never)
  *   "k1_wpb", "k1_lds_pad", "k1_ablate"   debug: wavefronts per K1 workgroup, extra LDS per wavefront, phase ablation
- * Environment read at model load: XRL_K1T=1 (build K1T tile images), XRL_LOOKUP=bitmap|bucket (force the row lookup
- * structure; default: rank-bitmaps unless they would take more than a quarter of the free HBM),
+ * Environment read at model load: XRL_K1T=1 (build K1T tile images), XRL_LOOKUP=bitmap|bitmap64|bucket (force the row
+ * lookup structure; default per layer: bucket table if rank-bitmaps would take more than a quarter of the free HBM, else
+ * 64-feature words carrying the first row's extent on sparse tiles, else 32-feature words),
  * XRL_ROW_ALIGN=0 (keep tile rows packed instead of line-aligned), XRL_MAX_TILE_ENTRIES (lower the tile splitter's
  * limit; tests). */
 int xrl_set_option(void* model, const char* key, int64_t value);

@@ -341,6 +341,9 @@ uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
         else if (!std::strcmp(attr, "nr_bucket_layers")) {   // additive: layers using the bucket row lookup instead of rank-bitmaps
             for (auto& l : m.layers) v += l->dev.bucket ? 1u : 0u;
         }
+        else if (!std::strcmp(attr, "nr_bitmap64_layers")) {  // additive: layers using 64-feature bitmap words that carry the first row's extent
+            for (auto& l : m.layers) v += l->dev.bitmap64 ? 1u : 0u;
+        }
         else if (!std::strcmp(attr, "nr_k1t_layers")) {      // additive: layers that carry K1T tile images
             for (auto& l : m.layers) v += l->dev.img ? 1u : 0u;
         }

@@ -334,7 +334,9 @@ template <int G, int NS> struct K1Cfg {
 #ifndef XRL_K1_WPE
 #define XRL_K1_WPE 5
 #endif
-template <int G, int NS, int PPC, bool DENSE, bool BUCKET>
+// LK = row lookup: 0 rank-bitmap {bits32, rank} (8 B / 32 features), 1 bucket table + binary search,
+//      2 rank-bitmap {bits64, rank, extent of the word's first row} (16 B / 64 features; sparse tiles)
+template <int G, int NS, int PPC, bool DENSE, int LK>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1_WPE, 8))) k1_kernel(K1Args a) {
     constexpr int W = K1Cfg<G, NS>::W, H = K1Cfg<G, NS>::H, UH = K1Cfg<G, NS>::UH, P = K1Cfg<G, NS>::P, U = K1Cfg<G, NS>::U,
                   NB = K1Cfg<G, NS>::NB, TAIL = K1Cfg<G, NS>::TAIL;
@@ -390,8 +392,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
 
     const uint32_t* __restrict__ xi = a.X.col_idx;
     const float* __restrict__ xv = a.X.val;
-    const BmWord* __restrict__ bm = a.L.bitmap + (BUCKET ? 0ull : (uint64_t)(active ? it.tile : 0u) * a.L.nwords);
-    const uint32_t* __restrict__ bkt = BUCKET ? a.L.bucket + (uint64_t)(active ? it.tile : 0u) * (a.L.bk_n + 1u) : nullptr;   // tile-relative row slots
+    const BmWord* __restrict__ bm = a.L.bitmap + (LK != 0 ? 0ull : (uint64_t)(active ? it.tile : 0u) * a.L.nwords);
+    const BmWord64* __restrict__ bm64 = a.L.bitmap64 + (LK != 2 ? 0ull : (uint64_t)(active ? it.tile : 0u) * a.L.nwords64);
+    const uint32_t* __restrict__ bkt = LK == 1 ? a.L.bucket + (uint64_t)(active ? it.tile : 0u) * (a.L.bk_n + 1u) : nullptr;   // tile-relative row slots
     const uint32_t* __restrict__ ridx_t = a.L.row_idx + td.rowptr_base;                          // the tile's sorted row ids
     const unsigned long long below = (1ull << lig) - 1ull;
     const uint64_t xlast = xe > cur ? xe - 1 : 0;                      // a valid x index for clamped loads
@@ -409,8 +412,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
             const uint32_t h = h0 + lig;
             const bool ok = h < nh;
             const uint2 hv = my_hq[ok ? h : 0u];
-            const uint32_t s = ok ? hv.y : 0u;
-            const uint32_t rx = rp[s];                                 // unconditional (slot 0 when idle): packed {offset, length - 1}
+            // queue value: the row slot -- or, with 64-feature bitmap words, the packed extent itself unless its length
+            // field reads 0x7F, which marks "slot in the low bits" (kRowLookup; extents of 128-entry rows take that route)
+            const bool need = ok && (LK != 2 || DENSE || (hv.y >> 25) == 0x7Fu);
+            const uint32_t s = need ? ((LK == 2 && !DENSE) ? (hv.y & 0x1FFFFFFu) : hv.y) : 0u;
+            const uint32_t rl = rp[s];                                 // unconditional (slot 0 when not needed): packed {offset, length - 1}
+            const uint32_t rx = need ? rl : hv.y;
             const uint32_t rs = rx & 0x1FFFFFFu;
             const uint32_t len = ok ? (rx >> 25) + 1u : 0u;
             uint32_t cnt = (NS == 1) ? (len ? 1u : 0u) : min((len + G - 1) / G, (uint32_t)NS);
@@ -521,8 +528,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
                 v[u] = vi;
             }
             // ---- row lookup: is feature f a row of the tile, and which slot
-            bool hit[U]; uint32_t slot[U];
-            if (!BUCKET) {
+            bool hit[U]; uint32_t slot[U];      // slot: what goes into the hit queue (row slot; LK 2: extent or marked slot)
+            if (LK == 0) {
                 // rank-bitmap: one 8-byte load per probe
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -531,6 +538,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
                     const uint32_t b = f[u] & 31u;
                     hit[u] = inr && ((wi.bits >> b) & 1u);
                     slot[u] = wi.rank + (uint32_t)__popc(wi.bits & ((1u << b) - 1u));
+                }
+            } else if (LK == 2) {
+                // sparse tiles (few rows per word): one 16-byte load per probe returns the word AND the extent of its
+                // first row, so only hits on a later row of the word go through the extent table in D1
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool inr = f[u] != 0xFFFFFFFFu;
+                    const BmWord64 wi = bm64[inr ? (f[u] >> 6) : 0u];
+                    const uint32_t b = f[u] & 63u;
+                    const unsigned long long bits = ((unsigned long long)wi.hi << 32) | wi.lo;
+                    hit[u] = inr && ((bits >> b) & 1ull);
+                    const uint32_t before = (uint32_t)__popcll(bits & ((1ull << b) - 1ull));
+                    slot[u] = before == 0u ? wi.ext0 : (0xFE000000u | (wi.rank + before));
                 }
             } else {
                 // layers whose bitmaps would not fit in HBM: bucket table over feature-id ranges (one 8-byte load), then
@@ -651,11 +671,13 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     // debug: bit 6 = per-phase cycle accounting; bits 8.. select one layer (value layer+1, 0 = every layer)
     a.phase = ((g_k1_ablate & 64) && ((g_k1_ablate >> 8) == 0 || (g_k1_ablate >> 8) == P.layer + 1)) ? k1_phase_buffer() : nullptr;
     const int ppc = pp_class(P.pp);
+#define XRL_K1_PP(GG, NN, DD, LL) do { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, DD, LL>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, DD, LL>, a, 64 / GG, lds, s); } while (0)
 #define XRL_K1(GG, NN) do { \
         const size_t lds = K1Cfg<GG, NN>::lds_bytes(a.acc_stride); \
-        if (X.dense) { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, true, false>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, true, false>, a, 64 / GG, lds, s); } \
-        else if (L.bucket) { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, false, true>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, false, true>, a, 64 / GG, lds, s); } \
-        else { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, false, false>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, false, false>, a, 64 / GG, lds, s); } } while (0)
+        if (X.dense) XRL_K1_PP(GG, NN, true, 0); \
+        else if (L.bucket) XRL_K1_PP(GG, NN, false, 1); \
+        else if (L.bitmap64) XRL_K1_PP(GG, NN, false, 2); \
+        else XRL_K1_PP(GG, NN, false, 0); } while (0)
     // a tile row must fit NS units of `group` lanes; widen a (forced) group that is too narrow
     if (group < 1 || group > 64 || (group & (group - 1))) fail("k1: lanes-per-item must be a power of two in [1, 64]");
     auto max_ns = [](int g) { return g < 8 ? 1u : (g == 32 ? 4u : 2u); };
@@ -672,6 +694,7 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     default: if (ns <= 1) XRL_K1(64, 1); else XRL_K1(64, 2); break;
     }
 #undef XRL_K1
+#undef XRL_K1_PP
 }
 
 // ---------------------------------------------------------------------------------------------

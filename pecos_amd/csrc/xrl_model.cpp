@@ -192,19 +192,32 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     //      337k features = 2.8 TB) the layer uses a bucket table + binary search over the tile's row ids instead
     //      (O(rows of the tile) memory).  XRL_LOOKUP=bitmap|bucket forces one (tests).
     uint64_t bm_words = (uint64_t)T * L->nwords;
-    bool use_bucket = false;
+    const uint32_t nwords64 = (W.rows + 63) / 64;
+    bool use_bucket = false, use_bm64 = false;
     {
         size_t free_b = 0, total_b = 0;
         const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
         const char* lk = std::getenv("XRL_LOOKUP");
         if (lk && !std::strcmp(lk, "bucket")) use_bucket = true;
         else if (lk && !std::strcmp(lk, "bitmap")) use_bucket = false;
-        else use_bucket = have ? bm_words * 8 > (uint64_t)(free_b / 4) : bm_words * 8 > (48ull << 30);
+        else if (lk && !std::strcmp(lk, "bitmap64")) use_bm64 = true;
+        else {
+            use_bucket = have ? bm_words * 8 > (uint64_t)(free_b / 4) : bm_words * 8 > (48ull << 30);
+            // sparse tiles: at most ~4 rows per 64-feature word on average -> most hits are the first row of their word,
+            // and the 64-feature word (same bytes per feature) hands back that row's extent with the probe
+            if (!use_bucket && T > 0 && nnz > 0) {
+                uint64_t rows_ub = 0;   // sum over tiles of distinct rows <= sum of column nnz; exact count comes later, this is a cheap bound
+                for (uint32_t t = 0; t < T; ++t) rows_ub += std::min<uint64_t>(tile_nnz[t], W.rows);
+                use_bm64 = rows_ub <= 4ull * T * nwords64;
+            }
+        }
         if (use_bucket) bm_words = 0;
         if (have && bm_words * 8 + nnz * 8 > (uint64_t)(free_b * 0.9))
             fail("layer: the device layout needs " + std::to_string((bm_words * 8 + nnz * 8) >> 20) + " MiB (" + std::to_string(T) +
                  " tiles x " + std::to_string(W.rows) + " features) but only " + std::to_string(free_b >> 20) + " MiB of HBM are free");
+        if (use_bm64) bm_words = 0;   // the 64-feature words replace the 32-feature ones (same size)
     }
+    const bool want_bm32 = !use_bucket && !use_bm64;
     std::vector<Entry> entries(nnz);
     std::vector<BmWord> bitmap(bm_words, BmWord{0, 0});
     std::vector<std::vector<uint32_t>> t_rows(T), t_rptr(T);
@@ -224,7 +237,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         // rows ascending; inside a row the column order (ascending) is kept: stable
         std::stable_sort(nz.begin(), nz.end(), [](const Nz& a, const Nz& b) { return a.row < b.row; });
         auto& rows = t_rows[t]; auto& rptr = t_rptr[t];
-        BmWord* bm = use_bucket ? nullptr : bitmap.data() + t * (uint64_t)L->nwords;
+        BmWord* bm = want_bm32 ? bitmap.data() + t * (uint64_t)L->nwords : nullptr;
         Entry* ent = entries.data() + td.ent_base;
         for (size_t i = 0; i < nz.size(); ++i) {
             if (i == 0 || nz[i].row != nz[i - 1].row) {
@@ -405,10 +418,32 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         for (uint32_t t = 0; t < T; ++t) tiles[t].ent_base = dev_base[t];
         entries.swap(dev_entries);
     }
+    std::vector<BmWord64> bitmap64;
+    if (use_bm64) {
+        bitmap64.assign((size_t)T * nwords64 + 1, BmWord64{0u, 0u, 0u, 0u});
+        parallel_for(T, [&](size_t t) {
+            BmWord64* bw = bitmap64.data() + t * (size_t)nwords64;
+            const std::vector<uint32_t>& rows = t_rows[t];
+            const uint32_t* ext = row_ext.data() + tiles[t].rowptr_base;
+            for (uint32_t r = 0; r < (uint32_t)rows.size(); ++r) {
+                BmWord64& w = bw[rows[r] >> 6];
+                if ((w.lo | w.hi) == 0u) {                                         // first row of the word (rows ascend)
+                    w.rank = r;
+                    w.ext0 = (ext[r] >> 25) == 0x7Fu ? (0xFE000000u | r) : ext[r];   // a 128-entry row reads like the "slot" marker: send it through the table
+                }
+                const uint32_t b = rows[r] & 63u;
+                if (b < 32) w.lo |= 1u << b; else w.hi |= 1u << (b - 32);
+            }
+            uint32_t run = 0;                                                   // empty words still need a rank (hits never read it)
+            for (uint32_t k = 0; k < nwords64; ++k) { if ((bw[k].lo | bw[k].hi) == 0u) bw[k].rank = run; run = bw[k].rank + (uint32_t)__builtin_popcount(bw[k].lo) + (uint32_t)__builtin_popcount(bw[k].hi); }
+        });
+    }
     row_idx.push_back(0u);
     L->d_bias_prod.upload(bias_prod);
     L->d_tiles.upload(tiles); L->d_ptile.upload(ptile); L->d_chunk_col.upload(chunk_col);
-    if (!use_bucket) L->d_bitmap.upload(bitmap); else L->d_bucket.upload(bucket);
+    if (want_bm32) L->d_bitmap.upload(bitmap);
+    if (use_bucket) L->d_bucket.upload(bucket);
+    if (use_bm64) L->d_bitmap64.upload(bitmap64);
     L->d_row_ptr.upload(row_ext); L->d_row_idx.upload(row_idx);
     L->d_entries.upload(entries); L->d_chunk_alg.upload(chunk_alg);
     if (!contiguous) {
@@ -427,11 +462,12 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
                       L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap +
-                      L->d_img.cap + L->d_img_off.cap + L->d_bucket.cap;
+                      L->d_img.cap + L->d_img_off.cap + L->d_bucket.cap + L->d_bitmap64.cap;
 
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
-    d.bitmap = use_bucket ? nullptr : L->d_bitmap.as<BmWord>();
+    d.bitmap = want_bm32 ? L->d_bitmap.as<BmWord>() : nullptr;
+    d.bitmap64 = use_bm64 ? L->d_bitmap64.as<BmWord64>() : nullptr; d.nwords64 = nwords64;
     d.bucket = use_bucket ? L->d_bucket.as<uint32_t>() : nullptr; d.bk_shift = L->bk_shift; d.bk_n = L->bk_n; d.bk_levels = L->bk_levels;
     d.row_ext = L->d_row_ptr.as<uint32_t>(); d.row_idx = L->d_row_idx.as<uint32_t>();
     d.entries = L->d_entries.as<Entry>(); d.perm_inv = (contiguous && !perm_inv_override) ? nullptr : L->d_perm_inv.as<uint32_t>();

@@ -45,6 +45,7 @@ struct TileDesc {            // 32 bytes, device
 
 struct Entry { uint32_t col; float val; };          // 8 bytes, == chunk_entry_t
 struct BmWord { uint32_t bits; uint32_t rank; };    // 8 bytes per 32 features
+struct alignas(16) BmWord64 { uint32_t lo, hi, rank, ext0; };   // 16 bytes per 64 features: bits, rank, packed extent of the first set row
 // one tile row in 4 bytes: tile-relative entry offset (25 bits, < max_tile_entries) | (length - 1) << 25 (rows hold 1..128 entries)
 inline uint32_t pack_row_extent(uint32_t start, uint32_t len) { return start | ((len - 1u) << 25); }
 
@@ -54,6 +55,8 @@ struct LayerDev {
     const uint32_t* ptile;       // [n_parents+1] tiles of parent p = [ptile[p], ptile[p+1])
     const uint32_t* chunk_col;   // [n_parents+1] child-column range of parent p (rearranged space)
     const BmWord* bitmap;        // [n_tiles * nwords], or nullptr when the layer uses the bucket lookup
+    const BmWord64* bitmap64;    // [n_tiles * nwords64] sparse tiles (few rows per word): 64-feature words that carry the first row's extent, else nullptr
+    uint32_t nwords64;
     const uint32_t* bucket;      // [n_tiles * (bk_n+1)] first row slot of every feature-id bucket (bitmap too large for HBM), else nullptr
     uint32_t bk_shift, bk_n, bk_levels;   // bucket = feature >> bk_shift; binary-search steps that cover the longest bucket
     const uint32_t* row_ext;     // [sum(nrows)] packed {entry offset, length} of every tile row (pack_row_extent)
@@ -93,7 +96,7 @@ struct Layer {
     DevBuf d_csc_ptr, d_csc_idx, d_csc_val; bool csc_ready = false;
     // device storage
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
-    DevBuf d_img, d_img_off, d_bucket;
+    DevBuf d_img, d_img_off, d_bucket, d_bitmap64;
     uint32_t bk_shift = 0, bk_n = 0, bk_levels = 0;
     LayerDev dev{};
     uint64_t device_bytes = 0;

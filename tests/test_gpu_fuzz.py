@@ -75,14 +75,16 @@ def test_fuzz(seed, tmp_path, oracle_mod):
     bias = float(rng.choice([1.0, -1.0, 0.5]))
     folder = str(tmp_path / "m")
     sizes = random_model(folder, rng, D, depth, bias)
-    # row lookup: rank-bitmaps (default) or, for every third model, the bucket table + binary search that layers
-    # too large for bitmaps fall back to
-    os.environ["XRL_LOOKUP"] = "bucket" if seed % 3 == 0 else "bitmap"
+    # row lookup structure, rotated over the models: 32-feature rank-bitmap words, the bucket table + binary search
+    # that layers too large for bitmaps fall back to, 64-feature words that carry the first row's extent (sparse tiles)
+    mode = ("bucket", "bitmap", "bitmap64")[seed % 3]
+    os.environ["XRL_LOOKUP"] = mode
     try:
         m = XLinearModel.load(folder)
     finally:
         os.environ.pop("XRL_LOOKUP", None)
-    assert clib.xlinear_get_int_attr(m.model.model_chain, "nr_bucket_layers") == (depth if seed % 3 == 0 else 0)
+    assert clib.xlinear_get_int_attr(m.model.model_chain, "nr_bucket_layers") == (depth if mode == "bucket" else 0)
+    assert clib.xlinear_get_int_attr(m.model.model_chain, "nr_bitmap64_layers") == (depth if mode == "bitmap64" else 0)
     om = oracle_mod.OracleModel.load(folder)
     X = random_queries(rng, int(rng.integers(1, 70)), D)
     for trial in range(4):

@@ -122,17 +122,20 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
     clib.set_option(m.model.model_chain, "k1t_min_items", 0)
     assert_same_topk(m.predict(X, beam_size=5, only_topk=3, max_pred_chunk=37), ref.predict(X, beam_size=5, only_topk=3),
                      exact_scores=True, what="max_pred_chunk")
-    # the same model with the bucket row lookup (what layers too large for rank-bitmaps use)
-    os.environ["XRL_LOOKUP"] = "bucket"
-    try:
-        mb = XLM.load(folder)
-    finally:
-        os.environ.pop("XRL_LOOKUP", None)
-    assert clib.xlinear_get_int_attr(mb.model.model_chain, "nr_bucket_layers") == len(ks)
-    for pp in (None, "sigmoid"):
-        kw = dict(beam_size=cfg["beam"], only_topk=10, **({"post_processor": pp} if pp else {}))
-        assert_same_topk(mb.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} bucket lookup {pp}")
-    del mb
+    # the same model with every other row lookup structure: bucket table (what layers too large for rank-bitmaps use),
+    # 32-feature words and 64-feature words with the first row's extent (the default picks per layer by tile sparsity)
+    for mode, attr in (("bucket", "nr_bucket_layers"), ("bitmap64", "nr_bitmap64_layers"), ("bitmap", None)):
+        os.environ["XRL_LOOKUP"] = mode
+        try:
+            mb = XLM.load(folder)
+        finally:
+            os.environ.pop("XRL_LOOKUP", None)
+        if attr:
+            assert clib.xlinear_get_int_attr(mb.model.model_chain, attr) == len(ks)
+        for pp in (None, "sigmoid"):
+            kw = dict(beam_size=cfg["beam"], only_topk=10, **({"post_processor": pp} if pp else {}))
+            assert_same_topk(mb.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} lookup={mode} {pp}")
+        del mb
     if X.shape[1] <= 6000:
         Xd = np.ascontiguousarray(X[:64].toarray())
         assert_same_topk(m.predict(Xd, beam_size=4, only_topk=6), ref.predict(Xd, beam_size=4, only_topk=6),
