@@ -5,8 +5,10 @@
 //   K1 k1_kernel       compute_sparse_predictions + chunk_ops + transform + combine
 //                                                           inference.hpp:925-1007, 769-839, 506-518,
 //                                                           1360-1384, PostProcessor :192-240
+//   K1T k1t_kernel     the same, tile-stationary: tile image held in LDS (optional, see below)
 //   K2 k2_topk_*       sorted_csr + reorder_prediction      inference.hpp:1223-1298, 1919-1923
 //   K3 k3_kernel       sparse_inner_products                matrix.hpp:1049-1060, 836-877
+//   K4 k4_selected     predict_on_selected_outputs (CSC)    inference.hpp:1018-1078, 1302-1358
 //
 // Arithmetic contract (verified bit-for-bit against the compiled reference, see oracle/):
 // every output column accumulates fl32(acc + fl32(x_f * w)) over matched features in ASCENDING
@@ -20,6 +22,11 @@
 // FIFO is drained row by row with the G lanes striding over the row's entries (distinct output
 // columns -> no conflicts), accumulators living in LDS.  Rows are drained in feature order, so
 // the per-column summation order is exactly the reference's.
+//
+// What bounds K1 on MI355X (profiles/): not HBM bytes and, since the drain was rewritten, not
+// VALU issue (50-65 % busy) but the stream of 128-byte lines its 8-byte gathers request from the L2 -- hence one
+// 4-byte packed extent per row, rows placed so that none straddles an extra line, bitmap words that return the
+// first row's extent with the probe, lanes past a unit's end re-reading its first entry.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>

@@ -12,7 +12,8 @@
 //   * the row lookup "is feature f present in this tile, and where" is a rank-bitmap:
 //     one 8-byte {bits, rank} word per 32 features, i.e. ONE load per probe instead of the
 //     reference's ~log2(R) binary-search steps (:786-803).  It costs rows/4 bytes per tile,
-//     which is what 288 GB of HBM3E is for;
+//     which is what 288 GB of HBM3E is for; sparse tiles use 64-feature words that also return the first
+//     row's extent, and layers whose bitmaps would not fit fall back to a bucket table + binary search;
 //   * rows are {start, length} packed in 32 bits, tile-relative, laid out so that no row touches more 128-byte
 //     lines than its length requires; entries stay {u32 col_offset, f32 val} (8 B).
 #pragma once
