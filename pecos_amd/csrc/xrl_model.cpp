@@ -215,6 +215,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         if (have && bm_words * 8 + nnz * 8 > (uint64_t)(free_b * 0.9))
             fail("layer: the device layout needs " + std::to_string((bm_words * 8 + nnz * 8) >> 20) + " MiB (" + std::to_string(T) +
                  " tiles x " + std::to_string(W.rows) + " features) but only " + std::to_string(free_b >> 20) + " MiB of HBM are free");
+        if (W.rows >= (1u << 25)) use_bm64 = false;   // the hit queue packs a row slot into 25 bits in that mode
         if (use_bm64) bm_words = 0;   // the 64-feature words replace the 32-feature ones (same size)
     }
     const bool want_bm32 = !use_bucket && !use_bm64;
