@@ -142,6 +142,42 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
                          exact_scores=True, what="dense")
 
 
+def test_full_width_rows_every_lookup(XLM, clib, oracle_mod, tmp_path):
+    # one 128-column chunk whose weight rows are completely dense: every tile row holds 128 entries, the value at which
+    # the packed extent's length field is all ones (the 64-feature bitmap words route such rows through the extent table);
+    # plus a second layer with narrow chunks, under each row lookup structure
+    import json
+    D, K0, K1 = 70, 128, 256
+    folder = str(tmp_path / "m")
+    rng = np.random.default_rng(5)
+    for d, (K, Kp) in enumerate(((K0, 1), (K1, K0))):
+        lf = os.path.join(folder, "ranker", f"{d}.model"); os.makedirs(lf, exist_ok=True)
+        W = rng.standard_normal((D + 1, K)).astype(np.float32)
+        if d == 1:
+            W[rng.random(W.shape) < 0.7] = 0.0
+        smat.save_npz(os.path.join(lf, "W.npz"), smat.csc_matrix(W), compressed=False)
+        par = np.arange(K) * Kp // K
+        C = smat.csc_matrix((np.ones(K, np.float32), (np.arange(K), par)), shape=(K, Kp))
+        smat.save_npz(os.path.join(lf, "C.npz"), C, compressed=False)
+        json.dump({"model": "MLModel", "bias": 1.0, "pred_kwargs": {"only_topk": 20, "post_processor": "l3-hinge"}},
+                  open(os.path.join(lf, "param.json"), "w"))
+    json.dump({"model": "HierarchicalMLModel", "depth": 2}, open(os.path.join(folder, "ranker", "param.json"), "w"))
+    json.dump({"model": "XLinearModel"}, open(os.path.join(folder, "param.json"), "w"))
+    X = smat.random(40, D, density=0.3, format="csr", dtype=np.float32, random_state=3); X.sort_indices()
+    om = oracle_mod.OracleModel.load(folder)
+    want = om.predict(X, beam_size=128, only_topk=30)
+    for mode in ("bitmap", "bitmap64", "bucket", None):
+        if mode:
+            os.environ["XRL_LOOKUP"] = mode
+        try:
+            m = XLM.load(folder)
+        finally:
+            os.environ.pop("XRL_LOOKUP", None)
+        assert_same_topk(m.predict(X, beam_size=128, only_topk=30), want, exact_scores=True, what=f"full-width rows, lookup={mode}")
+        assert_same_topk(m.predict(np.ascontiguousarray(X.toarray()), beam_size=128, only_topk=30),
+                         om.predict(np.ascontiguousarray(X.toarray()), beam_size=128, only_topk=30), exact_scores=True, what=f"dense X, lookup={mode}")
+
+
 def test_edge_cases(XLM, clib, oracle_mod, tmp_path):
     import xrl_synth
     folder = str(tmp_path / "m")
