@@ -124,15 +124,19 @@ def main():
     if world > 1:
         g_packed = torch.empty((world, maxr, 2 * k), dtype=torch.int32, device=dev)
         g_cnt = torch.empty((world, maxr), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    # one explicit (non-default) torch stream carries the kernels AND the RCCL all-gathers, so that the gather of a
+    # step is ordered after its predict without a host sync (handle 0 would mean "the library's own stream")
+    tstream = torch.cuda.Stream(device=dev)
+    stream = tstream.cuda_stream
 
     def step():
-        if rows:
-            clib.predict_device(h, q, beam, None, args.topk, packed.data_ptr(), packed.data_ptr() + 4 * k, cnt.data_ptr(),
-                                2 * k, stream=stream, sync=False)
-        if world > 1:
-            dist.all_gather_into_tensor(g_packed, packed)
-            dist.all_gather_into_tensor(g_cnt, cnt)
+        with torch.cuda.stream(tstream):
+            if rows:
+                clib.predict_device(h, q, beam, None, args.topk, packed.data_ptr(), packed.data_ptr() + 4 * k, cnt.data_ptr(),
+                                    2 * k, stream=stream, sync=False)
+            if world > 1:
+                dist.all_gather_into_tensor(g_packed, packed)
+                dist.all_gather_into_tensor(g_cnt, cnt)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -140,6 +144,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    torch.cuda.synchronize()        # buffers were zero-filled on the default stream
     for _ in range(args.warmup):
         step()
     sync_all()

@@ -184,7 +184,8 @@ void xrl_queries_free(void* queries);
 /* Beam search with inputs already resident in HBM.  Writes fixed-stride results
  *   d_out_idx u32[rows*out_stride], d_out_val f32[rows*out_stride], d_out_cnt u32[rows]
  * into caller-provided DEVICE buffers (e.g. torch tensors) on `hip_stream` (a hipStream_t, NULL =
- * the library's own stream) and returns without synchronising when `sync` == 0.
+ * the library's own stream -- so a caller working on the legacy default stream, whose handle is NULL, must either pass
+ * `sync` != 0 or use an explicit stream) and returns without synchronising when `sync` == 0.
  * out_stride must be >= the effective only_topk.  Returns 0 on success. */
 int xrl_predict_device(void* model, void* queries, uint32_t beam_size, const char* post_processor,
                        uint32_t only_topk, uint32_t* d_out_idx, float* d_out_val,
