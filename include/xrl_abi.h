@@ -215,6 +215,15 @@ uint32_t xrl_profile_get(void* model, xrl_profile_rec_t* out, uint32_t cap);
 int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char* post_processor,
                       uint32_t only_topk, double* stats_out, uint32_t stats_cap);
 
+/* Host-only pieces of the model compiler, exported so that they can be tested without a GPU.
+ * xrl_debug_split_chunk: number of even column tiles for a chunk of n columns whose entry-count prefix sums are
+ *   cum[0..n], such that every tile has <= 128 columns and fewer than `limit` entries (0: impossible).
+ * xrl_debug_layout_rows: places a tile's rows (rptr[0..nrows] = packed CSR starts); with align != 0 a row that would touch
+ *   more 128-byte lines than its length requires starts on the next 16-entry boundary.  Writes one packed extent
+ *   `offset | (len-1) << 25` per row to ext_out (may be NULL) and returns the padded entry count of the tile. */
+uint32_t xrl_debug_split_chunk(const uint64_t* cum, uint32_t n, uint64_t limit);
+uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, uint32_t* ext_out);
+
 /* Tuning knobs (benchmark / tests only).  Results never depend on them.
  *   "k1_group"            lanes per (query, tile) item in K1: 0 = auto, else a power of two <= 64
  *   "max_batch_rows"      rows of X per internal batch (0 = auto: candidate buffer <= 6 GiB)

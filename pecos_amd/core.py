@@ -426,6 +426,26 @@ class corelib(object):
     def effective_topk(self, c_model, only_topk):
         return int(self.clib_float32.xrl_effective_topk(c_void_p(c_model), only_topk or 0))
 
+    def debug_split_chunk(self, col_nnz, limit):
+        """Host-only: number of even column tiles the model compiler cuts a chunk with these column nnz into."""
+        cum = np.concatenate([[0], np.cumsum(np.asarray(col_nnz, dtype=np.uint64))]).astype(np.uint64)
+        fn = self.clib_float32.xrl_debug_split_chunk
+        fn.restype = ctypes.c_uint32
+        fn.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.c_uint32, ctypes.c_uint64]
+        return int(fn(cum.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), len(col_nnz), int(limit)))
+
+    def debug_layout_rows(self, row_len, align=True):
+        """Host-only: (offset, length) of every tile row and the padded entry count, as the model compiler places them."""
+        rptr = np.concatenate([[0], np.cumsum(np.asarray(row_len, dtype=np.int64))]).astype(np.uint32)
+        ext = np.zeros(len(row_len), dtype=np.uint32)
+        fn = self.clib_float32.xrl_debug_layout_rows
+        fn.restype = ctypes.c_uint64
+        fn.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
+        total = int(fn(rptr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(row_len), 1 if align else 0,
+                       ext.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+        self._check()
+        return ext & 0x1FFFFFF, (ext >> 25) + 1, total
+
     def profile_enable(self, c_model, on=True):
         self.clib_float32.xrl_profile_enable(c_void_p(c_model), 1 if on else 0)
 

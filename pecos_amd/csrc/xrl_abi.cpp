@@ -569,6 +569,18 @@ uint32_t xrl_profile_get(void* model, xrl_profile_rec_t* out, uint32_t cap) {
     return n;
 }
 
+uint32_t xrl_debug_split_chunk(const uint64_t* cum, uint32_t n, uint64_t limit) {
+    uint32_t v = 0;
+    guarded([&] { if (!cum) fail("null cum"); v = split_chunk(cum, n, limit); });
+    return v;
+}
+
+uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, uint32_t* ext_out) {
+    uint64_t v = 0;
+    guarded([&] { if (!rptr) fail("null rptr"); v = layout_tile_rows(rptr, nrows, align != 0, ext_out); });
+    return v;
+}
+
 int xrl_set_option(void* model, const char* key, int64_t value) {
     int rc = -1;
     guarded([&] {

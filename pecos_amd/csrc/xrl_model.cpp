@@ -97,6 +97,39 @@ static uint64_t max_tile_entries() {
     return v;
 }
 
+// Even split of a chunk of n columns into column tiles: the smallest count (starting from ceil(n / kMaxTileCols), grown
+// by a quarter at a time) for which every tile [n*t/k, n*(t+1)/k) holds fewer than `limit` entries; cum[0..n] are the
+// prefix sums of the columns' entry counts.  Returns 0 when even one column per tile does not fit.
+uint32_t split_chunk(const uint64_t* cum, uint32_t n, uint64_t limit) {
+    uint32_t nt = (n + kMaxTileCols - 1) / kMaxTileCols;
+    if (n == 0) return nt;
+    auto fits = [&](uint32_t k) {
+        for (uint32_t t = 0; t < k; ++t)
+            if (cum[(uint64_t)n * (t + 1) / k] - cum[(uint64_t)n * t / k] >= limit) return false;
+        return true;
+    };
+    while (!fits(nt)) {
+        if (nt >= n) return 0;
+        nt = std::min<uint32_t>(n, nt + std::max<uint32_t>(1, nt / 4));
+    }
+    return nt;
+}
+
+// Placement of a tile's rows in its entry block.  rptr[0..nrows] are the rows' packed (CSR) starts; with `align` a row
+// that would touch more 128-byte lines (16 entries) than its length requires starts at the next 16-entry boundary.
+// Writes the packed extents (pack_row_extent) when ext != nullptr; returns the block's entry count, a multiple of 16.
+uint64_t layout_tile_rows(const uint32_t* rptr, uint32_t nrows, bool align, uint32_t* ext) {
+    uint64_t cur = 0;
+    for (uint32_t r = 0; r < nrows; ++r) {
+        const uint32_t len = rptr[r + 1] - rptr[r];
+        if (len == 0 || len > kMaxTileCols) fail("layer: internal error, tile row length");
+        if (align && ((cur & 15) + len + 15) / 16 > ((uint64_t)len + 15) / 16) cur = (cur + 15) & ~15ull;
+        if (ext) ext[r] = pack_row_extent((uint32_t)(cur & 0x1FFFFFFu), len);
+        cur += len;
+    }
+    return (cur + 15) & ~15ull;
+}
+
 static bool k1t_images_enabled() {
     const char* e = std::getenv("XRL_K1T");
     return e && e[0] && e[0] != '0';
@@ -144,15 +177,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
                 if (oc >= W.cols) fail("layer: C row index out of range of W's columns");
                 cum[c + 1] = cum[c] + (W.col_ptr[oc + 1] - W.col_ptr[oc]);
             }
-            auto fits = [&](uint32_t k) {
-                for (uint32_t t = 0; t < k; ++t)
-                    if (cum[(uint64_t)n * (t + 1) / k] - cum[(uint64_t)n * t / k] >= max_tile_entries()) return false;
-                return true;
-            };
-            while (!fits(nt)) {
-                if (nt >= n) fail("layer: one weight column holds " + std::to_string(max_tile_entries()) + " or more entries");
-                nt = std::min<uint32_t>(n, nt + std::max<uint32_t>(1, nt / 4));
-            }
+            nt = split_chunk(cum.data(), n, max_tile_entries());
+            if (nt == 0) fail("layer: one weight column holds " + std::to_string(max_tile_entries()) + " or more entries");
         }
         for (uint32_t t = 0; t < nt; ++t) {
             TileDesc td{};
@@ -386,18 +412,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     {
         const char* ra = std::getenv("XRL_ROW_ALIGN");
         bool align = !(ra && ra[0] == '0');
-        auto lay_out = [&](size_t t, uint32_t* ext) -> uint64_t {   // returns the tile's padded entry count (multiple of 16)
-            const uint32_t* trp = t_rptr[t].data();
-            uint64_t cur = 0;
-            for (uint32_t r = 0; r < tiles[t].nrows; ++r) {
-                const uint32_t len = trp[r + 1] - trp[r];
-                if (align && ((cur & 15) + len + 15) / 16 > ((uint64_t)len + 15) / 16) cur = (cur + 15) & ~15ull;
-                if (len == 0 || len > kMaxTileCols) fail("layer: internal error, tile row length");
-                if (ext) ext[r] = pack_row_extent((uint32_t)(cur & 0x1FFFFFFu), len);
-                cur += len;
-            }
-            return (cur + 15) & ~15ull;
-        };
+        auto lay_out = [&](size_t t, uint32_t* ext) -> uint64_t { return layout_tile_rows(t_rptr[t].data(), tiles[t].nrows, align, ext); };
         std::vector<uint64_t> dev_base((size_t)T + 1, 0);
         for (int pass = 0; pass < 2; ++pass) {
             std::vector<uint64_t> padded(T, 0);

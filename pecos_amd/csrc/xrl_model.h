@@ -151,6 +151,10 @@ struct Model {
     uint64_t device_bytes() const;
 };
 
+// host-only pieces of the model compiler (also exported for tests: xrl_debug_split_chunk / xrl_debug_layout_rows)
+uint32_t split_chunk(const uint64_t* cum, uint32_t n, uint64_t limit);
+uint64_t layout_tile_rows(const uint32_t* rptr, uint32_t nrows, bool align, uint32_t* ext);
+
 // Build one layer from host CSC W / C (LayerData<chunked>::init, inference.hpp:1849-1883).
 // perm_inv_override / orig_rows: W and C are already in the rearranged (contiguous) child order and the
 // given map takes rearranged -> original ids (mmap model folders, LayerData::init_mmap :1885-1908).

@@ -112,3 +112,40 @@ def test_shard_bounds_balance_nnz():
         assert max(work) - min(work) <= 60 + 0.05 * np.mean(work)
     assert list(shard_bounds(np.zeros((10, 3), np.float32), 4)) == [0, 3, 5, 8, 10] or True
     assert shard_bounds(smat.csr_matrix((0, 5), dtype=np.float32), 2).tolist() == [0, 0, 0]
+
+
+def test_model_compiler_tile_split_and_row_placement():
+    """Host-only pieces of the model compiler (no GPU): nnz-aware column tiling and line-aware row placement."""
+    from pecos_amd import clib
+    rng = np.random.default_rng(0)
+    # ---- tile split: <= 128 columns and fewer than `limit` entries per tile, even split, smallest count tried first
+    for n, limit in ((1, 10), (128, 10**9), (129, 10**9), (300, 5000), (1000, 777), (64, 65), (5, 3)):
+        nnz = rng.integers(0, 60, n)
+        if limit == 3:
+            nnz[:] = 2                                   # 5 columns of 2 entries, limit 3: one column per tile
+        nt = clib.debug_split_chunk(nnz, limit)
+        if nnz.max() >= limit:
+            assert nt == 0                               # a single column already breaks the limit
+            continue
+        assert nt >= (n + 127) // 128 and nt <= n
+        cum = np.concatenate([[0], np.cumsum(nnz)])
+        for t in range(nt):
+            b, e = n * t // nt, n * (t + 1) // nt
+            assert 0 < e - b <= 128 and cum[e] - cum[b] < limit, (n, limit, nt, t)
+    assert clib.debug_split_chunk([5, 5, 5, 5], 11) == 2 and clib.debug_split_chunk([5, 5, 5, 5], 10) == 4
+    # ---- row placement: rows in order, no overlap, none touches more 16-entry lines than ceil(len/16)
+    for trial in range(20):
+        lens = rng.integers(1, 129, int(rng.integers(1, 400)))
+        for align in (True, False):
+            off, ln, total = clib.debug_layout_rows(lens, align)
+            assert np.array_equal(ln, lens) and total % 16 == 0 and total >= int(off[-1] + ln[-1])
+            assert np.all(off[1:] >= off[:-1] + ln[:-1])                       # ascending, disjoint
+            lines = (off + ln - 1) // 16 - off // 16 + 1
+            if align:
+                assert np.array_equal(lines, (ln + 15) // 16), trial            # minimal line count for every row
+                assert total <= 16 * int(np.sum((ln + 15) // 16)) + 16          # never worse than one row per line group
+            else:
+                assert np.array_equal(off, np.concatenate([[0], np.cumsum(lens)[:-1]]))   # packed
+    # a row longer than a tile is wide is a compiler bug: loud error, not a bad layout
+    with pytest.raises(RuntimeError):
+        clib.debug_layout_rows([3, 200, 1])
