@@ -162,6 +162,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = clib.profile_get(h)
+    if rank == 0:
+        log("per-launch ms: " + "  ".join(f"{r['name']}[{r['layer']}]={r['ms'] / max(1, r['launches']):.3f}" for r in prof))
 
     out = None
     if rank == 0:

@@ -344,6 +344,9 @@ uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
         else if (!std::strcmp(attr, "nr_bitmap64_layers")) {  // additive: layers using 64-feature bitmap words that carry the first row's extent
             for (auto& l : m.layers) v += l->dev.bitmap64 ? 1u : 0u;
         }
+        else if (!std::strcmp(attr, "nr_dense_layers")) {    // additive: layers that also carry the dense row format (K1Q)
+            for (auto& l : m.layers) v += l->dev.wd ? 1u : 0u;
+        }
         else if (!std::strcmp(attr, "nr_k1t_layers")) {      // additive: layers that carry K1T tile images
             for (auto& l : m.layers) v += l->dev.img ? 1u : 0u;
         }
@@ -589,6 +592,8 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         if (!std::strcmp(key, "k1_group")) m.k1_group = (int)value;
         else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
         else if (!std::strcmp(key, "sort_min_tiles")) m.sort_min_tiles = (int)value;
+        else if (!std::strcmp(key, "dense_layers")) m.dense_layers = (int)value;   // 0: never run the fused dense-format kernel K1Q
+        else if (!std::strcmp(key, "k2_legacy")) m.k2_legacy = (int)value;        // debug / A-B: round-1 insertion top-k
         else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
         else if (!std::strcmp(key, "k1t_min_items")) m.k1t_min_items = (int)value;
         else if (!std::strcmp(key, "k1t_items_per_block")) m.k1t_items_per_block = (int)value;

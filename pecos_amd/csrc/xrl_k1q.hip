@@ -1,0 +1,233 @@
+// K1Q: one whole beam-search layer in ONE kernel for layers held in the DENSE row format -- prolongate
+// (inference.hpp:1155-1219), chunk products (:769-839, 506-518), post-processor + combine (:192-240, 1360-1384),
+// top-k with the positional tie-break (:1223-1298) and the child re-ordering (:1919-1923) -- query-stationary:
+// a wavefront owns one query, its lanes own the query's candidate columns.
+//
+// Why a second row format.  K1 (xrl_kernels.hip) looks every query feature up in a per-tile rank-bitmap and
+// gathers the matching 8-byte entry rows; on MI355X it is bound by the NUMBER of cache lines those gathers
+// request from the L2 (profiles/): a probe line per (feature, tile), an extent line and 1..5 entry
+// lines per hit, three dependent loads deep.  For the narrow chunks of the upper tree levels (nr_splits = 16
+// children per parent) the weights of one feature for one chunk are 64 bytes when stored densely --
+//      wd[feature][dense tile * Gp + column]     (f32 bits; kMissing where W has no entry)
+// -- so ONE independent load per (feature, chunk) replaces probe + extent + entries, half a cache line each,
+// and because lane == column the accumulators live in registers: no LDS traffic, no compaction, 4 VALU
+// instructions per (feature, 64 candidates).  It costs rows x padded-columns x 4 bytes of HBM per layer
+// (Amazon-670K level 3: 4.4 GB), which is what 288 GB are for; layers that do not fit (the leaf) stay in
+// the sparse tile format and run K0 -> K1 -> K2.
+//
+// Arithmetic is the reference's, bit for bit: per candidate column, fl32(acc + fl32(x_f * w)) over the
+// query's features in ascending order; a column WITHOUT an entry at feature f is skipped (select on the
+// kMissing bit pattern), so explicit zeros stored in W and non-finite x behave exactly as in the sparse
+// walk; bias last (sparse X) / first (dense X); transform in fp64; combine in fp32.
+//
+// Wavefront layout: candidate u = r*64 + lane (r < NS registers) <-> slot u >> log2(Gp) = (beam rank j,
+// dense tile tt of that parent), column u & (Gp-1).  u is also the candidate's POSITION in the reference's
+// order (beam rank major, child order minor), which is what ties are broken by.
+#include <hip/hip_runtime.h>
+
+#include "xrl_device.h"
+#include "xrl_kernels.h"
+
+namespace xrl {
+
+#define XRL_LAUNCH_CHECK() XRL_HIP(hipGetLastError())
+
+struct K1QArgs {
+    LayerDev L;
+    QueriesDev X;
+    const uint32_t* p_idx; const float* p_val; const uint32_t* p_cnt; uint32_t p_stride;
+    uint32_t* out_idx; float* out_val; uint32_t* out_cnt; uint32_t out_stride;
+    uint32_t row0, nrows, beam_in, k;
+    int pp_kind, pp_p, first_layer, implicit_root;
+};
+
+template <int NS> struct K1QCfg {
+    // weight rows (features) whose loads are in flight together: U * NS loads per lane
+    static constexpr int U = NS <= 2 ? 16 : NS <= 4 ? 8 : NS <= 8 ? 4 : 2;
+};
+
+template <int NS, int PPC, bool DENSEX>
+__global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
+    constexpr int U = K1QCfg<NS>::U;
+    __shared__ uint2 sc_all[4 * 64];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar control flow below
+    const uint32_t q = blockIdx.x * 4u + wave;
+    if (q >= a.nrows) return;
+    uint2* sc = sc_all + wave * 64u;
+
+    // ---- prolongate: which (parent, dense tile, column) does each of this lane's candidates stand for
+    const uint32_t gl = a.L.d_gp_log2, gmask = (1u << gl) - 1u, TT = a.L.d_max_tiles;
+    const uint32_t cnt = a.implicit_root ? 1u : min(a.p_cnt[q], a.beam_in);
+    uint32_t woff[NS], child[NS]; float ps[NS], acc[NS]; bool valid[NS];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+        const uint32_t u = (uint32_t)r * 64u + (uint32_t)lane;
+        const uint32_t slot = u >> gl, col = u & gmask;
+        const uint32_t j = TT == 1u ? slot : slot / TT;
+        const uint32_t tt = TT == 1u ? 0u : slot - j * TT;
+        bool v = j < cnt;
+        uint32_t parent = 0; float pscore = 1.0f;
+        if (!a.implicit_root) {
+            const size_t at = (size_t)q * a.p_stride + (v ? j : 0u);
+            parent = a.p_idx[at]; pscore = a.p_val[at];
+        }
+        v = v && parent < a.L.n_parents;
+        if (!v) parent = 0;
+        const uint32_t dt = a.L.d_ptile[parent] + tt;
+        v = v && dt < a.L.d_ptile[parent + 1];
+        const uint32_t dtc = v ? dt : 0u;
+        const uint32_t cb = a.L.d_tcol[dtc], ce = a.L.d_tcol[dtc + 1];
+        v = v && col < ce - cb;
+        woff[r] = v ? ((dtc << gl) + col) * 4u : 0u;                   // BYTE offset inside a feature row (d_ld < 2^30)
+        child[r] = v ? cb + col : 0u;
+        ps[r] = pscore; valid[r] = v;
+        // dense queries: bias FIRST (inference.hpp:824-830); bias_prod holds fl32(bias * w) or +0.0
+        acc[r] = (DENSEX && a.L.has_bias) ? a.L.bias_prod[child[r]] : 0.0f;
+    }
+
+    const uint32_t* __restrict__ wd = a.L.wd;
+    const uint64_t ld = a.L.d_ld;
+    const uint32_t w_rows = a.L.w_rows;
+
+    // U features per batch: their U*NS weight loads are issued together (addresses depend only on the
+    // feature ids: scalar row base + this lane's column offset), then applied in feature order
+    auto batch = [&](uint32_t fv, uint32_t vbits, uint32_t t, uint32_t f_end) {
+        uint32_t wb[U][NS]; float xs[U]; bool sk[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)(t + (uint32_t)u));
+            xs[u] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)vbits, (int)(t + (uint32_t)u)));
+            sk[u] = f >= f_end;                                        // padding lanes carry f = 0xFFFFFFFF
+            const char* __restrict__ row = reinterpret_cast<const char*>(wd + (uint64_t)(sk[u] ? 0u : f) * ld);
+#pragma unroll
+            for (int r = 0; r < NS; ++r) wb[u][r] = *reinterpret_cast<const uint32_t*>(row + woff[r]);   // scalar base + 32-bit lane offset
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int r = 0; r < NS; ++r) {
+                // scalar * val, then add: no fma (inference.hpp:512-517); no entry -> no operation
+                const float s = __fadd_rn(acc[r], __fmul_rn(xs[u], __uint_as_float(wb[u][r])));
+                acc[r] = (sk[u] || wb[u][r] == kMissing) ? acc[r] : s;
+            }
+        }
+    };
+
+    if (DENSEX) {
+        // chunk_ops<drm, bin_search> (inference.hpp:815-839): every chunk row except the bias row, x gathered by row id
+        const float* __restrict__ xd = a.X.val + ((uint64_t)a.row0 + q) * a.X.cols;
+        const uint32_t n_feat = a.L.has_bias ? w_rows - 1u : w_rows;
+        for (uint32_t t0 = 0; t0 < n_feat; t0 += 64u) {
+            const uint32_t f = t0 + (uint32_t)lane;
+            const float xv = f < a.X.cols ? xd[f] : 0.0f;
+            const uint32_t fv = f < n_feat ? f : 0xFFFFFFFFu;
+            const uint32_t n = min(64u, n_feat - t0);
+            for (uint32_t t = 0; t < n; t += (uint32_t)U) batch(fv, __float_as_uint(xv), t, n_feat);
+        }
+    } else {
+        // chunk_ops<csr, bin_search> (inference.hpp:769-813): the query's features in ascending order
+        const uint64_t xb = a.X.row_ptr[(uint64_t)a.row0 + q];
+        const uint32_t xl = (uint32_t)(a.X.row_ptr[(uint64_t)a.row0 + q + 1] - xb);
+        const uint32_t* __restrict__ xi = a.X.col_idx + xb;
+        const float* __restrict__ xv = a.X.val + xb;
+        uint32_t fv = 0xFFFFFFFFu, vb = 0u;
+        if (xl) { const bool ok = (uint32_t)lane < xl; const uint32_t t = ok ? (uint32_t)lane : 0u; fv = ok ? xi[t] : 0xFFFFFFFFu; vb = __float_as_uint(xv[t]); }
+        for (uint32_t t0 = 0; t0 < xl; t0 += 64u) {
+            uint32_t fn = 0xFFFFFFFFu, vn = 0u;                          // next 64 features: in flight while this chunk is applied
+            if (t0 + 64u < xl) {
+                const uint32_t tn = t0 + 64u + (uint32_t)lane;
+                const bool ok = tn < xl; const uint32_t tc = ok ? tn : t0;
+                fn = ok ? xi[tc] : 0xFFFFFFFFu; vn = __float_as_uint(xv[tc]);
+            }
+            const uint32_t n = min(64u, xl - t0);
+            for (uint32_t t = 0; t < n; t += (uint32_t)U) batch(fv, vb, t, w_rows);
+            fv = fn; vb = vn;
+        }
+    }
+
+    // ---- bias last (sparse X, inference.hpp:806-811), transform in fp64, combine with the parent's score
+    uint32_t key[NS], sbits[NS];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+        float s = acc[r];
+        if (!DENSEX && a.L.has_bias) s = __fadd_rn(s, a.L.bias_prod[child[r]]);
+        float v = pp_transform<PPC>(a.pp_kind, a.pp_p, s);
+        if (!a.first_layer) v = pp_combine(a.pp_kind, v, ps[r]);
+        sbits[r] = __float_as_uint(v);
+        key[r] = valid[r] ? score_key(v) : 0u;
+    }
+    // ---- top-k (value desc, position asc) and reorder_prediction
+    uint32_t rank, sb, ch;
+    const uint32_t kk = wave_topk<NS>(key, sbits, child, a.k, sc, lane, rank, sb, ch);
+    if ((uint32_t)lane < kk) {
+        const size_t o = (size_t)q * a.out_stride + rank;
+        a.out_idx[o] = a.L.perm_inv ? a.L.perm_inv[ch] : ch;
+        a.out_val[o] = __uint_as_float(sb);
+    }
+    if (lane == 0) a.out_cnt[q] = kk;
+}
+
+// registers per lane a layer needs with `beam_in` parents per query, or 0 when K1Q cannot serve it
+uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k) {
+    if (!L.wd || k == 0 || k > 64) return 0;
+    const uint64_t cands = ((uint64_t)beam_in * L.d_max_tiles) << L.d_gp_log2;
+    const uint64_t ns = (cands + 63) / 64;
+    return ns <= 16 ? (uint32_t)std::max<uint64_t>(1, ns) : 0u;
+}
+
+void launch_k1q(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
+                uint32_t* out_cnt, uint32_t out_stride, hipStream_t s) {
+    if (P.nrows == 0) return;
+    const uint32_t ns = k1q_regs(L, P.beam_in, P.k);
+    if (ns == 0) fail("k1q: layer not eligible");
+    K1QArgs a;
+    a.L = L; a.X = X;
+    a.p_idx = prev.idx; a.p_val = prev.val; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
+    a.out_idx = out_idx; a.out_val = out_val; a.out_cnt = out_cnt; a.out_stride = out_stride;
+    a.row0 = P.row0; a.nrows = P.nrows; a.beam_in = P.beam_in; a.k = P.k;
+    a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer; a.implicit_root = P.implicit_root;
+    const dim3 grid((P.nrows + 3u) / 4u), block(256);
+    const int ppc = pp_class(P.pp);
+#define XRL_K1Q(NN) do { \
+        if (X.dense) { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, true>), grid, block, 0, s, a); } \
+        else { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, false>), grid, block, 0, s, a); } } while (0)
+    if (ns <= 1) XRL_K1Q(1);
+    else if (ns <= 2) XRL_K1Q(2);
+    else if (ns <= 3) XRL_K1Q(3);
+    else if (ns <= 4) XRL_K1Q(4);
+    else if (ns <= 6) XRL_K1Q(6);
+    else if (ns <= 8) XRL_K1Q(8);
+    else if (ns <= 12) XRL_K1Q(12);
+    else XRL_K1Q(16);
+#undef XRL_K1Q
+    XRL_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Model compiler, device side: scatter CSC weight columns into the dense row format.
+//   wd[row * ld + dst_off[c]] = W[row, src_col[c]]   for every (rearranged) child column c
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+densify_kernel(const uint64_t* __restrict__ col_ptr, const uint32_t* __restrict__ row_idx, const float* __restrict__ val,
+               const uint32_t* __restrict__ src_col, const uint32_t* __restrict__ dst_off, uint32_t n_children,
+               uint64_t ld, uint32_t* __restrict__ wd) {
+    // one wavefront per column: lanes stride over the column's entries
+    const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (c >= n_children) return;
+    const uint32_t oc = src_col[c], off = dst_off[c];
+    const uint64_t e0 = col_ptr[oc], e1 = col_ptr[oc + 1];
+    for (uint64_t e = e0 + (threadIdx.x & 63u); e < e1; e += 64u) wd[(uint64_t)row_idx[e] * ld + off] = __float_as_uint(val[e]);
+}
+
+void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,
+                    const uint32_t* dst_off, uint32_t n_children, uint32_t w_rows, uint64_t ld, uint32_t* wd, hipStream_t s) {
+    XRL_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wd), (int)kMissing, (size_t)w_rows * ld, s));
+    if (n_children) {
+        hipLaunchKernelGGL(densify_kernel, dim3((n_children + 3u) / 4u), dim3(256), 0, s, col_ptr, row_idx, val, src_col, dst_off,
+                           n_children, ld, wd);
+        XRL_LAUNCH_CHECK();
+    }
+}
+
+}  // namespace xrl

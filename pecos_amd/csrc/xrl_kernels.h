@@ -54,7 +54,7 @@ size_t sort_hist_bytes(uint64_t n_slots, uint32_t n_tiles);
 // K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
-                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s);
+                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, bool legacy = false /* round-1 insertion kernels (A/B) */);
 // stats: sum over (query, parent) of the reference chunk's algorithmic bytes, and of candidates
 void launch_stats(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* ncand,
                   double* out2 /* [0]=chunk bytes, [1]=candidates */, hipStream_t s);
@@ -75,6 +75,11 @@ void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const 
                         const uint64_t* prev_off, const float* prev_val, float* out_val, uint64_t n_pairs,
                         const PostProc& pp, int first_layer, hipStream_t s);
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
+// K1Q (xrl_k1q.hip): a whole layer -- prolongate, chunk products against the DENSE row format, post-processor,
+// combine, top-k, child re-ordering -- in one query-stationary kernel: previous beam in, next beam out.
+uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k);   // 0: the layer / beam / k cannot be served by K1Q
+void launch_k1q(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
+                uint32_t* out_cnt, uint32_t out_stride, hipStream_t s);
 size_t k2_max_k();
 
 }  // namespace xrl

@@ -32,82 +32,12 @@
 #include <cfloat>
 #include <cmath>
 
+#include "xrl_device.h"
 #include "xrl_kernels.h"
 
 namespace xrl {
 
 #define XRL_LAUNCH_CHECK() XRL_HIP(hipGetLastError())
-
-__device__ __forceinline__ void wave_sync_lds() {
-    // LDS operations of one wavefront execute in program order; this only stops the compiler
-    // from moving LDS accesses across the point (cross-lane RAW through LDS inside a wave).
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// ---------------------------------------------------------------------------------------------
-// post-processor (inference.hpp:192-240).  The reference lambdas take `const float&`:
-//   sigmoid / log-sigmoid evaluate std::exp(float) (= expf) and continue in double;
-//   l{p}-hinge keeps z in a FLOAT, then pow/exp in double.  Results are cast to float (:1369).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ref_expf(float x) { return (float)exp((double)x); }
-
-// z^p for the integer p of l{p}-hinge.  z is a float, so z*z is EXACT in double (48-bit product) and
-// z^3 = (z*z)*z, z^4 = (z*z)*(z*z) carry a single rounding: they are the correctly rounded powers,
-// which is what glibc's pow returns (its error bound is < 1 ULP, correctly rounded in practice).
-// Larger p fall back to pow().
-__device__ __forceinline__ double hinge_pow4(float zf, int p) {   // p in [0, 4] only
-    const double z = (double)zf;
-    const double z2 = z * z;
-    return p == 0 ? 1.0 : p == 1 ? z : p == 2 ? z2 : p == 3 ? z2 * z : z2 * z2;
-}
-
-__device__ __forceinline__ double hinge_pow(float zf, int p) {
-    const double z = (double)zf;
-    switch (p) {
-    case 0: return 1.0;
-    case 1: return z;
-    case 2: return z * z;
-    case 3: return (z * z) * z;
-    case 4: { const double t = z * z; return t * t; }
-    default: return pow(z, (double)p);
-    }
-}
-
-// PPC: compile-time post-processor CLASS.  0 = light (noop, l{p}-hinge and log-l{p}-hinge with
-// p <= 4: at most one fp64 exp, ~12 VGPRs), 1 = generic (adds sigmoid / log-sigmoid / pow(), ~42
-// VGPRs).  Keeping the heavy libm paths out of the default kernels keeps them at 8 waves per SIMD.
-template <int PPC>
-__device__ __forceinline__ float pp_transform(int kind, int p, float v) {
-    if (PPC == 0) {
-        if (kind == PP_LP_HINGE) { const float z = (float)fmax(0.0, 1.0 - (double)v); return (float)exp(-hinge_pow4(z, p)); }
-        if (kind == PP_LOG_LP_HINGE) { const float z = (float)fmax(0.0, 1.0 - (double)v); return (float)(-hinge_pow4(z, p)); }
-        return v;
-    }
-    switch (kind) {
-    case PP_SIGMOID: return (float)(1.0 / (1.0 + (double)ref_expf(-v)));
-    case PP_LOG_SIGMOID: return (float)(-log(1.0 + (double)ref_expf(-v)));
-    case PP_LP_HINGE: {
-        const float z = (float)fmax(0.0, 1.0 - (double)v);
-        return (float)exp(-hinge_pow(z, p));
-    }
-    case PP_LOG_LP_HINGE: {
-        const float z = (float)fmax(0.0, 1.0 - (double)v);
-        return (float)(-hinge_pow(z, p));
-    }
-    default: return v;
-    }
-}
-
-__device__ __forceinline__ float pp_combine(int kind, float x, float parent) {
-    switch (kind) {
-    case PP_SIGMOID:
-    case PP_LP_HINGE: return __fmul_rn(x, parent);        // std::multiplies<float>
-    case PP_LOG_SIGMOID:
-    case PP_LOG_LP_HINGE: return __fadd_rn(x, parent);    // std::plus<float>
-    default: return x;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // K0: one thread per query.  Besides the child-block offsets (prolongate) it writes one 16-byte
@@ -660,12 +590,6 @@ int k1_auto_group(const LayerDev& L, const Layer& host, int dense) {
     return 32;
 }
 
-static int pp_class(const PostProc& pp) {
-    if (pp.kind == PP_NOOP) return 0;
-    if ((pp.kind == PP_LP_HINGE || pp.kind == PP_LOG_LP_HINGE) && pp.p >= 0 && pp.p <= 4) return 0;
-    return 1;
-}
-
 void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, const uint32_t* n_items,
                float* cand, int group, hipStream_t s) {
     if (P.nrows == 0) return;
@@ -1137,11 +1061,42 @@ __global__ void __launch_bounds__(64) k2_topk_lds(K2Args a) {   // any k that fi
     if (lane == 0) a.out_cnt[q] = m;
 }
 
+// K2, register form (k <= 64, candidate rows of up to 64 * NS scores): the whole candidate row sits in registers
+// (candidate p = r*64 + lane) and wave_topk (xrl_device.h) selects and ranks with ballot bisection instead of
+// serial insertions.  Four queries (wavefronts) per workgroup.
+template <int NS>
+__global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
+    __shared__ uint2 sc_all[4 * 64];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t q32 = blockIdx.x * 4u + wave;
+    if (q32 >= a.nrows) return;
+    const uint64_t q = q32;
+    const uint32_t n = min(a.ncand[q], (uint32_t)(64 * NS));
+    const float* __restrict__ cv = a.cand + q * a.cand_stride;
+    const uint32_t nlast = n ? n - 1 : 0;
+    uint32_t key[NS], sbits[NS], pos[NS];
+#pragma unroll
+    for (int r = 0; r < NS; ++r) {
+        const uint32_t p = (uint32_t)r * 64u + (uint32_t)lane;
+        const float v = cv[p < n ? p : nlast];                     // unconditional, clamped
+        sbits[r] = __float_as_uint(v); pos[r] = p;
+        key[r] = p < n ? score_key(v) : 0u;
+    }
+    uint32_t rank, sb, pp;
+    const uint32_t kk = wave_topk<NS>(key, sbits, pos, a.k, sc_all + wave * 64u, lane, rank, sb, pp);
+    if ((uint32_t)lane < kk) {
+        a.out_idx[q * a.out_stride + rank] = k2_child_id(a, q, pp);
+        a.out_val[q * a.out_stride + rank] = __uint_as_float(sb);
+    }
+    if (lane == 0) a.out_cnt[q] = kk;
+}
+
 size_t k2_max_k() { return (160 * 1024) / 8; }
 
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
-                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s) {
+                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, bool legacy) {
     if (P.nrows == 0) return;
     K2Args a;
     a.chunk_col = L.chunk_col; a.perm_inv = L.perm_inv;
@@ -1151,7 +1106,18 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
     a.nrows = P.nrows; a.beam_in = P.beam_in; a.cand_stride = P.cand_stride; a.k = P.k; a.out_stride = out_stride;
     a.implicit_root = P.implicit_root;
     if (P.k == 0) fail("k2: only_topk / beam_size resolved to 0");
-    if (P.k <= 64) {
+    if (P.k <= 64 && P.cand_stride <= 64u * 32u && !legacy) {
+        const uint32_t ns = (P.cand_stride + 63u) / 64u;
+        const dim3 grid((P.nrows + 3u) / 4u), block(256);
+        if (ns <= 1) hipLaunchKernelGGL(k2_topk_wave<1>, grid, block, 0, s, a);
+        else if (ns <= 2) hipLaunchKernelGGL(k2_topk_wave<2>, grid, block, 0, s, a);
+        else if (ns <= 4) hipLaunchKernelGGL(k2_topk_wave<4>, grid, block, 0, s, a);
+        else if (ns <= 8) hipLaunchKernelGGL(k2_topk_wave<8>, grid, block, 0, s, a);
+        else if (ns <= 13) hipLaunchKernelGGL(k2_topk_wave<13>, grid, block, 0, s, a);
+        else if (ns <= 16) hipLaunchKernelGGL(k2_topk_wave<16>, grid, block, 0, s, a);
+        else if (ns <= 24) hipLaunchKernelGGL(k2_topk_wave<24>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(k2_topk_wave<32>, grid, block, 0, s, a);
+    } else if (P.k <= 64) {
         hipLaunchKernelGGL(k2_topk_reg, dim3(P.nrows), dim3(64), 0, s, a);
     } else {
         const size_t lds = (size_t)P.k * 8;

@@ -454,6 +454,60 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
             for (uint32_t k = 0; k < nwords64; ++k) { if ((bw[k].lo | bw[k].hi) == 0u) bw[k].rank = run; run = bw[k].rank + (uint32_t)__builtin_popcount(bw[k].lo) + (uint32_t)__builtin_popcount(bw[k].hi); }
         });
     }
+    // ---- DENSE row format (K1Q, xrl_k1q.hip) for layers whose padded dense matrix fits the HBM budget: chunks of
+    //      <= 64 children are one dense tile (padded to a power of two), wider chunks are cut evenly into tiles of
+    //      <= 32.  Built ON the device from the CSC columns (memset to kMissing + scatter); the tile format above is
+    //      kept too (it serves beams / top-k sizes K1Q cannot hold in registers).  XRL_DENSE=0 disables it,
+    //      XRL_DENSE_MAX_MB caps one layer's matrix (default 64 GiB, and never more than a quarter of the free HBM).
+    std::vector<uint32_t> d_ptile, d_tcol;
+    uint32_t d_gp_log2 = 0, d_max_tiles = 0; uint64_t d_ld = 0;
+    {
+        const char* de = std::getenv("XRL_DENSE");
+        bool want = !(de && de[0] == '0') && c_nnz > 0 && W.rows > 0;
+        // a column with duplicate or unsorted row ids cannot be scattered into one cell per (feature, column)
+        for (uint32_t c = 0; want && c < W.cols; ++c)
+            for (uint64_t e = W.col_ptr[c] + 1; e < W.col_ptr[c + 1]; ++e)
+                if (W.row_idx[e] <= W.row_idx[e - 1]) { want = false; break; }
+        if (want) {
+            const uint32_t wide = L->max_chunk_cols;
+            uint32_t gp = 1;
+            if (wide <= 64) { while (gp < wide) gp <<= 1; } else gp = 32;
+            d_ptile.assign(P + 1, 0);
+            for (uint32_t p = 0; p < P; ++p) {
+                const uint32_t cb = chunk_col[p], n = chunk_col[p + 1] - cb;
+                const uint32_t nt = n == 0 ? 0u : (wide <= 64 ? 1u : (n + 31u) / 32u);
+                for (uint32_t t = 0; t < nt; ++t) d_tcol.push_back(cb + (uint32_t)((uint64_t)n * t / nt));
+                d_ptile[p + 1] = (uint32_t)d_tcol.size();
+                d_max_tiles = std::max(d_max_tiles, nt);
+            }
+            const uint64_t n_dt = d_tcol.size();
+            d_tcol.push_back((uint32_t)c_nnz);
+            d_tcol.push_back((uint32_t)c_nnz);                     // one readable element past the end
+            while ((1u << d_gp_log2) < gp) ++d_gp_log2;
+            d_ld = (n_dt * gp + 31) & ~31ull;
+            const uint64_t bytes = (uint64_t)W.rows * d_ld * 4;
+            uint64_t cap_b = 64ull << 30;
+            if (const char* mb = std::getenv("XRL_DENSE_MAX_MB")) cap_b = std::strtoull(mb, nullptr, 10) << 20;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_b = std::min<uint64_t>(cap_b, free_b / 4);
+            if (n_dt == 0 || d_ld >= (1ull << 30) || bytes > cap_b) want = false;
+        }
+        if (want) {
+            std::vector<uint32_t> src_col(c_nnz), dst_off(c_nnz);
+            for (uint64_t dt = 0; dt + 2 < d_tcol.size(); ++dt)
+                for (uint32_t c = d_tcol[dt]; c < d_tcol[dt + 1]; ++c) { src_col[c] = orig_col(c); dst_off[c] = (uint32_t)(dt << d_gp_log2) + (c - d_tcol[dt]); }
+            DevBuf t_ptr, t_idx, t_val, t_src, t_dst;
+            t_ptr.upload(W.col_ptr); t_idx.upload(W.row_idx); t_val.upload(W.val); t_src.upload(src_col); t_dst.upload(dst_off);
+            L->d_wd.reserve((size_t)W.rows * d_ld * 4);
+            launch_densify(t_ptr.as<uint64_t>(), t_idx.as<uint32_t>(), t_val.as<float>(), t_src.as<uint32_t>(), t_dst.as<uint32_t>(),
+                           (uint32_t)c_nnz, W.rows, d_ld, L->d_wd.as<uint32_t>(), nullptr);
+            XRL_HIP(hipStreamSynchronize(nullptr));
+            L->d_dptile.upload(d_ptile); L->d_dtcol.upload(d_tcol);
+            L->dense_bytes = L->d_wd.cap;
+        } else {
+            d_ptile.clear(); d_tcol.clear();
+        }
+    }
     row_idx.push_back(0u);
     L->d_bias_prod.upload(bias_prod);
     L->d_tiles.upload(tiles); L->d_ptile.upload(ptile); L->d_chunk_col.upload(chunk_col);
@@ -478,7 +532,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
                       L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap +
-                      L->d_img.cap + L->d_img_off.cap + L->d_bucket.cap + L->d_bitmap64.cap;
+                      L->d_img.cap + L->d_img_off.cap + L->d_bucket.cap + L->d_bitmap64.cap + L->d_wd.cap + L->d_dptile.cap + L->d_dtcol.cap;
 
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
@@ -495,6 +549,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     d.img = img.empty() ? nullptr : L->d_img.as<uint32_t>(); d.img_off = img.empty() ? nullptr : L->d_img_off.as<uint64_t>();
     d.img_mw = L->img_mw; d.img_shift = L->img_shift; d.img_nbk = L->img_nbk;
     d.bias = bias; d.has_bias = has_bias ? 1 : 0;
+    d.wd = L->dense_bytes ? L->d_wd.as<uint32_t>() : nullptr; d.d_ld = d_ld; d.d_gp_log2 = d_gp_log2; d.d_max_tiles = d_max_tiles;
+    d.d_ptile = L->dense_bytes ? L->d_dptile.as<uint32_t>() : nullptr; d.d_tcol = L->dense_bytes ? L->d_dtcol.as<uint32_t>() : nullptr;
     return L;
 }
 

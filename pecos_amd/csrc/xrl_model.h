@@ -29,6 +29,7 @@ namespace xrl {
 
 constexpr uint32_t kMaxTileCols = 128;       // accumulators per (query, tile) item held in LDS
 constexpr uint32_t kNoBias = 0xFFFFFFFFu;
+constexpr uint32_t kMissing = 0x7FA5A5A5u;   // dense row format: "W has no entry here" (a signalling-NaN pattern no weight file holds)
 constexpr uint64_t kMaxTileImageBytes = 136 * 1024;   // K1T: largest tile image kept in LDS (160 KiB minus wavefront scratch)
 
 enum PPKind : int { PP_NOOP = 0, PP_SIGMOID = 1, PP_LOG_SIGMOID = 2, PP_LP_HINGE = 3, PP_LOG_LP_HINGE = 4 };
@@ -74,6 +75,15 @@ struct LayerDev {
     uint32_t img_mw, img_shift, img_nbk;   // words of the (u16) bucket table, feature-id shift, number of buckets
     float bias;
     int has_bias;
+    // DENSE row format (K1Q, xrl_k1q.hip), nullptr when the layer is held in the tile format only:
+    //   wd[feature * d_ld + (dense tile << d_gp_log2) + column] = weight bits, kMissing where W has no entry.
+    // Dense tiles partition every parent's children into runs of <= 2^d_gp_log2 columns (their own tiling: <= 64 wide).
+    const uint32_t* wd;
+    uint64_t d_ld;               // padded columns per feature row (a multiple of 32: rows start on 128-byte lines)
+    uint32_t d_gp_log2;          // log2 of the padded dense tile width
+    uint32_t d_max_tiles;        // max dense tiles per parent
+    const uint32_t* d_ptile;     // [n_parents+1] dense tiles of parent p
+    const uint32_t* d_tcol;      // [n_dtiles+1] first child column of every dense tile (children are contiguous)
 };
 
 struct Layer {
@@ -98,6 +108,8 @@ struct Layer {
     // device storage
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
     DevBuf d_img, d_img_off, d_bucket, d_bitmap64;
+    DevBuf d_wd, d_dptile, d_dtcol;          // dense row format (see LayerDev::wd)
+    uint64_t dense_bytes = 0;
     uint32_t bk_shift = 0, bk_n = 0, bk_levels = 0;
     LayerDev dev{};
     uint64_t device_bytes = 0;
@@ -142,6 +154,8 @@ struct Model {
                                             // K0/K2 run under the other half's K1; 0 = never (measured on Amazon-670K: 25.9 vs 25.5 ms, no gain)
     int k1t_min_items = 0;                  // run a layer tile-stationary (K1T) once a tile serves at least this many items on average (0 = never)
     int k1t_items_per_block = 1024;
+    int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
+    int k2_legacy = 0;                      // A/B and tests: 1 = round-1 insertion top-k kernels instead of the ballot-bisection K2
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
     bool profiling = false;
     std::vector<ProfileSlot> profile;
@@ -166,6 +180,9 @@ std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_
 void finalize_model(Model& m);
 std::unique_ptr<Model> load_mmap_model_from_disk(const std::string& path);        // xrl_mmap.cpp
 void compile_mmap_model(const std::string& npz_path, const std::string& mmap_path);   // xrl_mmap.cpp
-void ensure_device_csc(Layer& L);   // upload W as CSC (original column ids) if not there yet
+void ensure_device_csc(Layer& L);
+// xrl_k1q.hip: memset wd to kMissing and scatter the CSC columns src_col[c] to padded column dst_off[c]
+void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,
+                    const uint32_t* dst_off, uint32_t n_children, uint32_t w_rows, uint64_t ld, uint32_t* wd, hipStream_t s);   // upload W as CSC (original column ids) if not there yet
 
 }  // namespace xrl

@@ -162,6 +162,11 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             if (l == T - 1) { oi = d_out_idx + row0 * out_stride; ov = d_out_val + row0 * out_stride; oc = d_out_cnt + row0; os = out_stride; }
             else { const int b = (int)(l & 1); oi = lw.beam_idx[b].as<uint32_t>(); ov = lw.beam_val[b].as<float>(); oc = lw.beam_cnt[b].as<uint32_t>(); os = beam_stride; }
 
+            // layers held in the dense row format: the whole layer is one query-stationary kernel (beam in, beam out)
+            if (m.dense_layers && !o.stats_out && k1q_regs(L.dev, beam_in[l], k[l]) != 0) {
+                timed(X.dense ? "k1q_dense_x" : "k1q_dense", (uint32_t)l, [&] { launch_k1q(L.dev, P, X, prev, oi, ov, oc, os, S); });
+                continue;
+            }
             int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
             timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
             const int mode = layer_mode(l, nrows);
@@ -175,7 +180,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                     launch_k1(L.dev, P, X, mode == 1 ? lw.items_sorted.p : lw.items.p, mode == 1 ? lw.sort_start.as<uint32_t>() + L.n_tiles : nullptr,
                               lw.cand.as<float>(), g, S); });
             if (lanes == 2) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
-            timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S); });
+            timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
             if (o.stats_out) launch_stats(L.dev, P, prev, lw.ncand.as<uint32_t>(), ws.stats.as<double>() + 2 * l, S);
         }
     }

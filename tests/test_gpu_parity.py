@@ -70,11 +70,19 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
         m = models[c["model"]]
         X = load_X(os.path.join(GOLDEN, "synth", c["model"] + "__X.npz"), c["x"])
         G = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"]))
+        assert clib.xlinear_get_int_attr(m.model.model_chain, "nr_dense_layers") > 0
+        P = m.predict(X, **c["kwargs"])        # default: fused query-stationary kernel K1Q on the dense row format
+        assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} dense format (K1Q)")
+        clib.set_option(m.model.model_chain, "dense_layers", 0)     # tile format: K0 -> K1 -> K2
         for g in (0, 1, 2, 8, 64):
             clib.set_option(m.model.model_chain, "k1_group", g)
             clib.set_option(m.model.model_chain, "k1t_min_items", 0)
             P = m.predict(X, **c["kwargs"])
             assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} G={g}")
+        clib.set_option(m.model.model_chain, "k2_legacy", 1)        # round-1 insertion top-k kernels
+        P = m.predict(X, **c["kwargs"])
+        assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} legacy K2")
+        clib.set_option(m.model.model_chain, "k2_legacy", 0)
         clib.set_option(m.model.model_chain, "k1_group", 0)
         # tile-stationary kernel forced on every layer whose tiles fit in LDS
         for ipb in (64, 1024):
@@ -82,6 +90,8 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
             clib.set_option(m.model.model_chain, "k1t_items_per_block", ipb)
             P = m.predict(X, **c["kwargs"])
             assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1T ipb={ipb}")
+        clib.set_option(m.model.model_chain, "k1t_min_items", 0)
+        clib.set_option(m.model.model_chain, "dense_layers", 1)
 
 
 @pytest.mark.parametrize("name,scale", [("eurlex-4k", 0.5), ("wiki10-31k", 0.1), ("amazon-670k", 0.02)])
@@ -99,6 +109,15 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} {pp}")
     # model defaults (no overrides), max_pred_chunk slicing, dense queries
     assert_same_topk(m.predict(X), ref.predict(X), exact_scores=True, what="defaults")
+    # dense row format (default, K1Q) vs tile format: same bits, sparse and dense queries, beams wider than K1Q's registers
+    for kw in (dict(beam_size=cfg["beam"], only_topk=10), dict(beam_size=3, only_topk=64), dict(beam_size=70, only_topk=100),
+               dict(beam_size=200, only_topk=5, post_processor="log-sigmoid")):
+        a = m.predict(X, **kw)
+        clib.set_option(m.model.model_chain, "dense_layers", 0)
+        b = m.predict(X, **kw)
+        clib.set_option(m.model.model_chain, "dense_layers", 1)
+        assert_same_topk(a, b, exact_scores=True, what=f"{name} dense vs tile format {kw}")
+    clib.set_option(m.model.model_chain, "dense_layers", 0)     # the remaining checks are about the tile-format kernels
     # two row batches in flight on two streams (default only for large X): same results, also with a ragged tail batch
     for rows in (2, 150):
         clib.set_option(m.model.model_chain, "overlap_min_rows", 2)
@@ -120,6 +139,7 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
     if name != "wiki10-31k":   # its scaled-down leaf tiles (101938 features) do not fit in LDS: K1 serves every layer
         assert "k1t_sparse" in names, names
     clib.set_option(m.model.model_chain, "k1t_min_items", 0)
+    clib.set_option(m.model.model_chain, "dense_layers", 1)
     assert_same_topk(m.predict(X, beam_size=5, only_topk=3, max_pred_chunk=37), ref.predict(X, beam_size=5, only_topk=3),
                      exact_scores=True, what="max_pred_chunk")
     # the same model with every other row lookup structure: bucket table (what layers too large for rank-bitmaps use),
@@ -130,6 +150,7 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
             mb = XLM.load(folder)
         finally:
             os.environ.pop("XRL_LOOKUP", None)
+        clib.set_option(mb.model.model_chain, "dense_layers", 0)   # this loop is about the tile format's row lookups
         if attr:
             assert clib.xlinear_get_int_attr(mb.model.model_chain, attr) == len(ks)
         for pp in (None, "sigmoid"):
@@ -138,8 +159,11 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         del mb
     if X.shape[1] <= 6000:
         Xd = np.ascontiguousarray(X[:64].toarray())
-        assert_same_topk(m.predict(Xd, beam_size=4, only_topk=6), ref.predict(Xd, beam_size=4, only_topk=6),
-                         exact_scores=True, what="dense")
+        for dl in (1, 0):
+            clib.set_option(m.model.model_chain, "dense_layers", dl)
+            assert_same_topk(m.predict(Xd, beam_size=4, only_topk=6), ref.predict(Xd, beam_size=4, only_topk=6),
+                             exact_scores=True, what=f"dense X, dense_layers={dl}")
+        clib.set_option(m.model.model_chain, "dense_layers", 1)
 
 
 def test_full_width_rows_every_lookup(XLM, clib, oracle_mod, tmp_path):
@@ -174,6 +198,8 @@ def test_full_width_rows_every_lookup(XLM, clib, oracle_mod, tmp_path):
         finally:
             os.environ.pop("XRL_LOOKUP", None)
         assert_same_topk(m.predict(X, beam_size=128, only_topk=30), want, exact_scores=True, what=f"full-width rows, lookup={mode}")
+        clib.set_option(m.model.model_chain, "dense_layers", 0)
+        assert_same_topk(m.predict(X, beam_size=128, only_topk=30), want, exact_scores=True, what=f"full-width rows, tile format, lookup={mode}")
         assert_same_topk(m.predict(np.ascontiguousarray(X.toarray()), beam_size=128, only_topk=30),
                          om.predict(np.ascontiguousarray(X.toarray()), beam_size=128, only_topk=30), exact_scores=True, what=f"dense X, lookup={mode}")
 
@@ -379,14 +405,61 @@ def test_full_size_properties(XLM, clib, tmp_path):
     # top-k prefix property: only_topk=5 is the prefix of only_topk=10 at equal beam
     P5 = m.predict(X, beam_size=10, only_topk=5)
     assert np.array_equal(P5.indices.reshape(-1, 5), I[:, :5]) and np.array_equal(P5.data.reshape(-1, 5), D[:, :5])
-    # every lanes-per-item variant gives the same bits
-    for g in (1, 4, 16, 64):
+    # every lanes-per-item variant of the tile-format kernels gives the same bits as the dense-format kernel
+    clib.set_option(m.model.model_chain, "dense_layers", 0)
+    for g in (0, 1, 4, 16, 64):
         clib.set_option(m.model.model_chain, "k1_group", g)
         Pg = m.predict(X, beam_size=10, only_topk=10)
         assert np.array_equal(Pg.indices, P.indices) and np.array_equal(Pg.data.view(np.uint32), P.data.view(np.uint32))
     # device-resident path == host-ABI path; batching of rows does not change results
     clib.set_option(m.model.model_chain, "k1_group", 0)
+    clib.set_option(m.model.model_chain, "dense_layers", 1)
     clib.set_option(m.model.model_chain, "max_batch_rows", 1777)
     Pb = m.predict(X, beam_size=10, only_topk=10)
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)
     assert np.array_equal(Pb.indices, P.indices) and np.array_equal(Pb.data, P.data)
+
+
+def _reference_model(oracle_mod, folder):
+    return oracle_mod.RefModel(folder) if oracle_mod.ref_available() else oracle_mod.OracleModel.load(folder)
+
+
+@pytest.mark.parametrize("name", ["eurlex-4k", "wiki10-31k"])
+def test_full_size_vs_reference(name, XLM, clib, oracle_mod, tmp_path):
+    # BASELINE.json configs[1] and configs[2] at FULL size, every row against the reference (oracle/_ref when built,
+    # else the C restatement): label ids, order and fp32 scores bit-identical, for the dense row format (K1Q where a
+    # layer's candidates fit its registers) and for the tile format (K0 -> K1 -> K2)
+    import xrl_synth
+    folder = str(tmp_path / "m")
+    ks, X, cfg = xrl_synth.make_config(name, folder)
+    m = XLM.load(folder)
+    ref = _reference_model(oracle_mod, folder)
+    kw = dict(beam_size=cfg["beam"], only_topk=10)
+    want = ref.predict(X, threads=32, **kw) if oracle_mod.ref_available() else ref.predict(X, **kw)
+    assert want.shape == (X.shape[0], ks[-1])
+    for dl in (1, 0):
+        clib.set_option(m.model.model_chain, "dense_layers", dl)
+        assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{name} full size, dense_layers={dl}")
+
+
+def test_dense_input_config_vs_reference(XLM, clib, oracle_mod, tmp_path):
+    # BASELINE.json configs[4] (dense fp32 X, D=768) at a tenth of its label count: N=50k x 768, L=300k, tree
+    # [16, 256, 4096, 300000].  Every layer fits the dense row format, so the whole beam search runs in K1Q with dense
+    # queries; 2048 rows are compared with the reference (its dense path costs ~1 M multiply-adds per query), all rows
+    # with the tile-format kernels.
+    import xrl_synth
+    folder = str(tmp_path / "m")
+    ks, X, cfg = xrl_synth.make_config("dense-768", folder, scale=0.1)
+    X = np.ascontiguousarray(X[:50000])
+    m = XLM.load(folder)
+    assert clib.xlinear_get_int_attr(m.model.model_chain, "nr_dense_layers") == len(ks)
+    kw = dict(beam_size=10, only_topk=10)
+    P = m.predict(X, **kw)
+    ref = _reference_model(oracle_mod, folder)
+    ns = 2048
+    want = ref.predict(X[:ns], threads=32, **kw) if oracle_mod.ref_available() else ref.predict(X[:ns], **kw)
+    got = smat.csr_matrix((P.data[:P.indptr[ns]], P.indices[:P.indptr[ns]], P.indptr[:ns + 1]), shape=(ns, P.shape[1]))
+    assert_same_topk(got, want, exact_scores=True, what="dense-768 vs reference")
+    clib.set_option(m.model.model_chain, "dense_layers", 0)
+    Pt = m.predict(X[:8192], **kw)
+    assert np.array_equal(Pt.indices, P.indices[:P.indptr[8192]]) and np.array_equal(Pt.data.view(np.uint32), P.data[:P.indptr[8192]].view(np.uint32))
