@@ -3,23 +3,30 @@
 
     python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
 
-One STEP = one full beam search (all layers: prolongate -> sparse inner products + post-processor
-+ combine -> per-query top-k) over the whole synthetic query batch of the named workload, queries
-already resident in HBM, results left in HBM; with N>1 GPUs the batch is split into N contiguous
-nnz-balanced row shards (strong scaling: total work fixed) and every step ends with the RCCL
-all-gather of the fixed-stride top-k.  Rank 0 prints ONE JSON line.
+One STEP = one full beam search (all layers: prolongate -> inner products + post-processor + combine -> per-query
+top-k) over the whole synthetic query batch of the named workload, queries already resident in HBM, results left in
+HBM; with N>1 GPUs the batch is split into N contiguous nnz-balanced row shards (strong scaling: total work fixed)
+and every step ends with ONE RCCL all-gather of the packed fixed-stride top-k rows.  Rank 0 prints ONE JSON line.
 
-Workload: BASELINE.json's Amazon-670K shape (the configuration its target is quoted on; it fits
-one GPU): N=490,000 queries, D=135,000, L=670,091, tree [2,32,512,8192,670091], beam=10, top-k=10,
-post-processor l3-hinge, synthetic CSR (xrl_synth.py, fixed seeds).
+Workload: BASELINE.json's Amazon-670K shape (the configuration its target is quoted on; it fits one GPU): N=490,000
+queries, D=135,000, L=670,091, tree [2,32,512,8192,670091], beam=10, top-k=10, post-processor l3-hinge, synthetic CSR
+(xrl_synth.py, fixed seeds).  --config eurlex-4k | wiki10-31k | dense-768 (with --scale / --rows) run the other shapes.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel (k1_sparse, all layers): ALGORITHMIC bytes per launch (SURVEY.md 8d:
-                every active reference chunk streamed once, 8E+4R+4(R+1) bytes, + the query row + the
-                scores written) / average launch duration from hipEvent pairs recorded around each
-                launch on its own stream during the timed steps; peak = 8 TB/s HBM.
-  cpu_baseline  the REAL reference (oracle/_ref, compiled from /root/reference's own sources) timed
-                on this box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+On the JSON line:
+  value           queries/s with X resident in HBM when the timed region starts (the contract's `value`)
+  value_host_abi  queries/s through the drop-in entry point c_xlinear_predict_csr_f32 -- pageable host X in, H2D,
+                  kernels, D2H, allocator callback, host CSR out -- the figure SURVEY.md 8(d) specifies (N=1 only)
+  roofline        the kernel family with the most GPU time.  `achieved` = MATCHED-WORK bytes per launch / average launch
+                  duration (hipEvent pairs recorded around every launch on the stream it runs on, during the timed steps).
+                  Matched work = the bytes the algorithm addresses for the rows a query actually matches, NO inter-query
+                  reuse assumed (every item re-reads its query row, its lookups, its matched rows):
+                    tile format (K1):   per (query, tile) item  8*nnz_x + probe_bytes*nnz_x + 4*hit_rows + 8*hit_entries + 4*ncols
+                    dense format (K1Q): per query  8*nnz_x (dense X: 4*D)  + 4 * sum over (feature, candidate column) + 16*beam
+                  counted by an untimed stats pass (xrl_predict_stats).  `alg_bytes_ref_layout` keeps SURVEY.md 8(d)'s own
+                  figure (every active REFERENCE chunk streamed whole) -- an upper bound no implementation that looks rows
+                  up needs to move, which is why round 1's frac came out as 34.  `kernels` lists every launch family.
+  cpu_baseline    the REAL reference (oracle/_ref, compiled from /root/reference's own sources) on this box's host cores,
+                  bounded sample of the same workload, 1 warm-up + median of 5 calls (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -30,6 +37,9 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+L2_PEAK_GBPS = 34500.0          # MI355X_MICROARCH.md: ~34.5 TB/s aggregate L2
+
 
 def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
@@ -38,15 +48,18 @@ def log(*a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="amazon-670k")
     ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--rows", type=int, default=0, help="use only the first ROWS queries of the workload (dense-768)")
     ap.add_argument("--beam", type=int, default=0)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--cache", default="/tmp/xrl_bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-host-abi", action="store_true")
+    ap.add_argument("--host-steps", type=int, default=5)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--k1-group", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="library option key=int (xrl_set_option), repeatable")
     args = ap.parse_args()
@@ -61,13 +74,15 @@ def main():
     if world != args.gpus:
         log(f"WARNING: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get("XRL_BENCH_FORCE_DIST"):   # the latter: exercise RCCL init + the gather with one rank (tests)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
 
     import xrl_synth
     from pecos_amd import XLinearModel, clib
-    from pecos_amd.distributed import shard_bounds, take_rows
+    from pecos_amd.core import ScipyCompressedSparseAllocator, ScipyCsrF32, ScipyDrmF32
+    from pecos_amd.distributed import PackedTopk, shard_bounds, take_rows
 
     cfg = dict(xrl_synth.CONFIGS[args.config])
     beam = args.beam or cfg["beam"]
@@ -85,7 +100,7 @@ def main():
         open(done, "w").write("ok")
     t_wait = time.time()
     while not os.path.exists(done):
-        if time.time() - t_wait > 900:
+        if time.time() - t_wait > 1500:
             raise RuntimeError("timed out waiting for local rank 0 to generate the synthetic workload")
         time.sleep(0.5)
     meta = json.load(open(os.path.join(folder, "meta.json")))
@@ -93,10 +108,16 @@ def main():
     if os.path.exists(os.path.join(folder, "X.npz")):
         X = smat.load_npz(os.path.join(folder, "X.npz")).tocsr().astype(np.float32); X.sort_indices()
     else:
-        X = np.load(os.path.join(folder, "X.npy"))
+        X = np.load(os.path.join(folder, "X.npy"), mmap_mode="r")
+    if args.rows and args.rows < X.shape[0]:
+        X = X[: args.rows]
+    if not smat.issparse(X):
+        X = np.ascontiguousarray(X)
     n_total = X.shape[0]
+    sparse = smat.issparse(X)
+    nnz_row = (X.nnz if sparse else X.size) / max(1, n_total)
     if rank == 0:
-        log(f"workload {args.config} scale={args.scale}: layers={ks} X={X.shape} nnz/row={getattr(X, 'nnz', X.size) / max(1, n_total):.1f} ({time.time() - t0:.1f}s)")
+        log(f"workload {args.config} scale={args.scale}: layers={ks} X={X.shape} nnz/row={nnz_row:.1f} ({time.time() - t0:.1f}s)")
 
     clib.set_device(local)
     t0 = time.time()
@@ -107,44 +128,46 @@ def main():
     for kv in args.opt:
         key, val = kv.split("=")
         clib.set_option(h, key, int(val))
+    depth = len(ks)
+    linfo = [clib.layer_info(h, l) for l in range(depth)]
     if rank == 0:
-        log(f"model on GPU: {clib.model_device_bytes(h) / 1e9:.2f} GB in {time.time() - t0:.1f}s")
+        log(f"model on GPU: {clib.model_device_bytes(h) / 1e9:.2f} GB in {time.time() - t0:.1f}s; dense row format on layers "
+            f"{[l for l in range(depth) if linfo[l]['dense']]}")
 
+    # every rank keeps only ITS rows of X
     bounds = shard_bounds(X, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     Xs = take_rows(X, lo, hi)
+    if world > 1:
+        del X
     q = clib.queries_upload(h, Xs)
     k = clib.effective_topk(h, args.topk)
     rows = hi - lo
     maxr = int(np.diff(bounds).max())
     dev = torch.device("cuda", local)
-    # packed result rows [idx(k) | val(k)] so that ONE all-gather moves both
-    packed = torch.zeros((maxr, 2 * k), dtype=torch.int32, device=dev)
-    cnt = torch.zeros((maxr,), dtype=torch.int32, device=dev)
-    if world > 1:
-        g_packed = torch.empty((world, maxr, 2 * k), dtype=torch.int32, device=dev)
-        g_cnt = torch.empty((world, maxr), dtype=torch.int32, device=dev)
-    # one explicit (non-default) torch stream carries the kernels AND the RCCL all-gathers, so that the gather of a
-    # step is ordered after its predict without a host sync (handle 0 would mean "the library's own stream")
+    # one explicit (non-default) torch stream carries the kernels AND the RCCL all-gather, so that the gather of a step is
+    # ordered after its predict without a host sync (handle 0 would mean "the library's own stream")
     tstream = torch.cuda.Stream(device=dev)
     stream = tstream.cuda_stream
+    with torch.cuda.stream(tstream):
+        pk = PackedTopk(maxr, k, world, dev)      # packed rows [idx(k) | val(k) | cnt]: ONE all-gather per step
+    p_idx, p_val, p_cnt, p_stride = pk.pointers()
+    use_dist = dist.is_initialized()
 
     def step():
         with torch.cuda.stream(tstream):
             if rows:
-                clib.predict_device(h, q, beam, None, args.topk, packed.data_ptr(), packed.data_ptr() + 4 * k, cnt.data_ptr(),
-                                    2 * k, stream=stream, sync=False)
-            if world > 1:
-                dist.all_gather_into_tensor(g_packed, packed)
-                dist.all_gather_into_tensor(g_cnt, cnt)
+                clib.predict_device(h, q, beam, None, args.topk, p_idx, p_val, p_cnt, p_stride, stream=stream, sync=False)
+            if use_dist:
+                pk.gather()
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    torch.cuda.synchronize()        # buffers were zero-filled on the default stream
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -157,63 +180,117 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     clib.profile_enable(h, False)
-    if world > 1:
+    if use_dist and world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = clib.profile_get(h)
-    if rank == 0:
-        log("per-launch ms: " + "  ".join(f"{r['name']}[{r['layer']}]={r['ms'] / max(1, r['launches']):.3f}" for r in prof))
 
     out = None
     if rank == 0:
         ms_per_step = dt / max(1, args.steps) * 1e3
         value = n_total * args.steps / dt
-        # ---- roofline of the dominant kernel (k1, summed over layers) on this rank's shard
-        st = clib.predict_stats(h, q, beam, None, args.topk) if rows else []
-        xbytes = 8.0 * Xs.nnz if smat.issparse(Xs) else 4.0 * Xs.size
-        alg_k1 = sum(cb + 4.0 * ne for cb, ne in st) + xbytes            # bytes per predict
-        fam = {}
-        for r in prof:
-            f = fam.setdefault(r["name"], dict(ms=0.0, launches=0)); f["ms"] += r["ms"]; f["launches"] += r["launches"]
-        dom = max(fam, key=lambda n: fam[n]["ms"]) if fam else None
-        roof = None
-        if dom and dom.startswith("k1"):
-            launches_per_step = fam[dom]["launches"] / max(1, args.steps)
-            avg_ms = fam[dom]["ms"] / max(1, fam[dom]["launches"])
-            per_launch = alg_k1 / max(1.0, launches_per_step)
-            ach = per_launch / (avg_ms * 1e-3) / 1e9
-            traffic, tsrc = None, None
-            tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")   # written from separate rocprofv3 --pmc passes
-            if os.path.exists(tfile):
-                tj = json.load(open(tfile))
-                if tj.get("config") == args.config and tj.get("scale") == args.scale and tj.get("n_gpus") == world:
-                    traffic, tsrc = tj.get("hbm_bytes_per_launch"), tj.get("source")
-            roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4),
-                        traffic=traffic, traffic_source=tsrc, alg_bytes_per_launch=per_launch, avg_launch_ms=round(avg_ms, 4),
-                        launches_per_step=launches_per_step,
-                        per_kernel_ms_per_step={n: round(v["ms"] / max(1, args.steps), 4) for n, v in fam.items()},
-                        per_layer=[dict(layer=r["layer"], ms=round(r["ms"] / max(1, r["launches"]), 4),
-                                        ref_chunk_bytes=st[r["layer"]][0], candidates=st[r["layer"]][1])
-                                   for r in prof if r["name"] == dom],
-                        note="algorithmic bytes assume NO inter-query reuse (SURVEY.md 8d); frac>1 means chunks are served from L2/MALL")
-        cfg_out = dict(workload=f"{args.config} synthetic x{args.scale}: N={n_total} D={X.shape[1]} L={ks[-1]} tree={ks} "
-                                f"nnz/row={getattr(X, 'nnz', X.size) / max(1, n_total):.1f} beam={beam} topk={k} pp=l3-hinge bias=1.0",
-                       parallelism=f"query-shard x{world}" + (" + rccl all-gather(top-k)" if world > 1 else ""),
-                       model_hbm_gb=round(clib.model_device_bytes(h) / 1e9, 3))
+        log("per-launch ms: " + "  ".join(f"{r['name']}[{r['layer']}]={r['ms'] / max(1, r['launches']):.3f}" for r in prof))
+        roof = roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_step)
+        cfg_out = dict(workload=f"{args.config} synthetic x{args.scale}: N={n_total} D={Xs.shape[1]} L={ks[-1]} tree={ks} "
+                                f"nnz/row={nnz_row:.1f} beam={beam} topk={k} pp=l3-hinge bias=1.0",
+                       parallelism=f"query-shard x{world}" + (" + 1 rccl all-gather(packed top-k rows)" if world > 1 else ""),
+                       model_hbm_gb=round(clib.model_device_bytes(h) / 1e9, 3),
+                       dense_format_layers=[l for l in range(depth) if linfo[l]["dense"]])
         out = dict(metric=baseline_metric(), value=round(value, 1), unit="queries/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling="strong", vs_baseline=None, dtype="f32", data="synthetic", config=cfg_out, roofline=roof)
 
+        # ---- the SURVEY 8(d) figure: the drop-in C-ABI entry point, pageable host X in, host CSR out (N=1)
+        if world == 1 and not args.no_host_abi:
+            view = ScipyCsrF32.init_from(Xs) if sparse else ScipyDrmF32.init_from(Xs)
+            times = []
+            for it in range(1 + max(1, args.host_steps)):
+                alloc = ScipyCompressedSparseAllocator()
+                t0 = time.perf_counter()
+                clib.xlinear_predict(h, view, beam, None, args.topk, -1, alloc)
+                t1 = time.perf_counter() - t0
+                if it:
+                    times.append(t1)
+            med = float(np.median(times))
+            out["value_host_abi"] = round(n_total / med, 1)
+            out["host_abi"] = dict(entry="c_xlinear_predict_csr_f32" if sparse else "c_xlinear_predict_drm_f32", ms_per_call=round(med * 1e3, 3),
+                                   calls=len(times), includes="H2D of X from pageable host memory (pinned staging, row batches pipelined with compute), "
+                                   "kernels, D2H, allocator callback, host CSR assembly", x_bytes=int(Xs.nnz * 8 + (rows + 1) * 8) if sparse else int(Xs.size * 4),
+                                   ratio_to_device_resident=round(n_total / med / value, 3))
+            log(f"host ABI: {med * 1e3:.2f} ms per call = {n_total / med / 1e6:.2f} M q/s ({n_total / med / value:.2f} x device-resident)")
+
         # ---- CPU baseline + parity on a bounded sample (N=1 only)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["parity"] = cpu_baseline(folder, X, model, beam, args.topk, args.cpu_seconds, log)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(folder, Xs, model, beam, args.topk, args.cpu_seconds, log)
         print(json.dumps(out), flush=True)
 
     clib.queries_free(q)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_step):
+    import scipy.sparse as smat
+    sparse = smat.issparse(Xs)
+    st = clib.predict_stats(h, q, beam, None, args.topk) if rows else []
+    nnz = float(Xs.nnz) if sparse else float(Xs.size)
+    x_bytes_q = 8.0 * nnz if sparse else 4.0 * nnz               # the query rows read once
+
+    def matched_bytes(name, layer):
+        s, li = st[layer], linfo[layer]
+        if name.startswith("k1q"):                                # dense row format, query-stationary
+            return x_bytes_q + 4.0 * s["x_cols"] + 16.0 * k * rows
+        if name.startswith("k1"):                                 # tile format: per item x row + lookups + extents + matched entries + scores
+            probe = {0: 8.0, 1: 8.0 + 4.0 * li["bucket_levels"], 2: 16.0}[li["lookup"]]
+            if not sparse:                                        # dense X walks every tile row: row id + x value instead of lookups
+                return 8.0 * s["hit_rows"] + 4.0 * s["hit_rows"] + 8.0 * s["hit_entries"] + 4.0 * s["item_cols"]
+            return 8.0 * s["probes"] + probe * s["probes"] + 4.0 * s["hit_rows"] + 8.0 * s["hit_entries"] + 4.0 * s["item_cols"]
+        if name.startswith("k2"):
+            return 4.0 * s["candidates"] + 8.0 * k * rows
+        if name.startswith("k0"):
+            return 32.0 * s["items"] + 8.0 * rows
+        return 0.0
+
+    kernels, fam = [], {}
+    for r in prof:
+        ms = r["ms"] / max(1, r["launches"])
+        mb = matched_bytes(r["name"], r["layer"]) if st else 0.0
+        gbps = mb / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        kernels.append(dict(name=r["name"], layer=r["layer"], ms=round(ms, 4), matched_bytes=mb, gbps=round(gbps, 1), frac_hbm=round(gbps / HBM_PEAK_GBPS, 4)))
+        f = fam.setdefault(r["name"], dict(ms=0.0, launches=0, bytes=0.0))
+        f["ms"] += r["ms"]; f["launches"] += r["launches"]; f["bytes"] += mb * r["launches"]
+    if not fam:
+        return None
+    dom = max(fam, key=lambda n: fam[n]["ms"])
+    launches_per_step = fam[dom]["launches"] / max(1, args.steps)
+    avg_ms = fam[dom]["ms"] / max(1, fam[dom]["launches"])
+    per_launch = fam[dom]["bytes"] / max(1, fam[dom]["launches"])
+    ach = per_launch / (avg_ms * 1e-3) / 1e9
+    step_bytes = sum(kk["matched_bytes"] for kk in kernels)
+    traffic, tsrc, l2 = None, None, None
+    tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")     # written from separate rocprofv3 --pmc passes (scripts/pmc_traffic.py)
+    if os.path.exists(tfile):
+        tj = json.load(open(tfile))
+        ent = tj.get("kernels", {}).get(dom)
+        if tj.get("config") == args.config and tj.get("scale") == args.scale and tj.get("n_gpus") == world and ent:
+            traffic, tsrc = ent.get("hbm_bytes_per_launch"), tj.get("source")
+            if ent.get("l2_read_req_per_launch"):
+                req = ent["l2_read_req_per_launch"]
+                l2b = req * 64.0 / (avg_ms * 1e-3) / 1e9
+                l2 = dict(bound="l2", read_requests_per_launch=req, request_bytes=64, achieved=round(l2b, 1), peak=L2_PEAK_GBPS, unit="GB/s",
+                          frac=round(l2b / L2_PEAK_GBPS, 4), requests_per_s_G=round(req / (avg_ms * 1e-3) / 1e9, 1),
+                          note="TCP_TCC_READ_REQ (L1->L2 read requests) x 64 B / launch time; the gathers of this kernel use 8-16 B of every request")
+    return dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
+                traffic=traffic, traffic_source=tsrc, l2=l2,
+                alg_bytes_per_launch=per_launch, avg_launch_ms=round(avg_ms, 4), launches_per_step=launches_per_step,
+                model="matched work, no inter-query reuse (see bench.py docstring / DESIGN.md section 4)",
+                step_matched_bytes=step_bytes, step_gbps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                alg_bytes_ref_layout=(sum(s["ref_chunk_bytes"] + 4.0 * s["candidates"] for s in st) + x_bytes_q) if st else None,
+                per_kernel_ms_per_step={n: round(v["ms"] / max(1, args.steps), 4) for n, v in fam.items()},
+                kernels=kernels,
+                work=[dict(layer=l, **{kk: st[l][kk] for kk in ("items", "probes", "hit_rows", "hit_entries", "candidates")}) for l in range(len(st))])
 
 
 def baseline_metric():
@@ -225,11 +302,11 @@ def baseline_metric():
 
 
 def cpu_baseline(folder, X, model, beam, topk, budget_s, log):
-    """Time the real reference (oracle/_ref, built from /root/reference's own sources) on this box's
-    host cores on a bounded sample of the workload; fall back to the single-threaded C restatement
-    ("port") when oracle/_ref is absent.  The reference's OpenMP path does not scale to hundreds of
-    threads on a small batch, so the thread count is swept and the BEST is reported (cores = threads
-    used).  Also compares the GPU output with the reference's on that sample."""
+    """Time the real reference (oracle/_ref, built from /root/reference's own sources) on this box's host cores on a
+    bounded sample of the workload; fall back to the single-threaded C restatement ("port") when oracle/_ref is absent.
+    The reference's OpenMP path does not scale to hundreds of threads on a small batch, so the thread count is swept on
+    a small sample first and the best one is used (cores = threads used); then 1 warm-up + median of 5 timed calls
+    (SURVEY.md 8d).  Also compares the GPU output with the reference's on that sample."""
     import numpy as np
     from oracle import xrl_oracle as O
     ncpu = os.cpu_count() or 1
@@ -242,19 +319,24 @@ def cpu_baseline(folder, X, model, beam, topk, budget_s, log):
             rm = O.RefModel(folder, wtype)
             load_s = time.time() - t0
             ns = min(n, 8192)
-            rm.predict(X[:ns], beam_size=beam, only_topk=topk, threads=min(ncpu, 32))   # warm-up (page faults)
+            rm.predict(X[:ns], beam_size=beam, only_topk=topk, threads=min(ncpu, 32))   # page faults
             best = None
             for th in sorted({t for t in (8, 16, 32, 64, 128, ncpu) if t <= ncpu}):
                 t0 = time.perf_counter(); rm.predict(X[:ns], beam_size=beam, only_topk=topk, threads=th); t1 = time.perf_counter() - t0
                 if best is None or ns / t1 > best[0]:
                     best = (ns / t1, th)
             th = best[1]
-            ns = int(min(n, max(ns, best[0] * budget_s / 2)))
-            t0 = time.perf_counter(); P = rm.predict(X[:ns], beam_size=beam, only_topk=topk, threads=th); t1 = time.perf_counter() - t0
+            ns = int(min(n, max(ns, best[0] * budget_s / 2 / 6)))          # 6 calls (warm-up + 5) per layout within the budget
+            Xq = X[:ns]
+            P = rm.predict(Xq, beam_size=beam, only_topk=topk, threads=th)  # warm-up
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); P = rm.predict(Xq, beam_size=beam, only_topk=topk, threads=th); ts.append(time.perf_counter() - t0)
+            t1 = float(np.median(ts))
             results[wtype] = dict(qps=ns / t1, sample=ns, threads=th, load_s=round(load_s, 1))
-            log(f"cpu reference {wtype}: {ns} queries in {t1:.2f}s = {ns / t1:.0f} q/s with {th} threads of {ncpu} (load {load_s:.1f}s)")
+            log(f"cpu reference {wtype}: {ns} queries, median of 5 = {t1:.3f}s ({min(ts):.3f}-{max(ts):.3f}) = {ns / t1:.0f} q/s with {th} threads of {ncpu} (load {load_s:.1f}s)")
             if wtype == "BINARY_SEARCH_CHUNKED":
-                G = model.predict(X[:ns], beam_size=beam, only_topk=topk)
+                G = model.predict(Xq, beam_size=beam, only_topk=topk)
                 same_rows = np.array_equal(G.indptr, P.indptr)
                 same_idx = same_rows and np.array_equal(G.indices, P.indices)
                 rel = float(np.max(np.abs(G.data - P.data) / np.maximum(np.abs(P.data), 1e-30))) if same_rows and P.nnz else None
@@ -265,8 +347,8 @@ def cpu_baseline(folder, X, model, beam, topk, budget_s, log):
             del rm
         bw = max(results, key=lambda w: results[w]["qps"])
         base = dict(value=round(results[bw]["qps"], 1), unit="queries/s", cores=results[bw]["threads"], kind="reference",
-                    sample=f"first {results[bw]['sample']} queries of the workload, layout {bw}, best of a thread sweep "
-                           f"({results[bw]['threads']} OpenMP threads on a {ncpu}-cpu host), 1 warm-up + 1 timed call; other layout: " +
+                    sample=f"first {results[bw]['sample']} queries of the workload, layout {bw}, best thread count of a sweep "
+                           f"({results[bw]['threads']} OpenMP threads on a {ncpu}-cpu host), 1 warm-up + median of 5 timed calls; other layout: " +
                            "; ".join(f"{w}={results[w]['qps']:.0f} q/s @ {results[w]['threads']} thr" for w in results if w != bw))
     else:
         om = O.OracleModel.load(folder)

@@ -199,7 +199,7 @@ uint32_t xrl_effective_topk(void* model, uint32_t only_topk);
  * xrl_profile_get synchronises, folds the pending pairs and fills up to `cap` records; it returns
  * the number of records available. */
 typedef struct {
-    char name[32];          /* kernel family: "k0_prolongate", "k1_sparse", "k1_dense", "k2_topk" */
+    char name[32];          /* kernel family: "k0_prolongate", "k1_sparse", "k1_dense", "k1q_dense", "k1q_dense_x", "k1c_csc", "k2_topk" */
     uint32_t layer;
     uint32_t launches;
     double ms;              /* accumulated GPU time of those launches */
@@ -209,9 +209,12 @@ void xrl_profile_enable(void* model, int enable);
 void xrl_profile_reset(void* model);
 uint32_t xrl_profile_get(void* model, xrl_profile_rec_t* out, uint32_t cap);
 
-/* One untimed predict that also measures, per layer l, stats_out[2l] = algorithmic bytes of the
- * reference-layout chunks streamed (8*E_p + 4*R_p + 4*(R_p+1) per (query, beam parent), SURVEY.md
- * section 8d) and stats_out[2l+1] = candidates evaluated.  stats_cap >= 2*depth.  Returns 0 on success. */
+/* One untimed predict (tile-format kernels) that also counts, per layer l, 8 doubles at stats_out[8l ...]:
+ *   [0] algorithmic bytes of the reference-layout chunks streamed (8*E_p + 4*R_p + 4*(R_p+1) per (query, beam parent),
+ *       every active chunk whole, no inter-query reuse)      [1] candidates evaluated
+ *   [2] (query, tile) items   [3] row lookups (query features x items)   [4] matched tile rows   [5] entries of the matched rows
+ *   [6] tile columns over the items (scores written)   [7] query features x tile columns over the items (dense-format weights)
+ * [2..7] are the MATCHED work bench.py's roofline model is built from.  stats_cap >= 8*depth.  Returns 0 on success. */
 int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char* post_processor,
                       uint32_t only_topk, double* stats_out, uint32_t stats_cap);
 
@@ -232,17 +235,35 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *                         average (0 = never); needs the tile images, i.e. XRL_K1T=1 in the environment at load
  *   "k1t_items_per_block" items per K1T workgroup run
  *   "overlap_min_rows"    split predicts of at least this many rows into two batches on two streams (0 = never)
+ *   "host_pipeline"       1 (default): c_xlinear_predict_* cut a large X into nnz-balanced row batches; batch b+1 is staged into
+ *                         pinned memory and uploaded on a copy stream while batch b computes; 0: one synchronous upload
+ *   "dense_layers"        1 (default): layers that carry the dense row format run the fused query-stationary kernel K1Q
+ *                         whenever the beam's candidates fit its registers; 0: tile-format kernels K0 -> K1 -> K2 everywhere
+ *   "k2_legacy"           1: round-1 insertion top-k kernels instead of the ballot-bisection K2 (A/B, tests)
  *   "k1_wpb", "k1_lds_pad", "k1_ablate"   debug: wavefronts per K1 workgroup, extra LDS per wavefront, phase ablation
  * Environment read at model load: XRL_K1T=1 (build K1T tile images), XRL_LOOKUP=bitmap|bitmap64|bucket (force the row
  * lookup structure; default per layer: bucket table if rank-bitmaps would take more than a quarter of the free HBM, else
  * 64-feature words carrying the first row's extent on sparse tiles, else 32-feature words),
  * XRL_ROW_ALIGN=0 (keep tile rows packed instead of line-aligned), XRL_MAX_TILE_ENTRIES (lower the tile splitter's
- * limit; tests). */
+ * limit; tests), XRL_DENSE=0 (never build the dense row format), XRL_DENSE_MAX_MB (cap of one layer's dense matrix;
+ * default 65536, and never more than a quarter of the free HBM). */
 int xrl_set_option(void* model, const char* key, int64_t value);
 
 /* Debug: with option k1_ablate bit 6 set, K1 accumulates per-phase shader cycles
  * [prologue, fill, D1, D3, epilogue, #waves, -, -]; this reads (and optionally resets) them. */
 void xrl_debug_k1_phases(unsigned long long* out8, int reset);
+
+/* Single-layer API (c_xlinear_single_layer_predict*): compiled one-layer handles are cached by the identity of the caller's
+ * W / C arrays (pointers, shapes, nnz, bias) plus a fingerprint of their contents, at most 8 entries, least recently used
+ * evicted.  Clear the cache after modifying W / C in place.  stats: cumulative hits / misses and live entries (tests). */
+void xrl_single_layer_cache_clear(void);
+void xrl_single_layer_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* entries);
+
+/* Device layout of one layer: out[0..12) = {row lookup of the tile format (0 = 32-feature rank-bitmap, 1 = bucket table,
+ * 2 = 64-feature words with the first row's extent), bucket search levels, carries the dense row format (0/1), padded dense
+ * tile width, padded columns per dense row, tiles, weights (entries), bytes of the dense matrix, W.rows, children kept,
+ * widest tile, bytes of HBM}.  Returns the number of values available. */
+uint32_t xrl_layer_info(void* model, uint32_t layer, uint64_t* out, uint32_t cap);
 
 /* Bytes of HBM held by the compiled model. */
 uint64_t xrl_model_device_bytes(void* model);

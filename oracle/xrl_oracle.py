@@ -323,3 +323,80 @@ class RefModel:
         fn(self.h, C.byref(px), C.byref(ps), pp, threads, cb)
         return smat.csr_matrix((res["data"], res["indices"].astype(np.int64), res["indptr"].astype(np.int64)),
                                shape=res["shape"])
+
+
+# ---------------------------------------------------------------------------------------------
+# The real reference's single-layer and inner-product entry points (libpecos.cpp:201-235, 337-355)
+# ---------------------------------------------------------------------------------------------
+class _CscF32(C.Structure):  # pecos/core/utils/matrix.hpp:56-62
+    _fields_ = [("rows", C.c_uint32), ("cols", C.c_uint32), ("col_ptr", C.c_void_p),
+                ("row_idx", C.c_void_p), ("val", C.c_void_p)]
+
+
+def _ref_x(X, keep):
+    if smat.issparse(X):
+        X = smat.csr_matrix(X, dtype=np.float32); X.sort_indices()
+        b = (X.indptr.astype(np.uint64), X.indices.astype(np.uint32), X.data.astype(np.float32))
+        keep.append(b)
+        return _CsrF32(X.shape[0], X.shape[1], b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data), "csr"
+    b = np.ascontiguousarray(X, np.float32)
+    keep.append(b)
+    return _DrmF32(b.shape[0], b.shape[1], b.ctypes.data), "drm"
+
+
+def _ref_csc(M, keep, sort=True):
+    M = smat.csc_matrix(M, dtype=np.float32)
+    if sort:
+        M.sort_indices()
+    b = (M.indptr.astype(np.uint64), M.indices.astype(np.uint32), M.data.astype(np.float32))
+    keep.append(b)
+    return _CscF32(M.shape[0], M.shape[1], b[0].ctypes.data, b[1].ctypes.data, b[2].ctypes.data)
+
+
+def ref_single_layer_predict(X, csr_codes, W, Cm, post_processor, only_topk, bias, threads=8):
+    """c_xlinear_single_layer_predict_{csr,drm}_f32 of the real reference: MLModel<csc_t> around W / C, i.e. the CSC
+    arithmetic (bias first, dot product summed separately; inference.hpp:1018-1149)."""
+    lib = C.CDLL(REF_SO)
+    keep, res = [], {}
+
+    def alloc(is_col_major, rows, cols, nnz, indices_pp, indptr_pp, data_pp):
+        res["indptr"] = np.zeros(rows + 1, np.uint64); res["indices"] = np.zeros(nnz, np.uint32)
+        res["data"] = np.zeros(nnz, np.float32); res["shape"] = (rows, cols)
+        C.cast(indices_pp, C.POINTER(C.c_uint64)).contents.value = res["indices"].ctypes.data
+        C.cast(indptr_pp, C.POINTER(C.c_uint64)).contents.value = res["indptr"].ctypes.data
+        C.cast(data_pp, C.POINTER(C.c_uint64)).contents.value = res["data"].ctypes.data
+
+    cb = _ALLOC(alloc)
+    px, kind = _ref_x(X, keep)
+    fn = getattr(lib, f"c_xlinear_single_layer_predict_{kind}_f32")
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_uint32, C.c_int, C.c_float, _ALLOC]
+    pcodes = None
+    if csr_codes is not None:
+        S = smat.csr_matrix(csr_codes, dtype=np.float32)      # stored order kept: it is the beam order
+        sb = (S.indptr.astype(np.uint64), S.indices.astype(np.uint32), S.data.astype(np.float32)); keep.append(sb)
+        pcodes = _CsrF32(S.shape[0], S.shape[1], sb[0].ctypes.data, sb[1].ctypes.data, sb[2].ctypes.data)
+    pw = _ref_csc(W, keep)
+    pc = _ref_csc(Cm, keep, sort=False)                       # C keeps its STORED child order (tie-break)
+    fn(C.byref(px), C.byref(pcodes) if pcodes is not None else None, C.byref(pw), C.byref(pc), post_processor.encode(),
+       only_topk, threads, bias, cb)
+    return smat.csr_matrix((res["data"], res["indices"].astype(np.int64), res["indptr"].astype(np.int64)), shape=res["shape"])
+
+
+def ref_sparse_inner_products(X, W, rows, cols, threads=8):
+    """c_sparse_inner_products_{csr2csc,drm2csc,csr2dcm,drm2dcm}_f32 of the real reference."""
+    lib = C.CDLL(REF_SO)
+    keep = []
+    px, xk = _ref_x(X, keep)
+    if smat.issparse(W):
+        pw, wk = _ref_csc(W, keep), "csc"
+    else:
+        wb = np.asfortranarray(W, np.float32); keep.append(wb)
+        pw, wk = _DrmF32(wb.shape[0], wb.shape[1], wb.ctypes.data), "dcm"     # ScipyDcmF32 has the same fields
+    rows = np.ascontiguousarray(rows, np.uint32); cols = np.ascontiguousarray(cols, np.uint32)
+    out = np.zeros(len(rows), np.float32)
+    fn = getattr(lib, f"c_sparse_inner_products_{xk}2{wk}_f32")
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    fn(C.byref(px), C.byref(pw), len(rows), rows.ctypes.data, cols.ctypes.data, out.ctypes.data, threads)
+    return out

@@ -204,6 +204,9 @@ class corelib(object):
             "xrl_set_option": (c_int, [c_void_p, c_char_p, c_int64]),
             "xrl_model_device_bytes": (c_uint64, [c_void_p]),
             "xrl_debug_k1_phases": (None, [POINTER(c_uint64), c_int]),
+            "xrl_layer_info": (c_uint32, [c_void_p, c_uint32, POINTER(c_uint64), c_uint32]),
+            "xrl_single_layer_cache_clear": (None, []),
+            "xrl_single_layer_cache_stats": (None, [POINTER(c_uint64), POINTER(c_uint64), POINTER(c_uint64)]),
         }
         for name, (res, args) in sigs.items():
             fn = getattr(lib, name)
@@ -257,7 +260,7 @@ class corelib(object):
             self._lib.c_xlinear_destruct_model(c_void_p(c_model))
 
     def xlinear_get_int_attr(self, c_model, attr):
-        assert attr in {"depth", "nr_features", "nr_labels", "nr_codes", "nr_pred_cols", "nr_bucket_layers", "nr_bitmap64_layers", "nr_k1t_layers", "nr_dense_layers"}, f"attr {attr} not implemented"
+        assert attr in {"depth", "nr_features", "nr_labels", "nr_codes", "nr_pred_cols", "nr_bucket_layers", "nr_bitmap64_layers", "nr_k1t_layers", "nr_dense_layers", "device"}, f"attr {attr} not implemented"
         v = self.clib_float32.c_xlinear_get_int_attr(c_void_p(c_model), c_char_p(attr.encode("utf-8")))
         self._check()
         return v
@@ -460,14 +463,16 @@ class corelib(object):
                 for i in range(n)]
 
     def predict_stats(self, c_model, queries, beam_size, post_processor, only_topk):
-        """Untimed predict returning per layer (reference-chunk bytes streamed, candidates evaluated)."""
+        """Untimed predict (tile-format kernels) returning per layer a dict of work counters: ref_chunk_bytes (SURVEY.md 8d:
+        every active reference chunk streamed whole), candidates, items, probes, hit_rows, hit_entries, item_cols, x_cols."""
         depth = self.xlinear_get_int_attr(c_model, "depth")
-        out = (c_double * (2 * depth))()
+        out = (c_double * (8 * depth))()
         self.clib_float32.xrl_predict_stats(c_void_p(c_model), c_void_p(queries), beam_size or 0,
                                             post_processor.encode("utf-8") if post_processor else None,
-                                            only_topk or 0, out, 2 * depth)
+                                            only_topk or 0, out, 8 * depth)
         self._check()
-        return [(out[2 * l], out[2 * l + 1]) for l in range(depth)]
+        keys = ("ref_chunk_bytes", "candidates", "items", "probes", "hit_rows", "hit_entries", "item_cols", "x_cols")
+        return [dict(zip(keys, [out[8 * l + i] for i in range(8)])) for l in range(depth)]
 
     def set_option(self, c_model, key, value):
         self.clib_float32.xrl_set_option(c_void_p(c_model), key.encode("utf-8"), int(value))
@@ -478,6 +483,23 @@ class corelib(object):
         self.clib_float32.xrl_debug_k1_phases(out, 1 if reset else 0)
         self._check()
         return [int(v) for v in out]
+
+    def single_layer_cache_clear(self):
+        """Drop every cached single-layer handle (call after modifying W / C in place)."""
+        self.clib_float32.xrl_single_layer_cache_clear()
+
+    def single_layer_cache_stats(self):
+        h, m, e = c_uint64(0), c_uint64(0), c_uint64(0)
+        self.clib_float32.xrl_single_layer_cache_stats(byref(h), byref(m), byref(e))
+        return dict(hits=int(h.value), misses=int(m.value), entries=int(e.value))
+
+    def layer_info(self, c_model, layer):
+        out = (c_uint64 * 12)()
+        self.clib_float32.xrl_layer_info(c_void_p(c_model), layer, out, 12)
+        self._check()
+        keys = ("lookup", "bucket_levels", "dense", "dense_tile_width", "dense_ld", "tiles", "entries", "dense_bytes", "w_rows",
+                "children", "max_tile_cols", "device_bytes")
+        return dict(zip(keys, [int(v) for v in out]))
 
     def model_device_bytes(self, c_model):
         return int(self.clib_float32.xrl_model_device_bytes(c_void_p(c_model)))

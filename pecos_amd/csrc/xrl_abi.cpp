@@ -2,7 +2,11 @@
 // exceptions and records them for xrl_last_error(); nothing is ever thrown across the C boundary.
 #include "../../include/xrl_abi.h"
 
+#include <algorithm>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "xrl_predict.h"
 
@@ -52,22 +56,64 @@ void upload_drm(const ScipyDrmF32* X, DevBuf& val, QueriesDev& d) {
     d.rows = X->rows; d.cols = X->cols; d.dense = 1; d.nnz = 0;
 }
 
+// Host-side worker threads for the bulk copies of the host ABI (staging X into pinned memory, writing the result CSR):
+// one thread moves ~6-10 GB/s, which would make a 300 MB X the slowest stage of the pipeline below.
+template <class F> void parallel_ranges(size_t n, size_t min_per_thread, F&& fn) {
+    unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
+    nt = std::min(nt, std::max(1u, std::thread::hardware_concurrency()));
+    if (nt <= 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    std::exception_ptr err; std::mutex emu;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+            try { fn(n * t / nt, n * (t + 1) / nt); }
+            catch (...) { std::lock_guard<std::mutex> g(emu); err = std::current_exception(); }
+        });
+    for (auto& t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+void parallel_copy(void* dst, const void* src, size_t bytes) {
+    parallel_ranges(bytes, 4u << 20, [&](size_t b, size_t e) { std::memcpy((char*)dst + b, (const char*)src + b, e - b); });
+}
+
 // csr_t::create_pycsr, pecos/core/utils/matrix.hpp:300-316: one synchronous allocator call, then copy.
 void emit_csr(uint32_t rows, uint32_t cols, uint32_t stride, const uint32_t* idx, const float* val,
               const uint32_t* cnt, py_sparse_allocator_t alloc) {
-    uint64_t nnz = 0;
-    for (uint32_t r = 0; r < rows; ++r) nnz += cnt[r];
+    std::vector<uint64_t> ptr((size_t)rows + 1);
+    ptr[0] = 0;
+    for (uint32_t r = 0; r < rows; ++r) ptr[r + 1] = ptr[r] + std::min(cnt[r], stride);
+    const uint64_t nnz = ptr[rows];
     uint32_t* o_idx = nullptr; uint64_t* o_ptr = nullptr; float* o_val = nullptr;
     alloc(false, rows, cols, nnz, &o_idx, &o_ptr, &o_val);
     if (!o_ptr || (nnz && (!o_idx || !o_val))) fail("allocator callback returned null buffers");
-    uint64_t w = 0;
-    o_ptr[0] = 0;
-    for (uint32_t r = 0; r < rows; ++r) {
-        std::memcpy(o_idx + w, idx + (size_t)r * stride, (size_t)cnt[r] * 4);
-        std::memcpy(o_val + w, val + (size_t)r * stride, (size_t)cnt[r] * 4);
-        w += cnt[r];
-        o_ptr[r + 1] = w;
+    parallel_ranges((size_t)rows + 1, 1u << 16, [&](size_t b, size_t e) { std::memcpy(o_ptr + b, ptr.data() + b, (e - b) * 8); });
+    if (nnz == (uint64_t)rows * stride) {          // every row full: the fixed-stride buffers ARE the CSR arrays
+        parallel_copy(o_idx, idx, nnz * 4); parallel_copy(o_val, val, nnz * 4);
+        return;
     }
+    parallel_ranges(rows, 1u << 15, [&](size_t b, size_t e) {
+        for (size_t r = b; r < e; ++r) {
+            const size_t n = (size_t)(ptr[r + 1] - ptr[r]);
+            std::memcpy(o_idx + ptr[r], idx + r * stride, n * 4);
+            std::memcpy(o_val + ptr[r], val + r * stride, n * 4);
+        }
+    });
+}
+
+void reserve_outputs(Model& m, uint32_t rows, uint32_t k) {
+    Workspace& ws = *m.ws;
+    const size_t cells = (size_t)rows * k;
+    ws.out_idx.reserve(cells * 4); ws.out_val.reserve(cells * 4); ws.out_cnt.reserve((size_t)rows * 4);
+    ws.h_idx.reserve(cells * 4); ws.h_val.reserve(cells * 4); ws.h_cnt.reserve((size_t)rows * 4);
+}
+
+void download_rows(Model& m, uint32_t r0, uint32_t r1, uint32_t k) {
+    Workspace& ws = *m.ws;
+    if (r1 <= r0) return;
+    const size_t o = (size_t)r0 * k, n = (size_t)(r1 - r0) * k;
+    XRL_HIP(hipMemcpyAsync(ws.h_idx.as<uint32_t>() + o, ws.out_idx.as<uint32_t>() + o, n * 4, hipMemcpyDeviceToHost, m.stream));
+    XRL_HIP(hipMemcpyAsync(ws.h_val.as<float>() + o, ws.out_val.as<float>() + o, n * 4, hipMemcpyDeviceToHost, m.stream));
+    XRL_HIP(hipMemcpyAsync(ws.h_cnt.as<uint32_t>() + r0, ws.out_cnt.as<uint32_t>() + r0, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, m.stream));
 }
 
 void run_and_emit(Model& m, const QueriesDev& X, const PredictOpts& o, py_sparse_allocator_t alloc) {
@@ -75,30 +121,104 @@ void run_and_emit(Model& m, const QueriesDev& X, const PredictOpts& o, py_sparse
     const Layer& last = *m.layers.back();
     const uint32_t k = effective_topk(m, o.only_topk);
     const uint32_t out_cols = last.reordered ? last.c_rows : last.w_cols;   // inference.hpp:1776-1784
-    const size_t cells = (size_t)X.rows * k;
-    ws.out_idx.reserve(cells * 4); ws.out_val.reserve(cells * 4); ws.out_cnt.reserve((size_t)X.rows * 4);
-    ws.h_idx.reserve(cells * 4); ws.h_val.reserve(cells * 4); ws.h_cnt.reserve((size_t)X.rows * 4);
+    reserve_outputs(m, X.rows, k);
     predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, false);
-    XRL_HIP(hipMemcpyAsync(ws.h_idx.p, ws.out_idx.p, cells * 4, hipMemcpyDeviceToHost, m.stream));
-    XRL_HIP(hipMemcpyAsync(ws.h_val.p, ws.out_val.p, cells * 4, hipMemcpyDeviceToHost, m.stream));
-    XRL_HIP(hipMemcpyAsync(ws.h_cnt.p, ws.out_cnt.p, (size_t)X.rows * 4, hipMemcpyDeviceToHost, m.stream));
+    download_rows(m, 0, X.rows, k);
     XRL_HIP(hipStreamSynchronize(m.stream));
     emit_csr(X.rows, out_cols, k, ws.h_idx.as<uint32_t>(), ws.h_val.as<float>(), ws.h_cnt.as<uint32_t>(), alloc);
 }
 
+// The host ABI (c_xlinear_predict_{csr,drm}_f32) hands over PAGEABLE host arrays.  Large inputs are cut into nnz-balanced
+// row batches and pipelined: batch b+1 is copied into pinned staging memory by host threads and travels over PCIe on a copy
+// stream while batch b's kernels run; every batch's results start their way back as soon as its last kernel is queued.
+// The allocator callback is invoked once, synchronously, on the calling thread, after everything has finished
+// (pecos/core/base.py:431-464 discipline).  Small inputs take the single-batch path.
 template <class XT>
 void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, uint32_t topk,
                   py_sparse_allocator_t alloc, bool is_csr) {
     Model& m = *as_model(ptr);
     if (!alloc) fail("null allocator callback");
+    if (!input_x) fail("null X");
     std::lock_guard<std::mutex> g(m.mu);
     use_device(m.device);
     if (!m.ws) m.ws = std::make_unique<Workspace>();
-    QueriesDev X{};
-    if (is_csr) upload_csr(reinterpret_cast<const ScipyCsrF32*>(input_x), m.ws->x_ptr, m.ws->x_idx, m.ws->x_val, X);
-    else upload_drm(reinterpret_cast<const ScipyDrmF32*>(input_x), m.ws->x_val, X);
+    Workspace& ws = *m.ws;
     PredictOpts o; o.beam_size = beam; o.only_topk = topk; o.post_processor = pp;
-    run_and_emit(m, X, o, alloc);
+    const ScipyCsrF32* Xs = is_csr ? reinterpret_cast<const ScipyCsrF32*>(input_x) : nullptr;
+    const ScipyDrmF32* Xd = is_csr ? nullptr : reinterpret_cast<const ScipyDrmF32*>(input_x);
+    const uint32_t rows = is_csr ? Xs->rows : Xd->rows;
+    const uint64_t elems = is_csr ? (rows ? Xs->row_ptr[rows] : 0) : (uint64_t)rows * Xd->cols;
+    const uint64_t bytes = elems * (is_csr ? 8u : 4u);
+    const uint32_t n_batch = (m.host_pipeline && bytes >= (32ull << 20) && rows >= 8192)
+                                 ? (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, bytes / (24ull << 20))) : 1u;
+    QueriesDev X{};
+    if (n_batch == 1) {
+        if (is_csr) upload_csr(Xs, ws.x_ptr, ws.x_idx, ws.x_val, X);
+        else upload_drm(Xd, ws.x_val, X);
+        run_and_emit(m, X, o, alloc);
+        return;
+    }
+    // ---- batch boundaries: equal shares of the elements (CSR: of the nnz -- cost follows nnz, not rows)
+    std::vector<uint32_t> rb(n_batch + 1, rows);
+    rb[0] = 0;
+    for (uint32_t b = 1; b < n_batch; ++b) {
+        if (is_csr) rb[b] = (uint32_t)(std::lower_bound(Xs->row_ptr, Xs->row_ptr + rows + 1, elems * b / n_batch) - Xs->row_ptr);
+        else rb[b] = (uint32_t)((uint64_t)rows * b / n_batch);
+        rb[b] = std::min(std::max(rb[b], rb[b - 1]), rows);
+    }
+    auto elem_at = [&](uint32_t r) -> uint64_t { return is_csr ? Xs->row_ptr[r] : (uint64_t)r * Xd->cols; };
+    uint64_t max_elems = 0;
+    for (uint32_t b = 0; b < n_batch; ++b) max_elems = std::max(max_elems, elem_at(rb[b + 1]) - elem_at(rb[b]));
+    if (is_csr) {
+        ws.x_ptr.upload_raw(Xs->row_ptr, ((size_t)rows + 1) * 8);
+        ws.x_idx.reserve(elems * 4); ws.x_val.reserve(elems * 4);
+        X.row_ptr = ws.x_ptr.as<uint64_t>(); X.col_idx = ws.x_idx.as<uint32_t>(); X.val = ws.x_val.as<float>();
+        X.rows = rows; X.cols = Xs->cols; X.dense = 0; X.nnz = elems;
+    } else {
+        ws.x_val.reserve(elems * 4);
+        X.row_ptr = nullptr; X.col_idx = nullptr; X.val = ws.x_val.as<float>();
+        X.rows = rows; X.cols = Xd->cols; X.dense = 1; X.nnz = 0;
+    }
+    for (uint32_t b = 0; b < n_batch; ++b) o.reserve_rows = std::max(o.reserve_rows, rb[b + 1] - rb[b]);
+    for (int s2 = 0; s2 < 2; ++s2) ws.stage[s2].reserve(max_elems * (is_csr ? 8u : 4u));
+    if (!m.copy_stream) XRL_HIP(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
+    hipEvent_t up[2];
+    for (auto& e : up) XRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const uint32_t k = effective_topk(m, o.only_topk);
+    reserve_outputs(m, rows, k);
+    try {
+        for (uint32_t b = 0; b < n_batch; ++b) {
+            const int slot = (int)(b & 1u);
+            const uint64_t e0 = elem_at(rb[b]), n = elem_at(rb[b + 1]) - e0;
+            if (b >= 2) XRL_HIP(hipEventSynchronize(up[slot]));        // the slot's previous upload has left the staging buffer
+            char* st = ws.stage[slot].as<char>();
+            if (n) {
+                if (is_csr) {
+                    parallel_copy(st, Xs->col_idx + e0, n * 4); parallel_copy(st + n * 4, Xs->val + e0, n * 4);
+                    XRL_HIP(hipMemcpyAsync(ws.x_idx.as<uint32_t>() + e0, st, n * 4, hipMemcpyHostToDevice, m.copy_stream));
+                    XRL_HIP(hipMemcpyAsync(ws.x_val.as<float>() + e0, st + n * 4, n * 4, hipMemcpyHostToDevice, m.copy_stream));
+                } else {
+                    parallel_copy(st, Xd->val + e0, n * 4);
+                    XRL_HIP(hipMemcpyAsync(ws.x_val.as<float>() + e0, st, n * 4, hipMemcpyHostToDevice, m.copy_stream));
+                }
+            }
+            XRL_HIP(hipEventRecord(up[slot], m.copy_stream));
+            XRL_HIP(hipStreamWaitEvent(m.stream, up[slot], 0));         // batch b's kernels start when its rows have arrived
+            if (rb[b + 1] > rb[b]) {
+                predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, false,
+                               rb[b], rb[b + 1] - rb[b]);
+                download_rows(m, rb[b], rb[b + 1], k);
+            }
+        }
+        XRL_HIP(hipStreamSynchronize(m.stream));
+    } catch (...) {
+        (void)hipStreamSynchronize(m.copy_stream); (void)hipStreamSynchronize(m.stream);
+        for (auto& e : up) (void)hipEventDestroy(e);
+        throw;
+    }
+    for (auto& e : up) (void)hipEventDestroy(e);
+    const Layer& last = *m.layers.back();
+    emit_csr(rows, last.reordered ? last.c_rows : last.w_cols, k, ws.h_idx.as<uint32_t>(), ws.h_val.as<float>(), ws.h_cnt.as<uint32_t>(), alloc);
 }
 
 HostCsc host_csc(const ScipyCscF32* M, const char* what) {
@@ -112,8 +232,10 @@ HostCsc host_csc(const ScipyCscF32* M, const char* what) {
 }
 
 std::unique_ptr<Model> model_from_arrays(uint32_t depth, const ScipyCscF32* const* W, const ScipyCscF32* const* C,
-                                         const float* bias, const uint32_t* only_topk, const char* const* pp) {
+                                         const float* bias, const uint32_t* only_topk, const char* const* pp, bool csc_route = false) {
     auto m = std::make_unique<Model>();
+    m->csc_route = csc_route;
+    if (csc_route) m->weight_matrix_type = 0;
     m->device = g_device;
     for (uint32_t d = 0; d < depth; ++d) {
         HostCsc w = host_csc(W[d], "W");
@@ -124,38 +246,120 @@ std::unique_ptr<Model> model_from_arrays(uint32_t depth, const ScipyCscF32* cons
             c.row_idx.resize(w.cols); c.val.assign(w.cols, 1.f);
             for (uint32_t i = 0; i < w.cols; ++i) c.row_idx[i] = i;
         }
-        m->layers.push_back(compile_layer(w, c, bias[d], only_topk[d], pp[d] ? pp[d] : "noop"));
+        m->layers.push_back(compile_layer(w, c, bias[d], only_topk[d], pp[d] ? pp[d] : "noop", nullptr, 0, csc_route));
         m->layers.back()->w_host = std::make_shared<HostCsc>(std::move(w));
     }
     finalize_model(*m);
     return m;
 }
 
+// ---- single-layer API (libpecos.cpp:201-274): the reference builds a temporary MLModel<csc_t> around the caller's W / C
+// on every call.  Here the compiled one-layer handle (tree bookkeeping + W in CSC form on the device) is CACHED, keyed
+// by the identity of the caller's arrays (pointers, shapes, nnz, bias) plus a fingerprint of their contents, so that
+// loops which call the layer again and again with the same weights -- MAN negative mining (xmc/base.py:1562-1563), the
+// matcher -> ranker hand-off -- pay the compile + upload once.  xrl_single_layer_cache_clear() drops every entry (call it
+// after modifying W / C in place).
+struct SlKey {
+    const void *wp, *wi, *wv, *cp, *ci;
+    uint32_t wr, wc, cr, cc; uint64_t wnnz, cnnz; float bias; uint64_t fp; int device;
+    bool operator==(const SlKey& o) const {
+        return wp == o.wp && wi == o.wi && wv == o.wv && cp == o.cp && ci == o.ci && wr == o.wr && wc == o.wc && cr == o.cr &&
+               cc == o.cc && wnnz == o.wnnz && cnnz == o.cnnz && bias == o.bias && fp == o.fp && device == o.device;
+    }
+};
+struct SlEntry { SlKey key; std::shared_ptr<Model> model; uint64_t stamp; };
+std::mutex g_sl_mu;
+std::vector<SlEntry> g_sl_cache;
+uint64_t g_sl_clock = 0, g_sl_hits = 0, g_sl_misses = 0;
+constexpr size_t kSlCacheCap = 8;
+
+uint64_t fingerprint(uint64_t h, const void* data, size_t elems, size_t elem_bytes, size_t samples) {
+    // FNV-1a over up to `samples` evenly spaced elements (first and last included)
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    if (!p || !elems) return h;
+    const size_t n = std::min(elems, samples);
+    for (size_t i = 0; i < n; ++i) {
+        const size_t at = n == 1 ? 0 : (size_t)((double)i * (double)(elems - 1) / (double)(n - 1));
+        for (size_t b = 0; b < elem_bytes; ++b) { h ^= p[at * elem_bytes + b]; h *= 1099511628211ull; }
+    }
+    return h;
+}
+
+std::shared_ptr<Model> single_layer_model(const ScipyCscF32* W, const ScipyCscF32* C, float bias) {
+    if (!W) fail("null W");
+    SlKey k{};
+    k.wp = W->col_ptr; k.wi = W->row_idx; k.wv = W->val; k.wr = W->rows; k.wc = W->cols; k.wnnz = W->cols ? W->col_ptr[W->cols] : 0;
+    k.cp = C ? (const void*)C->col_ptr : nullptr; k.ci = C ? (const void*)C->row_idx : nullptr;
+    k.cr = C ? C->rows : 0; k.cc = C ? C->cols : 0; k.cnnz = (C && C->cols) ? C->col_ptr[C->cols] : 0;
+    k.bias = bias; k.device = g_device;
+    uint64_t h = 1469598103934665603ull;
+    h = fingerprint(h, W->col_ptr, (size_t)W->cols + 1, 8, 4096);
+    h = fingerprint(h, W->row_idx, k.wnnz, 4, 1024);
+    h = fingerprint(h, W->val, k.wnnz, 4, 1024);
+    if (C) { h = fingerprint(h, C->col_ptr, (size_t)C->cols + 1, 8, 4096); h = fingerprint(h, C->row_idx, k.cnnz, 4, 4096); }
+    k.fp = h;
+    {
+        std::lock_guard<std::mutex> g(g_sl_mu);
+        for (auto& e : g_sl_cache) if (e.key == k) { e.stamp = ++g_sl_clock; ++g_sl_hits; return e.model; }
+        ++g_sl_misses;
+    }
+    const ScipyCscF32* Wp = W; const ScipyCscF32* Cp = C;
+    const uint32_t topk = 0; const char* pps = "noop";     // per call: only_topk and the post-processor arrive through PredictOpts
+    std::shared_ptr<Model> m = model_from_arrays(1, &Wp, &Cp, &bias, &topk, &pps, /*csc_route=*/true);
+    m->ws = std::make_unique<Workspace>();
+    ensure_device_csc(*m->layers[0]);
+    std::lock_guard<std::mutex> g(g_sl_mu);
+    if (g_sl_cache.size() >= kSlCacheCap) {
+        size_t victim = 0;
+        for (size_t i = 1; i < g_sl_cache.size(); ++i) if (g_sl_cache[i].stamp < g_sl_cache[victim].stamp) victim = i;
+        g_sl_cache.erase(g_sl_cache.begin() + victim);
+    }
+    g_sl_cache.push_back(SlEntry{k, m, ++g_sl_clock});
+    return m;
+}
+
 template <class XT>
 void single_layer_predict(const XT* input_x, bool is_csr, const ScipyCsrF32* csr_codes, ScipyCscF32* W, ScipyCscF32* C,
                           const char* pp, uint32_t only_topk, float bias, py_sparse_allocator_t alloc) {
-    // libpecos.cpp:201-235: a temporary one-layer model around caller-owned W / C.
+    // libpecos.cpp:201-235: MLModel<csc_t> around caller-owned W / C -> the CSC arithmetic (K1C), bit for bit
     require_gpu();
     use_device(g_device);
     if (!alloc) fail("null allocator callback");
-    const ScipyCscF32* Wp = W; const ScipyCscF32* Cp = C;
     const char* pps = pp ? pp : "noop";
-    auto m = model_from_arrays(1, &Wp, &Cp, &bias, &only_topk, &pps);
-    m->ws = std::make_unique<Workspace>();
-    Workspace& ws = *m->ws;
+    std::shared_ptr<Model> mp = single_layer_model(W, C, bias);
+    Model& m = *mp;
+    std::lock_guard<std::mutex> g(m.mu);
+    Workspace& ws = *m.ws;
     QueriesDev X{};
     if (is_csr) upload_csr(reinterpret_cast<const ScipyCsrF32*>(input_x), ws.x_ptr, ws.x_idx, ws.x_val, X);
     else upload_drm(reinterpret_cast<const ScipyDrmF32*>(input_x), ws.x_val, X);
-    PredictOpts o; o.only_topk = only_topk; o.post_processor = pps;
+    PredictOpts o; o.only_topk = only_topk; o.post_processor = pps; o.csc_route = true;
+    if (only_topk == 0) fail("only_topk must be positive");
     BeamDev init{};
-    const uint32_t P = m->layers[0]->c_cols;
+    const Layer& L = *m.layers[0];
+    const uint32_t P = L.c_cols;
     std::vector<uint32_t> hi, hc; std::vector<float> hv;
     uint32_t stride = 1;
     const bool with_codes = csr_codes != nullptr;
     if (with_codes) {
         if (csr_codes->rows != X.rows) fail("Instance dimension of query and prev_layer_pred matrix do not match");
         if (csr_codes->cols != P) fail("Label dimension of prev_layer_pred and C matrix do not match");
-        for (uint32_t r = 0; r < X.rows; ++r) stride = std::max<uint32_t>(stride, (uint32_t)(csr_codes->row_ptr[r + 1] - csr_codes->row_ptr[r]));
+        // every parent id must exist; a row may list a parent more than once (a non-canonical CSR): the reference
+        // prolongates each occurrence, so the candidate row is sized from the real per-row sum of chunk sizes
+        uint64_t bound = 1;
+        for (uint32_t r = 0; r < X.rows; ++r) {
+            const uint64_t b = csr_codes->row_ptr[r], e = csr_codes->row_ptr[r + 1];
+            if (e < b) fail("csr_codes: row_ptr is not monotone");
+            stride = std::max<uint32_t>(stride, (uint32_t)(e - b));
+            uint64_t sum = 0;
+            for (uint64_t t = b; t < e; ++t) {
+                const uint32_t p = csr_codes->col_idx[t];
+                if (p >= P) fail("csr_codes: parent id " + std::to_string(p) + " out of range (C has " + std::to_string(P) + " columns)");
+                sum += L.h_c_ptr[p + 1] - L.h_c_ptr[p];
+            }
+            bound = std::max(bound, sum);
+        }
+        o.initial_cand_bound = bound;
         hi.assign((size_t)X.rows * stride, 0); hv.assign((size_t)X.rows * stride, 0.f); hc.assign(X.rows, 0);
         for (uint32_t r = 0; r < X.rows; ++r) {
             const uint64_t b = csr_codes->row_ptr[r], e = csr_codes->row_ptr[r + 1];
@@ -173,7 +377,7 @@ void single_layer_predict(const XT* input_x, bool is_csr, const ScipyCsrF32* csr
         o.initial = &init; o.initial_max = stride;
     }
     o.no_prev_pred = !with_codes;   // combine only when csr_codes were given (libpecos.cpp:215-222)
-    run_and_emit(*m, X, o, alloc);
+    run_and_emit(m, X, o, alloc);
 }
 
 template <class XT>
@@ -205,11 +409,9 @@ void single_layer_selected(const XT* input_x, bool is_csr, const ScipyCsrF32* S,
     use_device(g_device);
     if (!alloc) fail("null allocator callback");
     if (!S) fail("null selected_outputs_csr");
-    const ScipyCscF32* Wp = W; const ScipyCscF32* Cp = C;
     const char* pps = pp ? pp : "noop";
-    const uint32_t topk = 0;
-    auto m = model_from_arrays(1, &Wp, &Cp, &bias, &topk, &pps);
-    m->ws = std::make_unique<Workspace>();
+    std::shared_ptr<Model> m = single_layer_model(W, C, bias);
+    std::lock_guard<std::mutex> g(m->mu);
     QueriesDev X{};
     if (is_csr) upload_csr(reinterpret_cast<const ScipyCsrF32*>(input_x), m->ws->x_ptr, m->ws->x_idx, m->ws->x_val, X);
     else upload_drm(reinterpret_cast<const ScipyDrmF32*>(input_x), m->ws->x_val, X);
@@ -334,6 +536,7 @@ uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
         else if (!std::strcmp(attr, "nr_features")) v = m.nr_features;
         else if (!std::strcmp(attr, "nr_labels")) v = m.nr_labels;
         else if (!std::strcmp(attr, "nr_codes")) v = m.nr_codes;
+        else if (!std::strcmp(attr, "device")) v = (uint32_t)m.device;   // additive: the GPU the handle lives on
         else if (!std::strcmp(attr, "nr_pred_cols")) {   // additive: column count of predict()'s CSR
             const Layer& last = *m.layers.back();
             v = last.reordered ? last.c_rows : last.w_cols;
@@ -421,6 +624,16 @@ void c_xlinear_single_layer_predict_on_selected_outputs_drm_f32(const ScipyDrmF3
                                                                 const float bias, py_sparse_allocator_t pred_alloc) {
     (void)num_threads;
     guarded([&] { single_layer_selected(input_x, false, selected_outputs_csr, csr_codes, W, C, post_processor_str, bias, pred_alloc); });
+}
+
+void xrl_single_layer_cache_clear(void) {
+    guarded([&] { std::lock_guard<std::mutex> g(g_sl_mu); g_sl_cache.clear(); });
+}
+void xrl_single_layer_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* entries) {
+    std::lock_guard<std::mutex> g(g_sl_mu);
+    if (hits) *hits = g_sl_hits;
+    if (misses) *misses = g_sl_misses;
+    if (entries) *entries = g_sl_cache.size();
 }
 
 void c_sparse_inner_products_csr2csc_f32(const ScipyCsrF32* pX, const ScipyCscF32* pW, uint64_t len, uint32_t* r, uint32_t* c, float* val, int threads) {
@@ -531,7 +744,7 @@ int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char
     guarded([&] {
         Model& m = *as_model(model);
         if (!queries || !stats_out) fail("xrl_predict_stats: null argument");
-        if (stats_cap < 2 * m.layers.size()) fail("xrl_predict_stats: stats_out too small (need 2*depth doubles)");
+        if (stats_cap < kStatsPerLayer * m.layers.size()) fail("xrl_predict_stats: stats_out too small (need 8*depth doubles)");
         std::lock_guard<std::mutex> g(m.mu);
         use_device(m.device);
         if (!m.ws) m.ws = std::make_unique<Workspace>();
@@ -592,6 +805,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         if (!std::strcmp(key, "k1_group")) m.k1_group = (int)value;
         else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
         else if (!std::strcmp(key, "sort_min_tiles")) m.sort_min_tiles = (int)value;
+        else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;   // 0: the host ABI uploads X in one piece before computing
         else if (!std::strcmp(key, "dense_layers")) m.dense_layers = (int)value;   // 0: never run the fused dense-format kernel K1Q
         else if (!std::strcmp(key, "k2_legacy")) m.k2_legacy = (int)value;        // debug / A-B: round-1 insertion top-k
         else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
@@ -607,6 +821,21 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
 }
 
 void xrl_debug_k1_phases(unsigned long long* out8, int reset) { guarded([&] { k1_phase_read(out8, reset != 0); }); }
+
+uint32_t xrl_layer_info(void* model, uint32_t layer, uint64_t* out, uint32_t cap) {
+    uint32_t n = 0;
+    guarded([&] {
+        Model& m = *as_model(model);
+        if (layer >= m.layers.size()) fail("xrl_layer_info: layer out of range");
+        const Layer& L = *m.layers[layer];
+        const uint64_t rec[12] = {
+            (uint64_t)(L.dev.bucket ? 1 : (L.dev.bitmap64 ? 2 : 0)), L.bk_levels, (uint64_t)(L.dev.wd ? 1 : 0), 1ull << L.dev.d_gp_log2,
+            L.dev.d_ld, L.n_tiles, L.nnz, L.dense_bytes, L.w_rows, L.n_children, L.max_tile_cols, L.device_bytes};
+        n = 12;
+        for (uint32_t i = 0; i < n && i < cap && out; ++i) out[i] = rec[i];
+    });
+    return n;
+}
 
 uint64_t xrl_model_device_bytes(void* model) {
     uint64_t v = 0;

@@ -56,8 +56,10 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
                     uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, bool legacy = false /* round-1 insertion kernels (A/B) */);
 // stats: sum over (query, parent) of the reference chunk's algorithmic bytes, and of candidates
-void launch_stats(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* ncand,
-                  double* out2 /* [0]=chunk bytes, [1]=candidates */, hipStream_t s);
+constexpr int kStatsPerLayer = 8;   // [0] reference-chunk bytes, [1] candidates, [2] items, [3] probes, [4] matched rows, [5] their entries,
+                                    // [6] tile columns over the items, [7] query features x tile columns over the items
+void launch_stats(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, const uint32_t* ncand, const void* items,
+                  double* out8, hipStream_t s);
 // K3  sparse_inner_products (pecos/core/utils/matrix.hpp:1049-1060), 4 layout combos
 void launch_k3_inner_products(const uint64_t* x_ptr, const uint32_t* x_idx, const float* x_val, int x_dense,
                               const uint64_t* w_ptr, const uint32_t* w_idx, const float* w_val, int w_dense,
@@ -74,6 +76,9 @@ void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const 
                         const QueriesDev& X, const uint32_t* pair_q, const uint32_t* node, const uint32_t* ppos,
                         const uint64_t* prev_off, const float* prev_val, float* out_val, uint64_t n_pairs,
                         const PostProc& pp, int first_layer, hipStream_t s);
+// K1C (xrl_pairs.hip): the CSC route of a layer (w_ops<csc_t>, inference.hpp:1081-1149) over the candidates K0 laid out
+void launch_k1c_csc(const LayerDev& L, const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const LayerPlan& P,
+                    const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* ncand, float* cand, hipStream_t s);
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
 // K1Q (xrl_k1q.hip): a whole layer -- prolongate, chunk products against the DENSE row format, post-processor,
 // combine, top-k, child re-ordering -- in one query-stationary kernel: previous beam in, next beam out.

@@ -1157,138 +1157,57 @@ stats_kernel(const float* __restrict__ chunk_alg, uint32_t nrows, uint32_t beam_
     if (threadIdx.x == 0) { atomicAdd(&out2[0], sb[0]); atomicAdd(&out2[1], sc[0]); }
 }
 
-void launch_stats(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* ncand, double* out2,
-                  hipStream_t s) {
+// matched work per (query, tile) item, counted by walking the item's query features against the tile's sorted row ids
+// (independent of the row lookup structure the layer uses): out[0] items, [1] probes (= query features), [2] matched rows,
+// [3] entries of the matched rows, [4] tile columns (scores written), [5] query features x tile columns (dense-format MACs)
+__global__ void __launch_bounds__(256)
+stats_items_kernel(LayerDev L, QueriesDev X, const ItemDesc* __restrict__ items, uint64_t n_slots, uint32_t row0, double* out6) {
+    __shared__ double sh[6][256];
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    if (i < n_slots) {
+        const ItemDesc it = items[i];
+        if (it.tile != kNoTile) {
+            const TileDesc td = L.tiles[it.tile];
+            const uint32_t* __restrict__ ridx = L.row_idx + td.rowptr_base;
+            const uint32_t* __restrict__ rext = L.row_ext + td.rowptr_base;
+            uint32_t hits = 0, nx = 0; uint64_t ent = 0;
+            if (X.dense) {
+                nx = X.cols;
+                const uint32_t nr = td.bias_slot != kNoBias ? td.nrows - 1 : td.nrows;
+                hits = nr;
+                for (uint32_t r = 0; r < nr; ++r) ent += (rext[r] >> 25) + 1u;
+            } else {
+                nx = it.x_len;
+                uint32_t lo = 0;
+                for (uint32_t t = 0; t < it.x_len; ++t) {
+                    const uint32_t f = X.col_idx[it.x_begin + t];
+                    uint32_t a = lo, b = td.nrows;
+                    while (a < b) { const uint32_t mid = (a + b) >> 1; if (ridx[mid] < f) a = mid + 1; else b = mid; }
+                    lo = a;
+                    if (a < td.nrows && ridx[a] == f) { ++hits; ent += (rext[a] >> 25) + 1u; }
+                }
+            }
+            v[0] = 1; v[1] = nx; v[2] = hits; v[3] = (double)ent; v[4] = td.ncols; v[5] = (double)nx * td.ncols;
+        }
+    }
+    for (int k = 0; k < 6; ++k) sh[k][threadIdx.x] = v[k];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) for (int k = 0; k < 6; ++k) sh[k][threadIdx.x] += sh[k][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) atomicAdd(&out6[threadIdx.x], sh[threadIdx.x][0]);
+}
+
+void launch_stats(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, const uint32_t* ncand, const void* items,
+                  double* out8, hipStream_t s) {
     if (P.nrows == 0) return;
     hipLaunchKernelGGL(stats_kernel, dim3((P.nrows + 255) / 256), dim3(256), 0, s, L.chunk_alg_bytes, P.nrows,
-                       P.beam_in, P.implicit_root, prev.idx, prev.cnt, prev.stride, ncand, out2);
-    XRL_LAUNCH_CHECK();
-}
-
-// ---------------------------------------------------------------------------------------------
-// K4: predict_on_selected_outputs, one layer: one thread per (query, selected node) pair against the
-// CSC column (vector_ops::inner_product, inference.hpp:1018-1078):
-//   sparse X: res = 0; res += bias*w_bias (explicit entry only); res += dot(x, w)  [dot summed separately]
-//   dense  X: bias>0: res = bias*w_bias, then res += x[idx]*w over the non-bias entries, in order
-//             bias<=0: dot over all entries
-// then transform, and combine with the parent's value (prolongate_sparse_predictions, :1302-1358).
-// ---------------------------------------------------------------------------------------------
-struct K4Args {
-    const uint64_t* col_ptr; const uint32_t* row_idx; const float* val;   // W in CSC, ORIGINAL column ids
-    QueriesDev X;
-    const uint32_t* pair_q; const uint32_t* node; const uint32_t* ppos;
-    const uint64_t* prev_off;    // [rows+1] offsets of the previous layer's per-query lists
-    const float* prev_val;
-    float* out_val;
-    uint64_t n_pairs;
-    uint32_t w_rows;
-    float bias;
-    int pp_kind, pp_p, first_layer;
-};
-
-template <int PPC>
-__global__ void __launch_bounds__(256) k4_selected_kernel(K4Args a) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= a.n_pairs) return;
-    const uint32_t q = a.pair_q[i], j = a.node[i];
-    const uint64_t cb = a.col_ptr[j], ce = a.col_ptr[j + 1];
-    const bool use_bias = a.bias > 0.0f;
-    const bool has_b = use_bias && ce > cb && a.row_idx[ce - 1] == a.w_rows - 1;
-    float res = 0.0f;
-    if (a.X.dense) {
-        const float* __restrict__ x = a.X.val + (uint64_t)q * a.X.cols;
-        uint64_t range = ce;
-        if (use_bias && has_b) { range = ce - 1; res = __fadd_rn(res, __fmul_rn(a.bias, a.val[ce - 1])); }
-        for (uint64_t e = cb; e < range; ++e) {
-            const uint32_t f = a.row_idx[e];
-            res = __fadd_rn(res, __fmul_rn(f < a.X.cols ? x[f] : 0.0f, a.val[e]));
-        }
-    } else {
-        if (has_b) res = __fadd_rn(res, __fmul_rn(a.bias, a.val[ce - 1]));
-        float dot = 0.0f;
-        uint64_t s = a.X.row_ptr[q];
-        const uint64_t se = a.X.row_ptr[q + 1];
-        uint64_t t = cb;
-        if ((ce - cb) > 8 * (se - s)) {          // long column: x-driven binary search, same ascending order
-            for (; s < se && t < ce; ++s) {
-                const uint32_t f = a.X.col_idx[s];
-                uint64_t lo = t, hi = ce;
-                while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (a.row_idx[mid] < f) lo = mid + 1; else hi = mid; }
-                t = lo;
-                if (t < ce && a.row_idx[t] == f) { dot = __fadd_rn(dot, __fmul_rn(a.X.val[s], a.val[t])); ++t; }
-            }
-        } else {
-            while (s < se && t < ce) {
-                const uint32_t fx = a.X.col_idx[s], fw = a.row_idx[t];
-                if (fx == fw) { dot = __fadd_rn(dot, __fmul_rn(a.X.val[s], a.val[t])); ++s; ++t; }
-                else if (fx < fw) ++s;
-                else ++t;
-            }
-        }
-        res = __fadd_rn(res, dot);
-    }
-    float v = pp_transform<PPC>(a.pp_kind, a.pp_p, res);
-    if (!a.first_layer) v = pp_combine(a.pp_kind, v, a.prev_val[a.prev_off[q] + a.ppos[i]]);
-    a.out_val[i] = v;
-}
-
-void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, uint32_t w_rows, float bias,
-                        const QueriesDev& X, const uint32_t* pair_q, const uint32_t* node, const uint32_t* ppos,
-                        const uint64_t* prev_off, const float* prev_val, float* out_val, uint64_t n_pairs,
-                        const PostProc& pp, int first_layer, hipStream_t s) {
-    if (n_pairs == 0) return;
-    K4Args a;
-    a.col_ptr = col_ptr; a.row_idx = row_idx; a.val = val; a.X = X; a.pair_q = pair_q; a.node = node; a.ppos = ppos;
-    a.prev_off = prev_off; a.prev_val = prev_val; a.out_val = out_val; a.n_pairs = n_pairs; a.w_rows = w_rows; a.bias = bias;
-    a.pp_kind = pp.kind; a.pp_p = pp.p; a.first_layer = first_layer;
-    const uint64_t blocks = (n_pairs + 255) / 256;
-    if (blocks > 0x7FFFFFFFull) fail("k4: too many (query, label) pairs in one call");
-    if (pp_class(pp)) hipLaunchKernelGGL(k4_selected_kernel<1>, dim3((uint32_t)blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(k4_selected_kernel<0>, dim3((uint32_t)blocks), dim3(256), 0, s, a);
-    XRL_LAUNCH_CHECK();
-}
-
-// ---------------------------------------------------------------------------------------------
-// K3: sparse_inner_products, one thread per (row, col) pair, sequential fp32 accumulation in
-// ascending index order (do_dot_product overloads, matrix.hpp:836-877)
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k3_kernel(const uint64_t* __restrict__ x_ptr, const uint32_t* __restrict__ x_idx, const float* __restrict__ x_val,
-          int x_dense, const uint64_t* __restrict__ w_ptr, const uint32_t* __restrict__ w_idx,
-          const float* __restrict__ w_val, int w_dense, uint32_t dim, uint64_t len,
-          const uint32_t* __restrict__ rows, const uint32_t* __restrict__ cols, float* __restrict__ out) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= len) return;
-    const uint32_t r = rows[i], c = cols[i];
-    float ret = 0.f;
-    if (x_dense && w_dense) {
-        const float* x = x_val + (uint64_t)r * dim; const float* w = w_val + (uint64_t)c * dim;
-        for (uint32_t d = 0; d < dim; ++d) ret = __fadd_rn(ret, __fmul_rn(x[d], w[d]));
-    } else if (x_dense) {
-        const float* x = x_val + (uint64_t)r * dim;
-        for (uint64_t s = w_ptr[c]; s < w_ptr[c + 1]; ++s) ret = __fadd_rn(ret, __fmul_rn(x[w_idx[s]], w_val[s]));
-    } else if (w_dense) {
-        const float* w = w_val + (uint64_t)c * dim;
-        for (uint64_t s = x_ptr[r]; s < x_ptr[r + 1]; ++s) ret = __fadd_rn(ret, __fmul_rn(w[x_idx[s]], x_val[s]));
-    } else {
-        uint64_t s = x_ptr[r], se = x_ptr[r + 1], t = w_ptr[c], te = w_ptr[c + 1];
-        while (s < se && t < te) {
-            const uint32_t a = x_idx[s], b = w_idx[t];
-            if (a == b) { ret = __fadd_rn(ret, __fmul_rn(x_val[s], w_val[t])); ++s; ++t; }
-            else if (a < b) ++s;
-            else ++t;
-        }
-    }
-    out[i] = ret;
-}
-
-void launch_k3_inner_products(const uint64_t* x_ptr, const uint32_t* x_idx, const float* x_val, int x_dense,
-                              const uint64_t* w_ptr, const uint32_t* w_idx, const float* w_val, int w_dense,
-                              uint32_t dim, uint64_t len, const uint32_t* rows, const uint32_t* cols,
-                              float* out, hipStream_t s) {
-    if (len == 0) return;
-    hipLaunchKernelGGL(k3_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, s, x_ptr, x_idx, x_val,
-                       x_dense, w_ptr, w_idx, w_val, w_dense, dim, len, rows, cols, out);
+                       P.beam_in, P.implicit_root, prev.idx, prev.cnt, prev.stride, ncand, out8);
+    const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
+    hipLaunchKernelGGL(stats_items_kernel, dim3((uint32_t)((n_slots + 255) / 256)), dim3(256), 0, s, L, X,
+                       static_cast<const ItemDesc*>(items), n_slots, P.row0, out8 + 2);
     XRL_LAUNCH_CHECK();
 }
 

@@ -19,6 +19,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cstring>
 #include <fstream>
 
@@ -194,17 +195,30 @@ std::unique_ptr<Model> load_mmap_model_from_disk(const std::string& path) {
 
 // c_xlinear_compile_mmap_model (libpecos.cpp:133-138): npz folder -> mmap folder, byte layout as above
 // (make_chunked_from_csc, inference.hpp:557-650; rearrangement_t, :1746-1824; save_mmap, :2575-2595).
+static void make_dirs(const std::string& path) {
+    // mkdir -p without a shell: the path comes straight from the caller (C ABI / Python)
+    if (path.empty()) fail("Cannot create folder: empty path");
+    for (size_t i = 1; i <= path.size(); ++i) {
+        if (i != path.size() && path[i] != '/') continue;
+        const std::string part = path.substr(0, i);
+        if (::mkdir(part.c_str(), 0777) != 0 && errno != EEXIST)
+            fail("Cannot create folder " + part + ": " + std::strerror(errno));
+    }
+    struct stat st;
+    if (::stat(path.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) fail("Cannot create folder: " + path + " exists and is not a directory");
+}
+
 void compile_mmap_model(const std::string& npz_path, const std::string& mmap_path) {
     const JsonValue meta = parse_json_file(npz_path + "/param.json");
     const JsonValue* dv = meta.get("depth");
     if (!dv || dv->type != JsonValue::NUMBER) fail(npz_path + "/param.json: missing \"depth\"");
     if (const JsonValue* mm = meta.get("is_mmap")) if (mm->type == JsonValue::BOOL && mm->b) fail("This folder contains mmap model. Cannot load in npz format.");
     const int depth = (int)dv->num;
-    if (::system(("mkdir -p '" + mmap_path + "'").c_str()) != 0) fail("Cannot create folder: " + mmap_path);
+    make_dirs(mmap_path);
     { std::ofstream o(mmap_path + "/param.json"); o << "{\n\"model\": \"HierarchicalMLModel\",\n\"depth\": " << depth << ",\n\"is_mmap\": true\n}\n"; }
     for (int d = 0; d < depth; ++d) {
         const std::string lp = npz_path + "/" + std::to_string(d) + ".model", op = mmap_path + "/" + std::to_string(d) + ".model";
-        if (::system(("mkdir -p '" + op + "'").c_str()) != 0) fail("Cannot create folder: " + op);
+        make_dirs(op);
         float bias; uint32_t topk; std::string pp;
         read_layer_params(lp, bias, topk, pp);
         { std::ofstream o(op + "/param.json");

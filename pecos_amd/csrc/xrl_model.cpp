@@ -50,6 +50,7 @@ Model::Model() {}
 Model::~Model() {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }
 uint64_t Model::device_bytes() const {
@@ -135,9 +136,13 @@ static bool k1t_images_enabled() {
     return e && e[0] && e[0] != '0';
 }
 
-std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float bias, uint32_t only_topk,
+std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, float bias, uint32_t only_topk,
                                      const std::string& post_processor, const std::vector<uint32_t>* perm_inv_override,
-                                     uint32_t orig_rows) {
+                                     uint32_t orig_rows, bool structure_only) {
+    // structure_only: compile the same tree around an EMPTY weight pattern (no tile rows, no dense matrix, tiny bucket tables)
+    HostCsc W_empty;
+    if (structure_only) { W_empty.rows = W_full.rows; W_empty.cols = W_full.cols; W_empty.col_ptr.assign((size_t)W_full.cols + 1, 0); }
+    const HostCsc& W = structure_only ? W_empty : W_full;
     auto L = std::make_unique<Layer>();
     L->w_rows = W.rows; L->w_cols = W.cols; L->c_rows = C.rows; L->c_cols = C.cols;
     L->bias = bias; L->only_topk = only_topk; L->pp_name = post_processor;
@@ -224,7 +229,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
         size_t free_b = 0, total_b = 0;
         const bool have = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
         const char* lk = std::getenv("XRL_LOOKUP");
-        if (lk && !std::strcmp(lk, "bucket")) use_bucket = true;
+        if (structure_only) use_bucket = true;
+        else if (lk && !std::strcmp(lk, "bucket")) use_bucket = true;
         else if (lk && !std::strcmp(lk, "bitmap")) use_bucket = false;
         else if (lk && !std::strcmp(lk, "bitmap64")) use_bm64 = true;
         else {
@@ -463,7 +469,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float b
     uint32_t d_gp_log2 = 0, d_max_tiles = 0; uint64_t d_ld = 0;
     {
         const char* de = std::getenv("XRL_DENSE");
-        bool want = !(de && de[0] == '0') && c_nnz > 0 && W.rows > 0;
+        bool want = !(de && de[0] == '0') && c_nnz > 0 && W.rows > 0 && !structure_only;
         // a column with duplicate or unsorted row ids cannot be scattered into one cell per (feature, column)
         for (uint32_t c = 0; want && c < W.cols; ++c)
             for (uint64_t e = W.col_ptr[c] + 1; e < W.col_ptr[c + 1]; ++e)
@@ -594,6 +600,7 @@ std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_
     auto m = std::make_unique<Model>();
     XRL_HIP(hipGetDevice(&m->device));
     m->weight_matrix_type = weight_matrix_type;
+    m->csc_route = weight_matrix_type == 0;
     for (int d = 0; d < depth; ++d) {
         const std::string lp = path + "/" + std::to_string(d) + ".model";
         const JsonValue p = parse_json_file(lp + "/param.json");     // MLModelMetadata, inference.hpp:101-157
@@ -613,8 +620,12 @@ std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_
         } else {
             load_csc_npz(lp + "/C.npz", C);
         }
-        m->layers.push_back(compile_layer(W, C, (float)bias->num, (uint32_t)topk->num, pp->str));
+        // weight_matrix_type CSC (pecos/core/base.py:49): the reference then runs w_ops<csc_t> (inference.hpp:1081-1149) --
+        // bias first, dot product summed separately -- which differs from the chunked arithmetic in the last bits
+        const bool csc = weight_matrix_type == 0;
+        m->layers.push_back(compile_layer(W, C, (float)bias->num, (uint32_t)topk->num, pp->str, nullptr, 0, csc));
         m->layers.back()->w_path = lp + "/W.npz";
+        if (csc) m->layers.back()->w_host = std::make_shared<HostCsc>(std::move(W));
     }
     finalize_model(*m);
     return m;

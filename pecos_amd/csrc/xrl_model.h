@@ -133,6 +133,7 @@ struct Workspace {
     DevBuf x_ptr, x_idx, x_val;
     DevBuf out_idx, out_val, out_cnt;
     PinnedBuf h_idx, h_val, h_cnt;
+    PinnedBuf stage[2];   // double-buffered pinned staging of the pipelined host-ABI upload
     // initial beam for the single-layer API
     DevBuf init_idx, init_val, init_cnt;
 };
@@ -144,6 +145,8 @@ struct Model {
     uint32_t nr_features = 0, nr_labels = 0, nr_codes = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;       // second lane of the batch pipeline
+    hipStream_t copy_stream = nullptr;      // H2D of the pipelined host-ABI path
+    int host_pipeline = 1;                  // host ABI: cut large X into row batches whose upload overlaps the previous batch's kernels
     std::vector<hipEvent_t> events;         // cross-stream ordering (timing disabled), reused across predicts
     std::mutex mu;                          // one predict at a time per handle
     std::unique_ptr<Workspace> ws;
@@ -155,6 +158,7 @@ struct Model {
     int k1t_min_items = 0;                  // run a layer tile-stationary (K1T) once a tile serves at least this many items on average (0 = never)
     int k1t_items_per_block = 1024;
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
+    bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
     int k2_legacy = 0;                      // A/B and tests: 1 = round-1 insertion top-k kernels instead of the ballot-bisection K2
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
     bool profiling = false;
@@ -172,9 +176,12 @@ uint64_t layout_tile_rows(const uint32_t* rptr, uint32_t nrows, bool align, uint
 // Build one layer from host CSC W / C (LayerData<chunked>::init, inference.hpp:1849-1883).
 // perm_inv_override / orig_rows: W and C are already in the rearranged (contiguous) child order and the
 // given map takes rearranged -> original ids (mmap model folders, LayerData::init_mmap :1885-1908).
+// structure_only: keep the tree bookkeeping (chunks, child order, perm) but no weights in the tile / dense formats --
+// layers that run the CSC route (K1C, xrl_pairs.hip) read W in CSC form instead.
 std::unique_ptr<Layer> compile_layer(const HostCsc& W, const HostCsc& C, float bias, uint32_t only_topk,
                                      const std::string& post_processor,
-                                     const std::vector<uint32_t>* perm_inv_override = nullptr, uint32_t orig_rows = 0);
+                                     const std::vector<uint32_t>* perm_inv_override = nullptr, uint32_t orig_rows = 0,
+                                     bool structure_only = false);
 // Load <path>/param.json + {d}.model/ (HierarchicalMLModel::load, inference.hpp:2616-2655).
 std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_matrix_type);
 void finalize_model(Model& m);

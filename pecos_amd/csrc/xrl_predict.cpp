@@ -23,8 +23,12 @@ uint32_t effective_topk(const Model& m, uint32_t only_topk) {
 }
 
 void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_t* d_out_idx, float* d_out_val,
-                    uint32_t* d_out_cnt, uint32_t out_stride, hipStream_t stream, bool sync) {
+                    uint32_t* d_out_cnt, uint32_t out_stride, hipStream_t stream, bool sync, uint32_t row_begin, uint32_t row_count) {
     const size_t T = m.layers.size();
+    // rows [row_begin, row_end) of X (results land at the same rows of the output buffers); default: all rows
+    if (row_begin > X.rows) fail("predict: row range outside X");
+    const uint64_t row_end = std::min<uint64_t>(X.rows, (uint64_t)row_begin + row_count);
+    const uint64_t n_rows = row_end - row_begin;
     if (!m.ws) m.ws = std::make_unique<Workspace>();
     Workspace& ws = *m.ws;
     if (!stream) stream = m.stream;
@@ -40,6 +44,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     std::vector<uint32_t> k(T), beam_in(T), cstride(T);
     std::vector<PostProc> pp(T);
     const bool has_init = o.initial != nullptr;
+    const bool csc = o.csc_route || m.csc_route;
     for (size_t l = 0; l < T; ++l) {
         const Layer& L = *m.layers[l];
         const uint32_t ov = (l == T - 1) ? o.only_topk : o.beam_size;
@@ -50,7 +55,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                                 : std::min<uint64_t>(k[l - 1], cstride[l - 1]);
         bin = std::min<uint64_t>(bin, L.c_cols ? L.c_cols : 1);
         beam_in[l] = (uint32_t)std::max<uint64_t>(1, bin);
-        const uint64_t cb = std::max<uint64_t>(1, L.cand_bound(beam_in[l]));
+        const uint64_t cb = std::max<uint64_t>(1, (l == 0 && has_init && o.initial_cand_bound) ? o.initial_cand_bound : L.cand_bound(beam_in[l]));
         if (cb > 0x7FFFFFFFull) fail("candidate row too long; lower beam_size");
         cstride[l] = (uint32_t)cb;
     }
@@ -66,11 +71,11 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     uint64_t nb = std::max<uint64_t>(1, cand_budget / ((uint64_t)cs_max * 4));
     nb = std::min<uint64_t>(nb, 1u << 22);
     if (m.max_batch_rows > 0) nb = std::min<uint64_t>(nb, (uint64_t)m.max_batch_rows);
-    nb = std::min<uint64_t>(nb, std::max<uint32_t>(1, X.rows));
+    nb = std::min<uint64_t>(nb, std::max<uint64_t>(1, std::max<uint64_t>(n_rows, o.reserve_rows)));   // reserve_rows: size the scratch for the caller's largest batch up front
     // two lanes: the row batches alternate between the caller's stream and an auxiliary one.  K1 launches are chained
     // across the lanes (one K1 at a time owns the memory system); a lane's K0 / sort / K2 run under the other lane's K1.
-    const int lanes = (m.overlap_min_rows > 0 && !o.stats_out && !m.profiling && X.rows >= (uint64_t)m.overlap_min_rows) ? 2 : 1;
-    if (lanes == 2) nb = std::min<uint64_t>(nb, ((uint64_t)X.rows + 1) / 2);
+    const int lanes = (m.overlap_min_rows > 0 && !o.stats_out && !m.profiling && n_rows >= (uint64_t)m.overlap_min_rows) ? 2 : 1;
+    if (lanes == 2) nb = std::min<uint64_t>(nb, (n_rows + 1) / 2);
 
     for (int ln = 0; ln < lanes; ++ln) {
         LaneWs& lw = ws.lane[ln];
@@ -97,7 +102,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         size_t hist_max = 0; uint32_t tiles_max = 0; bool any = false;
         for (size_t l = 0; l < T; ++l) {
             const Layer& L = *m.layers[l];
-            if (layer_mode(l, nb) != 0 || (X.rows % nb && layer_mode(l, X.rows % nb) != 0)) {
+            if (layer_mode(l, nb) != 0 || (n_rows % nb && layer_mode(l, n_rows % nb) != 0)) {
                 any = true;
                 hist_max = std::max(hist_max, sort_hist_bytes(nb * beam_in[l] * L.max_tiles_per_parent, L.n_tiles));
                 tiles_max = std::max(tiles_max, L.n_tiles);
@@ -107,8 +112,8 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     }
     for (int ln = 0; ln < lanes; ++ln) { LaneWs& lw = ws.lane[ln]; lw.cand_off.reserve(nb * bin_max * 4); lw.ncand.reserve(nb * 4); lw.cand.reserve(nb * (uint64_t)cs_max * 4); }
     if (o.stats_out) {
-        ws.stats.reserve(T * 2 * sizeof(double));
-        XRL_HIP(hipMemsetAsync(ws.stats.p, 0, T * 2 * sizeof(double), stream));
+        ws.stats.reserve(T * kStatsPerLayer * sizeof(double));
+        XRL_HIP(hipMemsetAsync(ws.stats.p, 0, T * kStatsPerLayer * sizeof(double), stream));
     }
 
     // ---- streams and cross-stream ordering
@@ -128,8 +133,8 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     hipEvent_t k1_done = nullptr;                                      // the most recent K1 launch (either lane)
 
     uint64_t batch = 0;
-    for (uint64_t row0 = 0; row0 < X.rows; row0 += nb, ++batch) {
-        const uint32_t nrows = (uint32_t)std::min<uint64_t>(nb, X.rows - row0);
+    for (uint64_t row0 = row_begin; row0 < row_end; row0 += nb, ++batch) {
+        const uint32_t nrows = (uint32_t)std::min<uint64_t>(nb, row_end - row0);
         const int ln = (int)(batch % (uint64_t)lanes);
         LaneWs& lw = ws.lane[ln];
         hipStream_t S = lane_stream[ln];
@@ -163,6 +168,16 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             else { const int b = (int)(l & 1); oi = lw.beam_idx[b].as<uint32_t>(); ov = lw.beam_val[b].as<float>(); oc = lw.beam_cnt[b].as<uint32_t>(); os = beam_stride; }
 
             // layers held in the dense row format: the whole layer is one query-stationary kernel (beam in, beam out)
+            if (csc) {
+                // CSC route (weight_matrix_type CSC, single-layer API): one (query, child) dot product per candidate, bias first
+                Layer& Lm = *m.layers[l];
+                ensure_device_csc(Lm);
+                timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
+                timed("k1c_csc", (uint32_t)l, [&] { launch_k1c_csc(L.dev, Lm.d_csc_ptr.as<uint64_t>(), Lm.d_csc_idx.as<uint32_t>(), Lm.d_csc_val.as<float>(), P, X, prev,
+                                                                   lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), S); });
+                timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
+                continue;
+            }
             if (m.dense_layers && !o.stats_out && k1q_regs(L.dev, beam_in[l], k[l]) != 0) {
                 timed(X.dense ? "k1q_dense_x" : "k1q_dense", (uint32_t)l, [&] { launch_k1q(L.dev, P, X, prev, oi, ov, oc, os, S); });
                 continue;
@@ -181,7 +196,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                               lw.cand.as<float>(), g, S); });
             if (lanes == 2) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
             timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
-            if (o.stats_out) launch_stats(L.dev, P, prev, lw.ncand.as<uint32_t>(), ws.stats.as<double>() + 2 * l, S);
+            if (o.stats_out) launch_stats(L.dev, P, X, prev, lw.ncand.as<uint32_t>(), lw.items.p, ws.stats.as<double>() + kStatsPerLayer * l, S);
         }
     }
     if (lanes == 2) {                                                   // the caller's stream continues after the auxiliary lane
@@ -191,10 +206,10 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     }
 
     if (o.stats_out) {
-        // per layer: [0] algorithmic bytes of the reference chunks streamed (8E + 4R + 4(R+1) each,
-        // SURVEY.md 8d), [1] candidates evaluated
+        // per layer (kStatsPerLayer doubles): [0] algorithmic bytes of the reference chunks streamed (8E + 4R + 4(R+1) each,
+        // SURVEY.md 8d), [1] candidates evaluated, [2..7] matched work of the (query, tile) items (launch_stats)
         XRL_HIP(hipStreamSynchronize(stream));
-        XRL_HIP(hipMemcpy(o.stats_out, ws.stats.p, T * 2 * sizeof(double), hipMemcpyDeviceToHost));
+        XRL_HIP(hipMemcpy(o.stats_out, ws.stats.p, T * kStatsPerLayer * sizeof(double), hipMemcpyDeviceToHost));
     } else if (sync) {
         XRL_HIP(hipStreamSynchronize(stream));
     }

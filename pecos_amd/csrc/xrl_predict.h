@@ -19,8 +19,11 @@ struct PredictOpts {
     const char* post_processor = nullptr;
     const BeamDev* initial = nullptr;  // non-null: explicit previous-layer predictions (csr_codes)
     uint32_t initial_max = 0;          // max entries per row in `initial`
-    double* stats_out = nullptr;       // host [depth*2]: per layer {reference-chunk bytes streamed, candidates}
+    double* stats_out = nullptr;       // host [depth * kStatsPerLayer], see launch_stats
     bool no_prev_pred = false;         // explicit initial beam but no combine (fill_ones case, libpecos.cpp:219-222)
+    uint64_t initial_cand_bound = 0;   // explicit initial beam: max over rows of the candidates it prolongates to (0 = bound from the largest chunks)
+    uint32_t reserve_rows = 0;         // callers that predict row ranges of different sizes: the largest one (scratch is sized once, no realloc mid-pipeline)
+    bool csc_route = false;            // the reference's CSC arithmetic (w_ops<csc_t>): K0 -> K1C -> K2 on every layer
 };
 
 uint32_t effective_topk(const Model& m, uint32_t only_topk);
@@ -34,6 +37,7 @@ void predict_selected(Model& m, const QueriesDev& X, uint32_t s_rows, uint32_t s
 
 // Enqueue the whole beam search on `stream`; results land in fixed-stride device buffers.
 void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_t* d_out_idx, float* d_out_val,
-                    uint32_t* d_out_cnt, uint32_t out_stride, hipStream_t stream, bool sync);
+                    uint32_t* d_out_cnt, uint32_t out_stride, hipStream_t stream, bool sync,
+                    uint32_t row_begin = 0, uint32_t row_count = 0xFFFFFFFFu);
 
 }  // namespace xrl

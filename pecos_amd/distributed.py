@@ -1,11 +1,11 @@
 """Query-sharded multi-GPU prediction: one process per GPU, model replicated, rows of X split into
-contiguous nnz-balanced shards, ONE all-gather of the fixed-stride top-k at the end
+contiguous nnz-balanced shards, ONE all-gather of the packed fixed-stride top-k rows at the end
 (RCCL over xGMI through ``torch.distributed``'s "nccl" backend; "gloo" on CPU for tests).
 
 The reference has no multi-process inference at all (only sequential
 ``max_pred_chunk`` row chunking, pecos/xmc/xlinear/model.py:532-548); this module is what the
 MI355X build adds.  Every stage of the beam search is row-local, so there is no data-path
-collective until the final gather: payload = rows x k x 8 B + rows x 4 B.
+collective until the final gather: payload = rows x (8k + 4) B.  bench.py and ShardedXLinear share PackedTopk.
 
 torch is imported lazily and BEFORE the HIP library is first touched, so that both share one HIP
 runtime in the process.
@@ -46,38 +46,53 @@ def rows_to_csr(idx, val, cnt, n_cols):
     return smat.csr_matrix((val[mask].astype(np.float32), idx[mask].astype(np.int64), indptr), shape=(n, n_cols))
 
 
-def all_gather_topk(idx, val, cnt, bounds, group=None):
-    """All-gather per-rank fixed-stride results (torch tensors on the backend's device).
+class PackedTopk:
+    """Fixed-stride result rows ``[idx(k) | val(k) | cnt]`` of one rank's shard held as ONE int32 tensor, so that a
+    single ``all_gather_into_tensor`` moves labels, scores and row lengths together (shards are padded to the largest).
 
-    idx: int32/uint32-as-int32 [rows_r, k], val: float32 [rows_r, k], cnt: int32 [rows_r];
-    ``bounds`` are the global row boundaries, identical on every rank.  Shards are padded to the
-    largest shard so that one ``all_gather_into_tensor`` per array suffices.  Returns global
-    (idx, val, cnt) tensors in row order."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    sizes = np.diff(bounds)
-    k = idx.shape[1]
-    maxr = int(sizes.max()) if len(sizes) else 0
-    dev = idx.device
+    The compute writes labels / scores through :meth:`pointers` (row stride 2k+1) and row lengths into ``cnt``;
+    :meth:`gather` folds ``cnt`` into column 2k and runs the collective on the CURRENT stream of the backend's
+    device, :meth:`unpack` cuts the padding away."""
 
-    def pad(t, cols):
-        out = torch.zeros((maxr, cols) if cols else (maxr,), dtype=t.dtype, device=dev)
-        out[: t.shape[0]] = t
-        return out
+    def __init__(self, max_rows, k, world, device, dtype_check=True):
+        import torch
+        self.k, self.world, self.max_rows = int(k), int(world), int(max_rows)
+        self.buf = torch.zeros((self.max_rows, 2 * self.k + 1), dtype=torch.int32, device=device)
+        self.cnt = torch.zeros((self.max_rows,), dtype=torch.int32, device=device)
+        self.gathered = torch.empty((self.world, self.max_rows, 2 * self.k + 1), dtype=torch.int32, device=device) if self.world > 1 else None
 
-    outs = []
-    for t, cols in ((idx, k), (val, k), (cnt, 0)):
-        send = pad(t, cols).contiguous()
-        recv = torch.empty((world,) + tuple(send.shape), dtype=t.dtype, device=dev)
+    def pointers(self):
+        """(idx_ptr, val_ptr, cnt_ptr, row_stride) for ``clib.predict_device``."""
+        return self.buf.data_ptr(), self.buf.data_ptr() + 4 * self.k, self.cnt.data_ptr(), 2 * self.k + 1
+
+    def store(self, idx, val, cnt):
+        """Fill from separate tensors (CPU stand-ins in tests): idx int32 [n,k], val float32 [n,k], cnt int32 [n]."""
+        import torch
+        n = idx.shape[0]
+        self.buf[:n, : self.k] = idx
+        self.buf[:n, self.k: 2 * self.k] = val.contiguous().view(torch.int32)
+        self.cnt[:n] = cnt
+
+    def gather(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self.buf[:, 2 * self.k] = self.cnt
+        if self.world == 1:
+            return self.buf.unsqueeze(0)
         try:
-            dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+            dist.all_gather_into_tensor(self.gathered, self.buf, group=group)
         except (RuntimeError, NotImplementedError):  # backends without the fused form
-            parts = [torch.empty_like(send) for _ in range(world)]
-            dist.all_gather(parts, send, group=group)
-            recv = torch.stack(parts)
-        outs.append(torch.cat([recv[r, : int(sizes[r])] for r in range(world)], dim=0))
-    return tuple(outs)
+            parts = [torch.empty_like(self.buf) for _ in range(self.world)]
+            dist.all_gather(parts, self.buf, group=group)
+            self.gathered.copy_(torch.stack(parts))
+        return self.gathered
+
+    def unpack(self, gathered, bounds):
+        """-> global (idx int32 [N,k], val float32 [N,k], cnt int32 [N]) in row order."""
+        import torch
+        sizes = np.diff(bounds)
+        rows = torch.cat([gathered[r, : int(sizes[r])] for r in range(gathered.shape[0])], dim=0)
+        return rows[:, : self.k].contiguous(), rows[:, self.k: 2 * self.k].contiguous().view(torch.float32), rows[:, 2 * self.k].contiguous()
 
 
 class ShardedXLinear:
@@ -103,6 +118,10 @@ class ShardedXLinear:
         k = clib.effective_topk(h, only_topk)
         n = Xs.shape[0]
         dev = torch.device("cuda", torch.cuda.current_device())
+        model_dev = clib.xlinear_get_int_attr(h, "device")
+        if model_dev != dev.index:   # the handle lives on the device that was current when it was loaded (clib.set_device)
+            raise RuntimeError(f"model handle is on GPU {model_dev} but torch's current device is {dev.index}: call "
+                               "pecos_amd.clib.set_device(local_rank) before XLinearModel.load")
         idx = torch.zeros((n, k), dtype=torch.int32, device=dev)
         val = torch.zeros((n, k), dtype=torch.float32, device=dev)
         cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
@@ -119,7 +138,17 @@ class ShardedXLinear:
         """X: the FULL query matrix (identical on every rank).  Returns the full CSR on every rank."""
         bounds = shard_bounds(X, self.world)
         lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
-        idx, val, cnt = self._fn(take_rows(X, lo, hi), beam_size, only_topk, post_processor)
+        return self.predict_shard(take_rows(X, lo, hi), bounds, beam_size, only_topk, post_processor)
+
+    def predict_shard(self, X_local, bounds, beam_size=None, only_topk=None, post_processor=None):
+        """X_local: THIS rank's rows only, ``bounds``: the global row boundaries (world+1 ints, identical on every rank;
+        e.g. from :func:`shard_bounds`).  One packed all-gather; returns the full CSR on every rank."""
+        bounds = np.asarray(bounds, dtype=np.int64)
+        if X_local.shape[0] != int(bounds[self.rank + 1] - bounds[self.rank]):
+            raise ValueError("X_local does not hold the rows bounds assign to this rank")
+        idx, val, cnt = self._fn(X_local, beam_size, only_topk, post_processor)
         if self.world > 1:
-            idx, val, cnt = all_gather_topk(idx, val, cnt, bounds, self.group)
+            pk = PackedTopk(int(np.diff(bounds).max()), idx.shape[1], self.world, idx.device)
+            pk.store(idx, val, cnt)
+            idx, val, cnt = pk.unpack(pk.gather(self.group), bounds)
         return rows_to_csr(idx.cpu().numpy().view(np.uint32), val.cpu().numpy(), cnt.cpu().numpy(), self.model.nr_pred_cols)

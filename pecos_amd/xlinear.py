@@ -298,8 +298,10 @@ class XLinearModel:
 
     @classmethod
     def load(cls, model_folder, is_predict_only=True, **kwargs):
-        """kwargs: weight_matrix_type in {"BINARY_SEARCH_CHUNKED", "HASH_CHUNKED", "CSC"} is accepted
-        for compatibility; the GPU library has a single device layout."""
+        """kwargs: weight_matrix_type in {"BINARY_SEARCH_CHUNKED", "HASH_CHUNKED", "CSC"} (pecos/core/base.py:49).
+        "CSC" runs the reference's CSC arithmetic (bias first, dot product summed separately, inference.hpp:1018-1149) and is
+        bit-identical to the reference loaded with the same type; the two chunked types share one device layout and the
+        arithmetic of BINARY_SEARCH_CHUNKED (the reference's default; its hash layout iterates rows in hash order)."""
         model = HierarchicalMLModel.load(path.join(model_folder, "ranker"), is_predict_only, **kwargs)
         return cls(model)
 

@@ -1,5 +1,5 @@
-"""CPU, world_size 2 over gloo: the N>1 path (nnz-balanced sharding + padded all-gather + CSR
-assembly) with the oracle standing in for the per-rank GPU compute."""
+"""CPU, world_size 2 over gloo: the N>1 path (nnz-balanced sharding + ONE packed all-gather (PackedTopk, the same
+object bench.py's step uses) + CSR assembly) with the oracle standing in for the per-rank GPU compute."""
 import os
 import socket
 import sys
@@ -39,6 +39,11 @@ def _worker(rank, world, port, out_dir):
 
     sh = ShardedXLinear(Stub(), predict_shard_fn=fn)
     P = sh.predict(X, beam_size=10, only_topk=10)
+    # each rank passing only ITS rows (what bench.py does): same result
+    from pecos_amd.distributed import shard_bounds, take_rows
+    bounds = shard_bounds(X, world)
+    Pl = sh.predict_shard(take_rows(X, int(bounds[rank]), int(bounds[rank + 1])), bounds, beam_size=10, only_topk=10)
+    assert_same_topk(Pl, P, exact_scores=True, what=f"rank {rank} predict_shard")
     full = om.predict(X, beam_size=10, only_topk=10)
     assert_same_topk(P, full, exact_scores=True, what=f"rank {rank}")
     # ragged: more ranks than useful rows on one side (tiny X)

@@ -274,24 +274,88 @@ def test_sparse_inner_products(clib, oracle_mod):
         got = clib.sparse_inner_products(Aq, Bq, rr, cc)
         exp = oracle_mod.sparse_inner_products(Aq, Bq, rr, cc)
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+        if oracle_mod.ref_available():   # the function this entry point replaces (libpecos.cpp:337-355)
+            assert np.array_equal(got.view(np.uint32), oracle_mod.ref_sparse_inner_products(Aq, Bq, rr, cc).view(np.uint32))
+    # long index lists on both sides (several 16-entry steps, binary searches in either direction), empty rows / columns
+    A2 = smat.random(50, 20000, density=0.02, format="csr", dtype=np.float32, random_state=8); A2.sort_indices()
+    B2 = smat.random(20000, 60, density=0.3, format="csc", dtype=np.float32, random_state=9); B2.sort_indices()
+    B2 = B2.tolil(); B2[:, 5] = 0; B2 = B2.tocsc().astype(np.float32); B2.sort_indices()
+    r2 = rng.integers(0, 50, 3000).astype(np.uint32); c2 = rng.integers(0, 60, 3000).astype(np.uint32)
+    got = clib.sparse_inner_products(A2, B2, r2, c2)
+    assert np.array_equal(got.view(np.uint32), oracle_mod.sparse_inner_products(A2, B2, r2, c2).view(np.uint32))
 
 
 def test_single_layer_predict(clib, oracle_mod):
-    # c_xlinear_single_layer_predict (libpecos.cpp:201-235) == one oracle layer, with and without csr_codes
+    # N2: c_xlinear_single_layer_predict_{csr,drm}_f32 against the function it replaces -- the REAL reference's entry point
+    # (libpecos.cpp:201-235: MLModel<csc_t>, i.e. the CSC arithmetic: bias first, dot product summed separately) -- bit for
+    # bit: without codes, with codes (combine), sparse and dense X, a codes row that lists a parent twice
     from pecos_amd.core import ScipyCompressedSparseAllocator
     folder = os.path.join(GOLDEN, "synth", "s_eurlex")
     layers = oracle_mod.load_model_folder(folder)
     X = load_X(os.path.join(GOLDEN, "synth", "s_eurlex__X.npz"))
-    om_top = oracle_mod.OracleModel(layers[:1]); om2 = oracle_mod.OracleModel(layers[:2])
-    L0, L1 = layers[0], layers[1]
-    alloc = ScipyCompressedSparseAllocator()
-    clib.xlinear_single_layer_predict(X, None, L0["W"], L0["C"], "l3-hinge", 3, -1, L0["bias"], alloc)
-    P0 = alloc.get()
-    assert_same_topk(P0, om_top.predict(X, only_topk=3), exact_scores=True, what="layer 0")
-    codes = smat.csr_matrix(P0, dtype=np.float32)
-    alloc = ScipyCompressedSparseAllocator()
-    clib.xlinear_single_layer_predict(X, codes, L1["W"], L1["C"], "l3-hinge", 6, -1, L1["bias"], alloc)
-    assert_same_topk(alloc.get(), om2.predict(X, beam_size=3, only_topk=6), exact_scores=True, what="layer 1 with codes")
+    L0, L1, L2 = layers[0], layers[1], layers[2]
+
+    def ours(Xq, codes, L, pp, k):
+        alloc = ScipyCompressedSparseAllocator()
+        clib.xlinear_single_layer_predict(Xq, codes, L["W"], L["C"], pp, k, -1, L["bias"], alloc)
+        return alloc.get()
+
+    have_ref = oracle_mod.ref_available()
+    clib.single_layer_cache_clear()
+    st0 = clib.single_layer_cache_stats()
+    for Xq in (X, np.ascontiguousarray(X.toarray())):
+        for pp in ("l3-hinge", "noop", "sigmoid"):
+            P0 = ours(Xq, None, L0, pp, 3)
+            codes = smat.csr_matrix(P0, dtype=np.float32)
+            P1 = ours(Xq, codes, L1, pp, 6)
+            codes1 = smat.csr_matrix(P1, dtype=np.float32)
+            P2 = ours(Xq, codes1, L2, pp, 9)
+            if have_ref:
+                R0 = oracle_mod.ref_single_layer_predict(Xq, None, L0["W"], L0["C"], pp, 3, L0["bias"])
+                R1 = oracle_mod.ref_single_layer_predict(Xq, codes, L1["W"], L1["C"], pp, 6, L1["bias"])
+                R2 = oracle_mod.ref_single_layer_predict(Xq, codes1, L2["W"], L2["C"], pp, 9, L2["bias"])
+                for a, b, what in ((P0, R0, "layer 0"), (P1, R1, "layer 1 with codes"), (P2, R2, "leaf with codes (permuted children)")):
+                    assert_same_topk(a, b, exact_scores=EXACT_PP(pp), what=f"single layer vs reference: {what} {pp} dense={not smat.issparse(Xq)}")
+            else:   # chunked restatement: same labels, scores within the reference's own cross-layout tolerance
+                om = oracle_mod.OracleModel(layers[:1])
+                assert np.allclose(P0.toarray(), om.predict(Xq, only_topk=3, post_processor=pp).toarray(), atol=1e-6)
+    st1 = clib.single_layer_cache_stats()
+    assert st1["misses"] - st0["misses"] == 3 and st1["hits"] - st0["hits"] == 15, (st0, st1)   # 3 layers compiled once, reused 15 times
+    # a codes row listing the same parent twice (non-canonical CSR): the reference prolongates both occurrences
+    P0 = ours(X, None, L0, "l3-hinge", 3)
+    c = smat.csr_matrix(P0, dtype=np.float32)
+    d_idx = np.concatenate([np.tile(c.indices[c.indptr[i]:c.indptr[i + 1]], 2) for i in range(c.shape[0])]).astype(np.int32)
+    d_val = np.concatenate([np.tile(c.data[c.indptr[i]:c.indptr[i + 1]], 2) for i in range(c.shape[0])]).astype(np.float32)
+    d_ptr = np.concatenate([[0], np.cumsum(2 * np.diff(c.indptr))]).astype(np.int32)
+    dup = smat.csr_matrix(c.shape, dtype=np.float32)
+    dup.indices, dup.data, dup.indptr = d_idx, d_val, d_ptr          # assigned directly: the constructor would merge duplicates
+    Pd = ours(X, dup, L1, "l3-hinge", 12)
+    if have_ref:
+        assert_same_topk(Pd, oracle_mod.ref_single_layer_predict(X, dup, L1["W"], L1["C"], "l3-hinge", 12, L1["bias"]), exact_scores=True, what="duplicate parents")
+    bad = smat.csr_matrix((np.ones(1, np.float32), np.array([L1["C"].shape[1]]), np.array([0, 1] + [1] * (X.shape[0] - 1))), shape=(X.shape[0], L1["C"].shape[1] + 1))
+    with pytest.raises(RuntimeError):
+        ours(X, bad, L1, "l3-hinge", 3)
+    clib.single_layer_cache_clear()
+    assert clib.single_layer_cache_stats()["entries"] == 0
+
+
+def test_csc_weight_matrix_type(XLM, clib, oracle_mod, tmp_path):
+    # weight_matrix_type="CSC" (pecos/core/base.py:49): the reference runs w_ops<csc_t> (inference.hpp:1081-1149) on every
+    # layer; so does this library (K0 -> K1C -> K2), bit-identical to RefModel(folder, "CSC"), sparse and dense X
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built")
+    import xrl_synth
+    cases = [(os.path.join(GOLDEN, "synth", n), load_X(os.path.join(GOLDEN, "synth", n + "__X.npz"))) for n in ("s_eurlex", "s_pruned", "s_nobias", "s_flat", "s_deep")]
+    folder = str(tmp_path / "m")
+    ks, X, cfg = xrl_synth.make_config("eurlex-4k", folder, scale=0.5)
+    cases.append((folder, X[:300]))
+    for f, Xs in cases:
+        m = XLM.load(f, weight_matrix_type="CSC")
+        assert clib.xlinear_get_layer_type(m.model.model_chain, 0) == 0
+        rm = oracle_mod.RefModel(f, "CSC")
+        for kw in (dict(beam_size=5, only_topk=7), dict(beam_size=10, only_topk=10, post_processor="log-l2-hinge"), dict()):
+            for Xq in (Xs, np.ascontiguousarray(Xs[:48].toarray())):
+                assert_same_topk(m.predict(Xq, **kw), rm.predict(Xq, **kw), exact_scores=True, what=f"CSC type {os.path.basename(f)} {kw}")
 
 
 def test_predict_on_selected_outputs(manifest, XLM, oracle_mod):

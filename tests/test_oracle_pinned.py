@@ -72,6 +72,23 @@ def test_oracle_sparse_inner_products_kat(oracle_mod):
         assert np.allclose(oracle_mod.sparse_inner_products(Xq, Wq, r, c), true, atol=1e-9)
 
 
+def test_oracle_sparse_inner_products_pinned_on_reference(oracle_mod):
+    # the restatement of do_dot_product (matrix.hpp:836-877) against the REAL reference's c_sparse_inner_products_*
+    # on random pairs, all four layout combinations, bit for bit (the KAT above only holds 3 pairs)
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(5)
+    A = smat.random(300, 700, density=0.05, format="csr", dtype=np.float32, random_state=6); A.sort_indices()
+    B = smat.random(700, 400, density=0.08, format="csc", dtype=np.float32, random_state=7); B.sort_indices()
+    A = A.tolil(); A[3, :] = 0; A[4, :] = rng.standard_normal(700).astype(np.float32); A = A.tocsr().astype(np.float32); A.sort_indices()
+    rr = rng.integers(0, 300, 8000).astype(np.uint32); cc = rng.integers(0, 400, 8000).astype(np.uint32)
+    for Aq, Bq in [(A, B), (np.ascontiguousarray(A.toarray()), B), (A, np.asfortranarray(B.toarray())),
+                   (np.ascontiguousarray(A.toarray()), np.asfortranarray(B.toarray()))]:
+        got = oracle_mod.sparse_inner_products(Aq, Bq, rr, cc)
+        ref = oracle_mod.ref_sparse_inner_products(Aq, Bq, rr, cc)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def test_oracle_selected_outputs(manifest, oracle_mod):
     # reference golden: `predict -so Yt_pred.npz` reproduces Yt_pred (test_xlinear.py:368-383), and the
     # CSC-route restatement is bit-identical to the real reference (values AND output order) when present
