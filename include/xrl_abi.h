@@ -254,7 +254,7 @@ int xrl_set_option(void* model, const char* key, int64_t value);
 void xrl_debug_k1_phases(unsigned long long* out8, int reset);
 
 /* Single-layer API (c_xlinear_single_layer_predict*): compiled one-layer handles are cached by the identity of the caller's
- * W / C arrays (pointers, shapes, nnz, bias) plus a fingerprint of their contents, at most 8 entries, least recently used
+ * W / C value arrays (pointers, shapes, nnz, bias) plus a fingerprint of the contents of all arrays, at most 8 entries, least recently used
  * evicted.  Clear the cache after modifying W / C in place.  stats: cumulative hits / misses and live entries (tests). */
 void xrl_single_layer_cache_clear(void);
 void xrl_single_layer_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* entries);

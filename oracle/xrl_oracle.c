@@ -6,7 +6,7 @@
  * and bench.py's cpu_baseline leg can check the HIP path; nothing in pecos_amd/ may link,
  * import or call it.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_golden.py checks this file against
+ * Parity status: PINNED.  tests/test_oracle_pinned.py checks this file against
  *   (1) the reference's own golden predictions (test/tst-data/xmc/xlinear/*.npz) on models the
  *       reference itself trained (fixtures + generating script under tests/golden/), and
  *   (2) outputs of the real reference compiled from /root/reference (oracle/_ref) on seeded

@@ -260,10 +260,13 @@ std::unique_ptr<Model> model_from_arrays(uint32_t depth, const ScipyCscF32* cons
 // matcher -> ranker hand-off -- pay the compile + upload once.  xrl_single_layer_cache_clear() drops every entry (call it
 // after modifying W / C in place).
 struct SlKey {
-    const void *wp, *wi, *wv, *cp, *ci;
+    // identity of the caller's VALUE arrays (the reference's Python binding hands over W.data / C.data as they are, while
+    // the index arrays are re-cast to u32 / u64 copies on every call, pecos/core/base.py:235-239), shapes, nnz, bias,
+    // and a fingerprint of the contents of all arrays
+    const void *wv, *cv;
     uint32_t wr, wc, cr, cc; uint64_t wnnz, cnnz; float bias; uint64_t fp; int device;
     bool operator==(const SlKey& o) const {
-        return wp == o.wp && wi == o.wi && wv == o.wv && cp == o.cp && ci == o.ci && wr == o.wr && wc == o.wc && cr == o.cr &&
+        return wv == o.wv && cv == o.cv && wr == o.wr && wc == o.wc && cr == o.cr &&
                cc == o.cc && wnnz == o.wnnz && cnnz == o.cnnz && bias == o.bias && fp == o.fp && device == o.device;
     }
 };
@@ -288,8 +291,8 @@ uint64_t fingerprint(uint64_t h, const void* data, size_t elems, size_t elem_byt
 std::shared_ptr<Model> single_layer_model(const ScipyCscF32* W, const ScipyCscF32* C, float bias) {
     if (!W) fail("null W");
     SlKey k{};
-    k.wp = W->col_ptr; k.wi = W->row_idx; k.wv = W->val; k.wr = W->rows; k.wc = W->cols; k.wnnz = W->cols ? W->col_ptr[W->cols] : 0;
-    k.cp = C ? (const void*)C->col_ptr : nullptr; k.ci = C ? (const void*)C->row_idx : nullptr;
+    k.wv = W->val; k.wr = W->rows; k.wc = W->cols; k.wnnz = W->cols ? W->col_ptr[W->cols] : 0;
+    k.cv = C ? (const void*)C->val : nullptr;
     k.cr = C ? C->rows : 0; k.cc = C ? C->cols : 0; k.cnnz = (C && C->cols) ? C->col_ptr[C->cols] : 0;
     k.bias = bias; k.device = g_device;
     uint64_t h = 1469598103934665603ull;
@@ -811,9 +814,9 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
         else if (!std::strcmp(key, "k1t_min_items")) m.k1t_min_items = (int)value;
         else if (!std::strcmp(key, "k1t_items_per_block")) m.k1t_items_per_block = (int)value;
-        else if (!std::strcmp(key, "k1_wpb")) k1_set_wpb((int)value);
-        else if (!std::strcmp(key, "k1_lds_pad")) k1_set_lds_pad((int)value);   // debug: occupancy experiments
-        else if (!std::strcmp(key, "k1_ablate")) k1_set_ablate((int)value);   // debug: timing ablations only
+        else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
+        else if (!std::strcmp(key, "k1_lds_pad")) m.k1_lds_pad = (int)value;   // debug: occupancy experiments
+        else if (!std::strcmp(key, "k1_ablate")) m.k1_ablate = (int)value;     // debug: timing ablations only
         else fail(std::string("unknown option ") + key);
         rc = 0;
     });

@@ -12,6 +12,8 @@
 // same message class as scipy_loader.hpp:247-249.
 #include "xrl_io.h"
 
+#include <algorithm>
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -159,6 +161,7 @@ std::map<std::string, Member> zip_members(const MappedFile& f, const std::string
         uint64_t csize = rd<uint32_t>(f.p + c + 20), usize = rd<uint32_t>(f.p + c + 24);
         const uint16_t nlen = rd<uint16_t>(f.p + c + 28), xlen = rd<uint16_t>(f.p + c + 30), clen = rd<uint16_t>(f.p + c + 32);
         uint64_t lho = rd<uint32_t>(f.p + c + 42);
+        if (c + 46 + (uint64_t)nlen + xlen > f.n) fail(path + ": corrupt zip central directory (entry runs past the file)");
         std::string name((const char*)f.p + c + 46, nlen);
         // zip64 extra: fields appear only for values that were 0xFFFFFFFF, in this fixed order
         uint64_t x = c + 46 + nlen; const uint64_t xe = x + xlen;
@@ -166,16 +169,18 @@ std::map<std::string, Member> zip_members(const MappedFile& f, const std::string
             const uint16_t id = rd<uint16_t>(f.p + x), sz = rd<uint16_t>(f.p + x + 2);
             if (id == 0x0001) {
                 uint64_t y = x + 4;
-                if (usize == 0xFFFFFFFFu) { usize = rd<uint64_t>(f.p + y); y += 8; }
-                if (csize == 0xFFFFFFFFu) { csize = rd<uint64_t>(f.p + y); y += 8; }
-                if (lho == 0xFFFFFFFFu) { lho = rd<uint64_t>(f.p + y); y += 8; }
+                const uint64_t ye = std::min<uint64_t>(xe, x + 4 + sz);
+                auto take = [&](uint64_t& v) { if (y + 8 > ye) fail(path + ": corrupt zip64 extra field"); v = rd<uint64_t>(f.p + y); y += 8; };
+                if (usize == 0xFFFFFFFFu) take(usize);
+                if (csize == 0xFFFFFFFFu) take(csize);
+                if (lho == 0xFFFFFFFFu) take(lho);
             }
             x += 4 + sz;
         }
         if (method != 0) fail(path + ": only uncompressed npz archives are supported (save with compressed=False)");
-        if (lho + 30 > f.n || rd<uint32_t>(f.p + lho) != 0x04034b50u) fail(path + ": corrupt zip local header");
+        if (lho > f.n || f.n - lho < 30 || rd<uint32_t>(f.p + lho) != 0x04034b50u) fail(path + ": corrupt zip local header");
         const uint64_t data = lho + 30 + rd<uint16_t>(f.p + lho + 26) + rd<uint16_t>(f.p + lho + 28);
-        if (data + usize > f.n) fail(path + ": truncated zip member " + name);
+        if (data > f.n || usize > f.n - data) fail(path + ": truncated zip member " + name);   // no wrap-around
         out[name] = Member{data, usize};
         c += 46 + nlen + xlen + clen;
     }
@@ -272,6 +277,11 @@ void load_csc_npz(const std::string& path, HostCsc& out) {
     else fail(path + ": data must be float32/float64, got " + d.descr);
     if (out.col_ptr.size() != (size_t)out.cols + 1) fail(path + ": indptr length does not match shape");
     if (out.col_ptr.back() != out.row_idx.size() || out.row_idx.size() != out.val.size()) fail(path + ": inconsistent nnz");
+    // indptr must start at 0 and never decrease (a corrupt file would otherwise send the model compiler and the device
+    // kernels over bad ranges); row ids must lie inside the matrix
+    if (out.col_ptr.front() != 0) fail(path + ": indptr[0] != 0");
+    for (size_t c = 0; c < out.cols; ++c) if (out.col_ptr[c + 1] < out.col_ptr[c]) fail(path + ": indptr decreases at column " + std::to_string(c));
+    for (size_t i = 0; i < out.row_idx.size(); ++i) if (out.row_idx[i] >= out.rows) fail(path + ": row index out of range at entry " + std::to_string(i));
 }
 
 bool file_exists(const std::string& path) { return ::access(path.c_str(), F_OK) == 0; }

@@ -23,6 +23,8 @@ struct BeamDev {
     uint32_t stride;
 };
 
+struct K1Tune { int wpb = 1, lds_pad = 0, ablate = 0; };   // per-model tuning / debug knobs of K1 (xrl_set_option k1_wpb, k1_lds_pad, k1_ablate)
+
 struct LayerPlan {
     uint32_t row0, nrows;       // query rows [row0, row0+nrows) of the query matrix
     uint32_t beam_in;           // max #parents per query entering the layer
@@ -32,6 +34,7 @@ struct LayerPlan {
     int first_layer;            // no combine (no_prev_pred)
     int implicit_root;          // previous beam is the implicit all-ones root
     int layer;                  // index in the chain (profiling only)
+    K1Tune tune;
 };
 
 // K0  prolongate: per query, offsets of every beam parent's child block + candidate count, and one
@@ -66,9 +69,6 @@ void launch_k3_inner_products(const uint64_t* x_ptr, const uint32_t* x_idx, cons
                               uint32_t dim, uint64_t len, const uint32_t* rows, const uint32_t* cols,
                               float* out, hipStream_t s);
 
-void k1_set_ablate(int mask);   // debug only
-void k1_set_wpb(int waves_per_block);
-void k1_set_lds_pad(int bytes);   // debug only
 unsigned long long* k1_phase_buffer();
 void k1_phase_read(unsigned long long out[8], bool reset);   // debug: per-phase cycle totals of K1
 // K4  predict_on_selected_outputs: one layer of (query, node) pairs against CSC W

@@ -40,7 +40,7 @@ namespace xrl {
 #define XRL_LAUNCH_CHECK() XRL_HIP(hipGetLastError())
 
 // ---------------------------------------------------------------------------------------------
-// K0: one thread per query.  Besides the child-block offsets (prolongate) it writes one 16-byte
+// K0: one thread per query.  Besides the child-block offsets (prolongate) it writes one 32-byte
 // ITEM DESCRIPTOR per (query, beam slot, tile-in-parent) so that K1 starts from a single coalesced
 // load instead of a chain of dependent lookups (beam -> parent -> tile range -> offsets).
 // ---------------------------------------------------------------------------------------------
@@ -177,11 +177,9 @@ void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, v
     if (T > sort_max_tiles()) fail("sort_items: too many tiles for the LDS histogram");
     const uint32_t B = (uint32_t)((n_slots + kSortChunk - 1) / kSortChunk);
     const size_t lds = (size_t)T * 4;
-    static thread_local size_t configured = 0;
-    if (lds > 48 * 1024 && lds > configured) {
+    if (lds > 48 * 1024) {   // per DEVICE attribute: set on every large launch (a per-thread cache would miss a second GPU)
         XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
     }
     hipLaunchKernelGGL(sort_hist_kernel, dim3(B), dim3(256), lds, s, static_cast<const ItemDesc*>(items), n_slots, T, H);
     hipLaunchKernelGGL(sort_colsum_kernel, dim3((T + 255) / 256), dim3(256), 0, s, H, B, T, start);
@@ -547,15 +545,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
 #endif
 }
 
-int g_k1_wpb = 1;   // wavefronts per workgroup (tuning knob)
-int g_k1_lds_pad = 0;   // debug: extra LDS bytes per wavefront (lowers occupancy, for latency-sensitivity experiments)
-void k1_set_lds_pad(int b) { g_k1_lds_pad = b < 0 ? 0 : b; }
-void k1_set_wpb(int w) { g_k1_wpb = (w == 2 || w == 4) ? w : 1; }
-
 template <class KERNEL>
-static void launch_k1_any(KERNEL kernel, K1Args a, int W, size_t lds_wave, hipStream_t s) {
-    lds_wave = (lds_wave + (size_t)g_k1_lds_pad + 15) & ~(size_t)15;
-    int wpb = g_k1_wpb;
+static void launch_k1_any(KERNEL kernel, K1Args a, int W, size_t lds_wave, const K1Tune& tune, hipStream_t s) {
+    lds_wave = (lds_wave + (size_t)std::max(0, tune.lds_pad) + 15) & ~(size_t)15;
+    int wpb = (tune.wpb == 2 || tune.wpb == 4) ? tune.wpb : 1;
     while (wpb > 1 && lds_wave * wpb > 160 * 1024) wpb >>= 1;
     const size_t lds = lds_wave * wpb;
     if (lds > 160 * 1024) fail("k1: LDS request exceeds 160 KiB");
@@ -569,9 +562,7 @@ static void launch_k1_any(KERNEL kernel, K1Args a, int W, size_t lds_wave, hipSt
     XRL_LAUNCH_CHECK();
 }
 
-int g_k1_ablate = 0;
-void k1_set_ablate(int mask) { g_k1_ablate = mask; }
-static unsigned long long* g_phase_buf = nullptr;
+static unsigned long long* g_phase_buf = nullptr;   // debug only (k1_ablate bit 6): one per process
 unsigned long long* k1_phase_buffer() {
     if (!g_phase_buf) { XRL_HIP(hipMalloc(&g_phase_buf, 8 * 8)); XRL_HIP(hipMemset(g_phase_buf, 0, 64)); }
     return g_phase_buf;
@@ -598,11 +589,12 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     a.n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
     a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
     a.acc_stride = L.max_tile_cols | 1u;
-    a.ablate = g_k1_ablate & 0xFF;
+    const int ablate = P.tune.ablate;
+    a.ablate = ablate & 0xFF;
     // debug: bit 6 = per-phase cycle accounting; bits 8.. select one layer (value layer+1, 0 = every layer)
-    a.phase = ((g_k1_ablate & 64) && ((g_k1_ablate >> 8) == 0 || (g_k1_ablate >> 8) == P.layer + 1)) ? k1_phase_buffer() : nullptr;
+    a.phase = ((ablate & 64) && ((ablate >> 8) == 0 || (ablate >> 8) == P.layer + 1)) ? k1_phase_buffer() : nullptr;
     const int ppc = pp_class(P.pp);
-#define XRL_K1_PP(GG, NN, DD, LL) do { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, DD, LL>, a, 64 / GG, lds, s); else launch_k1_any(&k1_kernel<GG, NN, 0, DD, LL>, a, 64 / GG, lds, s); } while (0)
+#define XRL_K1_PP(GG, NN, DD, LL) do { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, DD, LL>, a, 64 / GG, lds, P.tune, s); else launch_k1_any(&k1_kernel<GG, NN, 0, DD, LL>, a, 64 / GG, lds, P.tune, s); } while (0)
 #define XRL_K1(GG, NN) do { \
         const size_t lds = K1Cfg<GG, NN>::lds_bytes(a.acc_stride); \
         if (X.dense) XRL_K1_PP(GG, NN, true, 0); \
@@ -916,7 +908,7 @@ void launch_k1t(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, cons
     a.tile_cap = (uint32_t)k1t_tile_cap(L);
     a.scratch_per_wave = (uint32_t)k1t_scratch(L);
     a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
-    a.phase = ((g_k1_ablate & 64) && ((g_k1_ablate >> 8) == 0 || (g_k1_ablate >> 8) == P.layer + 1)) ? k1_phase_buffer() : nullptr;
+    a.phase = ((P.tune.ablate & 64) && ((P.tune.ablate >> 8) == 0 || (P.tune.ablate >> 8) == P.layer + 1)) ? k1_phase_buffer() : nullptr;
     const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
     const uint64_t blocks = (n_slots + items_per_block - 1) / items_per_block;
     if (blocks > 0x7FFFFFFFull) fail("k1t: grid too large; lower max_batch_rows");
@@ -1122,12 +1114,8 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
     } else {
         const size_t lds = (size_t)P.k * 8;
         if (P.k > k2_max_k()) fail("k2: only_topk/beam_size " + std::to_string(P.k) + " exceeds the device limit " + std::to_string(k2_max_k()));
-        static thread_local size_t configured = 0;
-        if (lds > 48 * 1024 && lds > configured) {
-            XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_topk_lds),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            configured = lds;
-        }
+        if (lds > 48 * 1024)   // per DEVICE attribute: set on every large launch
+            XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k2_topk_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k2_topk_lds, dim3(P.nrows), dim3(64), lds, s, a);
     }
     XRL_LAUNCH_CHECK();

@@ -186,6 +186,7 @@ std::unique_ptr<Model> load_mmap_model_from_disk(const std::string& path) {
             perm_inv.assign(pinv, pinv + ni);
             orig_rows = (uint32_t)np;
             if (ni != C.rows) fail(lp + "/perm.mmap_store: size does not match C");
+            for (uint64_t i = 0; i < ni; ++i) if (perm_inv[i] >= np) fail(lp + "/perm.mmap_store: perm_inv entry out of range");
         }
         m->layers.push_back(compile_layer(W, C, bias, topk, pp, perm_inv.empty() ? nullptr : &perm_inv, orig_rows));
     }
