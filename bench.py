@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--cache", default="/tmp/xrl_bench")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-abi", action="store_true")
+    ap.add_argument("--no-stats", action="store_true", help="skip the untimed matched-work stats pass (PMC collection runs: only the timed kernels launch)")
     ap.add_argument("--host-steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--k1-group", type=int, default=0)
@@ -234,7 +235,7 @@ def main():
 def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_step):
     import scipy.sparse as smat
     sparse = smat.issparse(Xs)
-    st = clib.predict_stats(h, q, beam, None, args.topk) if rows else []
+    st = clib.predict_stats(h, q, beam, None, args.topk) if (rows and not args.no_stats) else []
     nnz = float(Xs.nnz) if sparse else float(Xs.size)
     x_bytes_q = 8.0 * nnz if sparse else 4.0 * nnz               # the query rows read once
 

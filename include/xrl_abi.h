@@ -179,6 +179,20 @@ void* xrl_model_create(uint32_t depth, const ScipyCscF32* const* W, const ScipyC
 /* Device-resident queries: upload once, predict many times (bench / multi-GPU shards). */
 void* xrl_queries_upload_csr(void* model, const ScipyCsrF32* X);
 void* xrl_queries_upload_drm(void* model, const ScipyDrmF32* X);
+/* Queries that are ALREADY in HBM (a GPU featurizer, a torch tensor): wrap device pointers without copying -- CSR with u64
+ * row_ptr[rows+1], u32 col_idx (sorted inside every row, as the reference requires, pecos/core/base.py:1073-1076), f32 val; or a
+ * dense row-major f32 matrix.  The handle does not own the arrays; they must stay valid until xrl_queries_free.  This is the
+ * hand-off for the callers of SURVEY.md N4 (c_tfidf_predict's output, Text2Text, pecos/apps/text2text/model.py:416-417): no host
+ * round trip of X. */
+void* xrl_queries_from_device_csr(void* model, uint32_t rows, uint32_t cols, const uint64_t* d_row_ptr,
+                                  const uint32_t* d_col_idx, const float* d_val, uint64_t nnz);
+void* xrl_queries_from_device_drm(void* model, uint32_t rows, uint32_t cols, const float* d_val);
+/* The query form of XR-Transformer's concat_model (TransformerMatcher.concat_features + smat_util.hstack_csr,
+ * pecos/xmc/xtransformer/matcher.py:864-890, model.py:589-603): [X_feat (device CSR, sparse_cols columns) | X_emb (device dense
+ * rows x dense_cols, already normalised by the caller)] assembled into one device CSR owned by the returned handle. */
+void* xrl_queries_concat_device(void* model, uint32_t rows, uint32_t sparse_cols, const uint64_t* d_row_ptr,
+                                const uint32_t* d_col_idx, const float* d_val, uint64_t nnz, uint32_t dense_cols,
+                                const float* d_emb, void* hip_stream);
 void xrl_queries_free(void* queries);
 
 /* Beam search with inputs already resident in HBM.  Writes fixed-stride results

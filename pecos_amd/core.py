@@ -194,6 +194,9 @@ class corelib(object):
             "xrl_model_create": (c_void_p, [c_uint32, c_void_p, c_void_p, POINTER(c_float), POINTER(c_uint32), POINTER(c_char_p)]),
             "xrl_queries_upload_csr": (c_void_p, [c_void_p, POINTER(ScipyCsrF32)]),
             "xrl_queries_upload_drm": (c_void_p, [c_void_p, POINTER(ScipyDrmF32)]),
+            "xrl_queries_from_device_csr": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64]),
+            "xrl_queries_from_device_drm": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p]),
+            "xrl_queries_concat_device": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_void_p]),
             "xrl_queries_free": (None, [c_void_p]),
             "xrl_predict_device": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int]),
             "xrl_predict_stats": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, POINTER(c_double), c_uint32]),
@@ -409,6 +412,25 @@ class corelib(object):
             h = lib.xrl_queries_upload_drm(c_void_p(c_model), byref(ScipyDrmF32.init_from(X)))
         else:
             raise NotImplementedError("type(X) = {} not implemented".format(type(X)))
+        self._check()
+        return h
+
+    def queries_from_device_csr(self, c_model, rows, cols, row_ptr_addr, col_idx_addr, val_addr, nnz):
+        """Wrap a CSR that already lives in HBM (raw device addresses: u64 row_ptr, u32 col_idx, f32 val); non-owning."""
+        h = self.clib_float32.xrl_queries_from_device_csr(c_void_p(c_model), rows, cols, c_void_p(row_ptr_addr), c_void_p(col_idx_addr),
+                                                          c_void_p(val_addr), nnz)
+        self._check()
+        return h
+
+    def queries_from_device_drm(self, c_model, rows, cols, val_addr):
+        h = self.clib_float32.xrl_queries_from_device_drm(c_void_p(c_model), rows, cols, c_void_p(val_addr))
+        self._check()
+        return h
+
+    def queries_concat_device(self, c_model, rows, sparse_cols, row_ptr_addr, col_idx_addr, val_addr, nnz, dense_cols, emb_addr, stream=None):
+        """[X_feat (device CSR) | X_emb (device dense)] -> one device CSR (XR-Transformer concat_model's query form)."""
+        h = self.clib_float32.xrl_queries_concat_device(c_void_p(c_model), rows, sparse_cols, c_void_p(row_ptr_addr), c_void_p(col_idx_addr),
+                                                        c_void_p(val_addr), nnz, dense_cols, c_void_p(emb_addr), c_void_p(stream or 0))
         self._check()
         return h
 

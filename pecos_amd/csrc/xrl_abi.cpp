@@ -715,6 +715,58 @@ void* xrl_queries_upload_drm(void* model, const ScipyDrmF32* X) {
     return out;
 }
 
+void* xrl_queries_from_device_csr(void* model, uint32_t rows, uint32_t cols, const uint64_t* d_row_ptr, const uint32_t* d_col_idx,
+                                  const float* d_val, uint64_t nnz) {
+    void* out = nullptr;
+    guarded([&] {
+        Model& m = *as_model(model);
+        if (rows && (!d_row_ptr || (nnz && (!d_col_idx || !d_val)))) fail("xrl_queries_from_device_csr: null device pointer");
+        auto q = std::make_unique<Queries>();
+        q->device = m.device; q->nnz = nnz;
+        q->dev.row_ptr = d_row_ptr; q->dev.col_idx = d_col_idx; q->dev.val = d_val;
+        q->dev.rows = rows; q->dev.cols = cols; q->dev.dense = 0; q->dev.nnz = nnz;
+        out = q.release();
+    });
+    return out;
+}
+
+void* xrl_queries_from_device_drm(void* model, uint32_t rows, uint32_t cols, const float* d_val) {
+    void* out = nullptr;
+    guarded([&] {
+        Model& m = *as_model(model);
+        if (rows && cols && !d_val) fail("xrl_queries_from_device_drm: null device pointer");
+        auto q = std::make_unique<Queries>();
+        q->device = m.device;
+        q->dev.row_ptr = nullptr; q->dev.col_idx = nullptr; q->dev.val = d_val;
+        q->dev.rows = rows; q->dev.cols = cols; q->dev.dense = 1; q->dev.nnz = 0;
+        out = q.release();
+    });
+    return out;
+}
+
+void* xrl_queries_concat_device(void* model, uint32_t rows, uint32_t sparse_cols, const uint64_t* d_row_ptr, const uint32_t* d_col_idx,
+                                const float* d_val, uint64_t nnz, uint32_t dense_cols, const float* d_emb, void* hip_stream) {
+    void* out = nullptr;
+    guarded([&] {
+        Model& m = *as_model(model);
+        if (rows && (!d_row_ptr || (nnz && (!d_col_idx || !d_val)) || (dense_cols && !d_emb))) fail("xrl_queries_concat_device: null device pointer");
+        use_device(m.device);
+        auto q = std::make_unique<Queries>();
+        q->device = m.device;
+        const uint64_t out_nnz = nnz + (uint64_t)rows * dense_cols;
+        q->ptr.reserve(((size_t)rows + 1) * 8); q->idx.reserve(out_nnz * 4); q->val.reserve(out_nnz * 4);
+        hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m.stream;
+        launch_concat_csr(d_row_ptr, d_col_idx, d_val, d_emb, rows, sparse_cols, dense_cols, q->ptr.as<uint64_t>(), q->idx.as<uint32_t>(),
+                          q->val.as<float>(), s);
+        XRL_HIP(hipStreamSynchronize(s));
+        q->nnz = out_nnz;
+        q->dev.row_ptr = q->ptr.as<uint64_t>(); q->dev.col_idx = q->idx.as<uint32_t>(); q->dev.val = q->val.as<float>();
+        q->dev.rows = rows; q->dev.cols = sparse_cols + dense_cols; q->dev.dense = 0; q->dev.nnz = out_nnz;
+        out = q.release();
+    });
+    return out;
+}
+
 void xrl_queries_free(void* queries) {
     guarded([&] {
         if (!queries) return;

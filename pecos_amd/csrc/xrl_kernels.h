@@ -79,6 +79,9 @@ void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const 
 // K1C (xrl_pairs.hip): the CSC route of a layer (w_ops<csc_t>, inference.hpp:1081-1149) over the candidates K0 laid out
 void launch_k1c_csc(const LayerDev& L, const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const LayerPlan& P,
                     const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* ncand, float* cand, hipStream_t s);
+// [X_feat | X_emb] -> one CSR on the device (concat_model's query form, matcher.py:864-890)
+void launch_concat_csr(const uint64_t* in_ptr, const uint32_t* in_idx, const float* in_val, const float* emb, uint32_t rows,
+                       uint32_t sparse_cols, uint32_t dense_cols, uint64_t* out_ptr, uint32_t* out_idx, float* out_val, hipStream_t s);
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
 // K1Q (xrl_k1q.hip): a whole layer -- prolongate, chunk products against the DENSE row format, post-processor,
 // combine, top-k, child re-ordering -- in one query-stationary kernel: previous beam in, next beam out.

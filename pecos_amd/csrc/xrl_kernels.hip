@@ -1122,6 +1122,36 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
 }
 
 // ---------------------------------------------------------------------------------------------
+// Query-side helper for device-resident featurizers: [X_feat | X_emb] as one CSR, the query form of
+// XR-Transformer's concat_model (TransformerMatcher.concat_features, pecos/xmc/xtransformer/matcher.py:864-890 followed by
+// smat_util.hstack_csr): row r = the sparse features of row r, then dense_cols entries with column ids sparse_cols + j.
+// One wavefront per row; the output row pointer is closed-form (in_ptr[r] + r * dense_cols).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+concat_csr_kernel(const uint64_t* __restrict__ in_ptr, const uint32_t* __restrict__ in_idx, const float* __restrict__ in_val,
+                  const float* __restrict__ emb, uint32_t rows, uint32_t sparse_cols, uint32_t dense_cols,
+                  uint64_t* __restrict__ out_ptr, uint32_t* __restrict__ out_idx, float* __restrict__ out_val) {
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (r > rows) return;
+    const uint64_t ob = in_ptr[r] + (uint64_t)r * dense_cols;
+    if (lane == 0) out_ptr[r] = ob;
+    if (r == rows) return;
+    const uint64_t ib = in_ptr[r];
+    const uint32_t n = (uint32_t)(in_ptr[r + 1] - ib);
+    for (uint32_t t = lane; t < n; t += 64u) { out_idx[ob + t] = in_idx[ib + t]; out_val[ob + t] = in_val[ib + t]; }
+    const float* __restrict__ e = emb + (uint64_t)r * dense_cols;
+    for (uint32_t j = lane; j < dense_cols; j += 64u) { out_idx[ob + n + j] = sparse_cols + j; out_val[ob + n + j] = e[j]; }
+}
+
+void launch_concat_csr(const uint64_t* in_ptr, const uint32_t* in_idx, const float* in_val, const float* emb, uint32_t rows,
+                       uint32_t sparse_cols, uint32_t dense_cols, uint64_t* out_ptr, uint32_t* out_idx, float* out_val, hipStream_t s) {
+    hipLaunchKernelGGL(concat_csr_kernel, dim3((rows + 1u + 3u) / 4u), dim3(256), 0, s, in_ptr, in_idx, in_val, emb, rows, sparse_cols,
+                       dense_cols, out_ptr, out_idx, out_val);
+    XRL_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
 // stats (not on the timed path): algorithmic bytes of the reference layout touched by a layer
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)

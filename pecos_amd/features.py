@@ -1,0 +1,66 @@
+"""Query-side hand-offs for callers that produce X on the GPU or in pieces.
+
+* :func:`concat_features` -- host mirror of ``TransformerMatcher.concat_features``
+  (pecos/xmc/xtransformer/matcher.py:864-890): [numerical features | (row-normalised) embeddings], the matrix
+  XR-Transformer's ``concat_model`` predicts on (pecos/xmc/xtransformer/model.py:589-603).
+* :func:`predict_from_torch` -- X already in HBM as torch tensors (a GPU TF-IDF featurizer's CSR -- the reference's
+  ``c_tfidf_predict`` produces that CSR on the host, pecos/core/libpecos.cpp:427-445 -- optionally with a dense embedding block to
+  append on the device): no host round trip of X, results stay on the device.
+"""
+import numpy as np
+import scipy.sparse as smat
+
+from .core import clib
+
+
+def concat_features(X_feat, X_emb, normalize_emb=True):
+    """matcher.py:864-890 on the host, same operations in the same order (sklearn's ``normalize``, ``dense_to_csr``, ``hstack_csr``)."""
+    if normalize_emb:
+        from sklearn.preprocessing import normalize as sk_normalize
+        X_cat = sk_normalize(X_emb)
+    else:
+        X_cat = X_emb
+    if isinstance(X_feat, smat.csr_matrix):
+        X_cat = smat.hstack([X_feat, smat.csr_matrix(X_cat, dtype=np.float32)], format="csr", dtype=np.float32)
+        X_cat.sort_indices()
+    elif isinstance(X_feat, np.ndarray):
+        X_cat = np.hstack([X_feat, X_cat])
+    elif X_feat is None:
+        pass
+    else:
+        raise TypeError(f"Expected CSR or ndarray, got {type(X_feat)}")
+    return X_cat
+
+
+def predict_from_torch(model, crow, col, val, n_cols, beam_size=None, only_topk=None, post_processor=None, emb=None, stream=None):
+    """Beam search on queries that are already on the GPU.
+
+    crow: int64 [rows+1], col: int32 [nnz] (sorted inside every row), val: float32 [nnz] -- CUDA tensors of a CSR with
+    ``n_cols`` columns; emb: optional float32 [rows, H] CUDA tensor appended as columns n_cols .. n_cols+H-1 on the device
+    (normalise it first if the model was trained on normalised embeddings).  Returns CUDA tensors
+    (labels int32 [rows, k], scores float32 [rows, k], counts int32 [rows]); row r holds counts[r] valid entries, best first."""
+    import torch
+    h = model.model.model_chain
+    assert crow.is_cuda and col.is_cuda and val.is_cuda and crow.dtype == torch.int64 and col.dtype == torch.int32 and val.dtype == torch.float32
+    crow, col, val = crow.contiguous(), col.contiguous(), val.contiguous()
+    rows = crow.numel() - 1
+    nnz = int(val.numel())
+    torch.cuda.current_stream().synchronize()          # the inputs were produced on torch's stream
+    if emb is not None:
+        assert emb.is_cuda and emb.dtype == torch.float32 and emb.shape[0] == rows
+        emb = emb.contiguous()
+        q = clib.queries_concat_device(h, rows, n_cols, crow.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, emb.shape[1], emb.data_ptr())
+    else:
+        q = clib.queries_from_device_csr(h, rows, n_cols, crow.data_ptr(), col.data_ptr(), val.data_ptr(), nnz)
+    try:
+        k = clib.effective_topk(h, only_topk)
+        idx = torch.zeros((rows, k), dtype=torch.int32, device=val.device)
+        sc = torch.zeros((rows, k), dtype=torch.float32, device=val.device)
+        cnt = torch.zeros((rows,), dtype=torch.int32, device=val.device)
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        if rows:
+            clib.predict_device(h, q, beam_size, post_processor, only_topk, idx.data_ptr(), sc.data_ptr(), cnt.data_ptr(), k,
+                                stream=s or None, sync=True)
+    finally:
+        clib.queries_free(q)
+    return idx, sc, cnt

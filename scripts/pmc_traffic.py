@@ -1,5 +1,5 @@
 """Build profiles/pmc_traffic.json from rocprofv3 counter-collection CSVs taken over
-`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi` (each counter set in its own run, --kernel-trace only).
+`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats` (each counter set in its own run, --kernel-trace only).
 
 usage: pmc_traffic.py <fetch.csv> <write.csv> <l2req.csv|-> <out.json> [fetch_factor]
 
@@ -42,7 +42,7 @@ for fam in f:
 json.dump({
     "config": "amazon-670k", "scale": 1.0, "n_gpus": 1, "fetch_factor": factor,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCP_TCC_READ_REQ_sum (separate passes, --kernel-trace only) over "
-              "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi`; mean over the launches of the family in a step; "
+              "`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats`; mean over the launches of the family in a step; "
               "bytes = (FETCH_SIZE x fetch_factor + WRITE_SIZE) KiB, fetch_factor from the calibration run on 8..64-byte gathers "
               "(profiles/r02_calib_fetch.md); counts fabric requests, Infinity-Cache hits included",
     "kernels": kernels,

@@ -1,0 +1,79 @@
+"""GPU (-m gpu): queries that are already in HBM and the RCCL step of bench.py with one rank.
+
+* device CSR / dense hand-off (xrl_queries_from_device_*): same bits as the host-ABI predict;
+* concat_model's query form [X_feat | X_emb] assembled on the device (xrl_queries_concat_device) == predicting on the
+  host-side TransformerMatcher.concat_features matrix;
+* bench.py's step -- predict on an explicit stream followed by ONE packed all_gather_into_tensor -- under
+  torch.distributed.run with the "nccl" (= RCCL) backend and one rank, so that RCCL initialisation and the collective on a
+  non-default stream have executed on hardware at least once before the driver's multi-GPU run."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import scipy.sparse as smat
+
+from conftest import GOLDEN, REPO, assert_same_topk, load_X
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows_to_csr(idx, val, cnt, n_cols):
+    from pecos_amd.distributed import rows_to_csr
+    return rows_to_csr(idx.cpu().numpy().view(np.uint32), val.cpu().numpy(), cnt.cpu().numpy(), n_cols)
+
+
+def test_device_resident_queries_and_concat():
+    import torch
+    from pecos_amd import XLinearModel, clib
+    from pecos_amd.features import concat_features, predict_from_torch
+    folder = os.path.join(GOLDEN, "synth", "s_eurlex")
+    X = load_X(os.path.join(GOLDEN, "synth", "s_eurlex__X.npz"))
+    m = XLinearModel.load(folder)
+    dev = torch.device("cuda", 0)
+    kw = dict(beam_size=5, only_topk=7)
+    want = m.predict(X, **kw)
+    crow = torch.from_numpy(X.indptr.astype(np.int64)).to(dev); col = torch.from_numpy(X.indices.astype(np.int32)).to(dev)
+    val = torch.from_numpy(X.data.astype(np.float32)).to(dev)
+    got = _rows_to_csr(*predict_from_torch(m, crow, col, val, X.shape[1], **kw), m.nr_pred_cols)
+    assert_same_topk(got, want, exact_scores=True, what="device-resident CSR")
+    # dense device matrix
+    Xd = np.ascontiguousarray(X.toarray())
+    td = torch.from_numpy(Xd).to(dev)
+    h = m.model.model_chain
+    q = clib.queries_from_device_drm(h, Xd.shape[0], Xd.shape[1], td.data_ptr())
+    k = clib.effective_topk(h, 7)
+    idx = torch.zeros((Xd.shape[0], k), dtype=torch.int32, device=dev); sc = torch.zeros((Xd.shape[0], k), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((Xd.shape[0],), dtype=torch.int32, device=dev)
+    clib.predict_device(h, q, 5, None, 7, idx.data_ptr(), sc.data_ptr(), cnt.data_ptr(), k, sync=True)
+    clib.queries_free(q)
+    assert_same_topk(_rows_to_csr(idx, sc, cnt, m.nr_pred_cols), m.predict(Xd, **kw), exact_scores=True, what="device-resident dense X")
+    # concat_model form: the last H feature columns play the embedding block
+    H = 24
+    D = X.shape[1]
+    X_feat = X[:, : D - H].tocsr(); X_feat.sort_indices()
+    emb = np.ascontiguousarray(X[:, D - H:].toarray()) + np.float32(0.25)      # dense block, no zeros
+    host_cat = concat_features(X_feat, emb, normalize_emb=False)
+    want_cat = m.predict(host_cat, **kw)
+    fcrow = torch.from_numpy(X_feat.indptr.astype(np.int64)).to(dev); fcol = torch.from_numpy(X_feat.indices.astype(np.int32)).to(dev)
+    fval = torch.from_numpy(X_feat.data.astype(np.float32)).to(dev)
+    got_cat = _rows_to_csr(*predict_from_torch(m, fcrow, fcol, fval, D - H, emb=torch.from_numpy(emb).to(dev), **kw), m.nr_pred_cols)
+    assert_same_topk(got_cat, want_cat, exact_scores=True, what="[X_feat | X_emb] assembled on the device")
+    # normalised embeddings (the reference's default): host mirror == sklearn on the same data
+    nrm = concat_features(X_feat, emb, normalize_emb=True)
+    assert nrm.shape == host_cat.shape and np.allclose(np.asarray(nrm[:, D - H:].multiply(nrm[:, D - H:]).sum(axis=1)).ravel(), 1.0, atol=1e-5)
+
+
+@pytest.mark.timeout(600)
+def test_bench_step_under_rccl_one_rank(tmp_path):
+    env = dict(os.environ, XRL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(REPO, "bench.py"), "--gpus", "1", "--config", "eurlex-4k", "--scale", "0.25",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-abi", "--cache", str(tmp_path / "cache")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
