@@ -253,6 +253,8 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *                         pinned memory and uploaded on a copy stream while batch b computes; 0: one synchronous upload
  *   "dense_layers"        1 (default): layers that carry the dense row format run the fused query-stationary kernel K1Q
  *                         whenever the beam's candidates fit its registers; 0: tile-format kernels K0 -> K1 -> K2 everywhere
+ *   "k1g_min_items"       dense X: a dense-format layer runs the tiled, k-ordered SGEMM K1G (tile-sorted items, weight and query
+ *                         panels staged in LDS) once a parent serves this many queries on average (default 16; 0 = never: K1Q)
  *   "k2_legacy"           1: round-1 insertion top-k kernels instead of the ballot-bisection K2 (A/B, tests)
  *   "k1_wpb", "k1_lds_pad", "k1_ablate"   debug: wavefronts per K1 workgroup, extra LDS per wavefront, phase ablation
  * Environment read at model load: XRL_K1T=1 (build K1T tile images), XRL_LOOKUP=bitmap|bitmap64|bucket (force the row

@@ -1,0 +1,249 @@
+// K1G: the dense-QUERY chunk products of a layer as a tiled, k-ordered SGEMM (chunk_ops<drm, bin_search>,
+// inference.hpp:815-839, for dense-format layers).
+//
+// With dense X every (query, parent) item multiplies the query's D features into the parent's chunk: per item D x ncols
+// multiply-adds over weights that every other query of the same parent needs too.  K1Q (query-stationary) streams the
+// weight rows once PER QUERY -- BASELINE.json's dense-input config (D = 768, 3 M labels) then moves ~4 MB of weights per
+// query through the L2.  K1G turns the loop nest around, the way a GEMM does:
+//   * the layer's items are tile-sorted (counting sort of xrl_kernels.hip), so the queries that share a parent are adjacent;
+//   * a workgroup owns ONE parent and up to QB of its queries: the parent's weight panel W[k0..k0+64, cols] and the queries'
+//     X[q, k0..k0+64] are staged in LDS once per 64-feature step and every weight is reused QB times, every x value WP times;
+//   * lane (cl, ql) holds an RQ x RC register tile of accumulators: queries {ql + 8 r}, columns {cl + 8 c}; per 4 features it
+//     reads RQ + RC float4 from LDS (conflict-free: 8 column lanes x 16 B and 8 query lanes x 16 B cover distinct banks) for
+//     4 RQ RC multiply-adds.
+// It is NOT an MFMA kernel: v_mfma_f32_* fuses the multiply and the add (one rounding), the reference rounds twice
+// (`output[c] += x * w` compiled without FMA), and the round's contract is bit-identical label order.  Each accumulator
+// therefore walks k in ascending order with a separate fp32 multiply and add (-ffp-contract=off), bias first -- exactly the
+// reference's chain -- and what the matrix cores would have bought, operand reuse, comes from the LDS/register tiling.
+// Roofline: 2 VALU lane-ops per multiply-add -> 39 T multiply-adds/s at 2.4 GHz (half the 157 TFLOP/s fp32 vector peak).
+//
+// Layers whose dense matrix holds kMissing cells (W has no entry there: sparse weight columns under dense X) run the MISS
+// variant, which skips those cells exactly like the reference's row walk does (select on the bit pattern, 4 lane-ops).
+#include <hip/hip_runtime.h>
+
+#include "xrl_device.h"
+#include "xrl_kernels.h"
+
+namespace xrl {
+
+#define XRL_LAUNCH_CHECK() XRL_HIP(hipGetLastError())
+
+struct alignas(16) ItemDescG {   // == ItemDesc of xrl_kernels.hip (K0 writes it)
+    uint32_t q, tile, out_off; float pscore;
+    uint64_t x_begin; uint32_t x_len, pad;
+};
+constexpr uint32_t kNoTileG = 0xFFFFFFFFu;
+
+constexpr int KC = 64;            // features per LDS step
+constexpr int LDK = KC + 4;       // row stride of the x panel in LDS (floats): 16-byte aligned rows on distinct banks
+
+struct K1GArgs {
+    LayerDev L; QueriesDev X;
+    const ItemDescG* items;       // tile-sorted, all active
+    const uint32_t* start;        // [n_tiles+1] first sorted item of every tile
+    const uint32_t* blk_start;    // [n_tiles+1] first workgroup of every tile
+    float* cand;
+    uint32_t row0;
+    int pp_kind, pp_p, first_layer;
+};
+
+// per tile: number of workgroups = ceil(items / qb)   (exclusive-scanned afterwards)
+__global__ void __launch_bounds__(256) k1g_count_blocks(const uint32_t* __restrict__ start, uint32_t n_tiles, uint32_t qb, uint32_t* __restrict__ blk) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < n_tiles) blk[t] = (start[t + 1] - start[t] + qb - 1u) / qb;
+}
+
+// single block: exclusive scan of v[0..n) in place; v[n] = grand total
+__global__ void __launch_bounds__(1024) k1g_scan_kernel(uint32_t* __restrict__ v, uint32_t n) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t x = i < n ? v[i] : 0u;
+        part[threadIdx.x] = x;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t t = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) v[i] = carry + part[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) v[n] = carry;
+}
+
+template <int RQ, int RC, bool MISS, int PPC>
+__global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
+    constexpr int QW = 8 * RQ, QB = 4 * QW, WPC = 8 * RC;     // queries per wavefront / workgroup, padded columns per workgroup
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sW = smem;                                           // [KC/4][WPC][4]: float4 groups of 4 consecutive features
+    float* sX = smem + KC * WPC;                                // [QB][LDK]
+    uint32_t* sRow = reinterpret_cast<uint32_t*>(sX + QB * LDK);   // [QB] query row of every item of the workgroup
+    uint32_t* sOut = sRow + QB;                                 // [QB] first candidate slot of the item's child block
+    float* sPs = reinterpret_cast<float*>(sOut + QB);           // [QB] parent score
+
+    const uint32_t T = a.L.n_tiles, b = blockIdx.x;
+    if (b >= a.blk_start[T]) return;
+    uint32_t lo = 0, hi = T;                                    // largest t with blk_start[t] <= b (tiles without items share a start)
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.blk_start[mid] <= b) lo = mid; else hi = mid; }
+    const uint32_t t = lo;
+    const uint32_t i0 = a.start[t] + (b - a.blk_start[t]) * (uint32_t)QB;
+    const uint32_t nq = min((uint32_t)QB, a.start[t + 1] - i0);
+    const TileDesc td = a.L.tiles[t];
+    const uint32_t parent = a.L.tile_parent[t];
+    const uint32_t gl = a.L.d_gp_log2, gmask = (1u << gl) - 1u;
+    const uint32_t dt0 = a.L.d_ptile[parent], ndt = a.L.d_ptile[parent + 1] - dt0;
+    const uint32_t WP = ndt << gl;                              // padded columns of this parent (<= WPC)
+    const uint64_t wbase = (uint64_t)dt0 << gl;
+
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, cl = lane & 7u, ql = lane >> 3;
+    for (uint32_t i = tid; i < (uint32_t)QB; i += 256u) {
+        ItemDescG it{}; it.tile = kNoTileG;
+        if (i < nq) it = a.items[i0 + i];
+        sRow[i] = it.q; sOut[i] = it.out_off; sPs[i] = it.pscore;
+    }
+
+    // this lane's columns: c = cc*8 + cl -> dense tile c >> gl, column c & gmask -> child
+    uint32_t coff[RC]; bool cval[RC];
+    float acc[RQ][RC];
+#pragma unroll
+    for (int cc = 0; cc < RC; ++cc) {
+        const uint32_t c = (uint32_t)cc * 8u + cl;
+        const uint32_t dt = c >> gl, within = c & gmask;
+        bool v = c < WP;
+        const uint32_t dtc = v ? dt0 + dt : 0u;
+        const uint32_t cb = a.L.d_tcol[dtc], ce = a.L.d_tcol[dtc + 1];
+        v = v && within < ce - cb;
+        cval[cc] = v; coff[cc] = v ? cb + within : 0u;
+        const float b0 = (v && a.L.has_bias) ? a.L.bias_prod[coff[cc]] : 0.0f;       // bias FIRST (inference.hpp:824-830)
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) acc[r][cc] = b0;
+    }
+
+    const uint32_t w_rows = a.L.w_rows, n_feat = a.L.has_bias ? w_rows - 1u : w_rows;
+    const uint64_t ld = a.L.d_ld;
+    const uint32_t* __restrict__ wd = a.L.wd;
+    const float* __restrict__ xg = a.X.val;
+    const uint32_t xcols = a.X.cols;
+    const uint32_t padw = MISS ? kMissing : 0u;
+
+    for (uint32_t k0 = 0; k0 < n_feat; k0 += (uint32_t)KC) {
+        __syncthreads();                                        // the previous step's readers are done (and sRow is visible)
+        // ---- weight panel: rows k0..k0+63, the parent's WP padded columns -> sW[k/4][col][k%4] (one 16-byte store per thread step)
+        for (uint32_t e = tid; e < (uint32_t)(KC / 4 * WPC); e += 256u) {
+            const uint32_t g = e / (uint32_t)WPC, col = e % (uint32_t)WPC;
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t f = k0 + g * 4u + (uint32_t)j;
+                w[j] = (col < WP && f < n_feat) ? wd[(uint64_t)f * ld + wbase + col] : padw;
+            }
+            *reinterpret_cast<uint4*>(sW + (size_t)e * 4) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        // ---- query panel: X[row, k0..k0+63] of the workgroup's queries (coalesced along the features)
+        for (uint32_t e = tid; e < (uint32_t)(QB * KC); e += 256u) {
+            const uint32_t qq = e / (uint32_t)KC, k = e % (uint32_t)KC, f = k0 + k;
+            float v = 0.0f;
+            if (qq < nq && f < n_feat && f < xcols) v = xg[((uint64_t)a.row0 + sRow[qq]) * xcols + f];
+            sX[qq * LDK + k] = v;
+        }
+        __syncthreads();
+        // ---- RQ x RC register tile, 4 features per step; every accumulator takes its features in ascending order
+#pragma unroll 2
+        for (int kk = 0; kk < KC; kk += 4) {
+            float4 wv[RC], xv[RQ];
+#pragma unroll
+            for (int cc = 0; cc < RC; ++cc) wv[cc] = *reinterpret_cast<const float4*>(sW + ((size_t)(kk >> 2) * WPC + (size_t)cc * 8 + cl) * 4);
+#pragma unroll
+            for (int r = 0; r < RQ; ++r) xv[r] = *reinterpret_cast<const float4*>(sX + (size_t)(wave * QW + r * 8 + ql) * LDK + kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int r = 0; r < RQ; ++r) {
+                    const float x = j == 0 ? xv[r].x : j == 1 ? xv[r].y : j == 2 ? xv[r].z : xv[r].w;
+#pragma unroll
+                    for (int cc = 0; cc < RC; ++cc) {
+                        const float w = j == 0 ? wv[cc].x : j == 1 ? wv[cc].y : j == 2 ? wv[cc].z : wv[cc].w;
+                        const float s = acc[r][cc] + x * w;     // built with -ffp-contract=off: multiply, round, add, round
+                        if (MISS) acc[r][cc] = (__float_as_uint(w) == kMissing) ? acc[r][cc] : s;
+                        else acc[r][cc] = s;
+                    }
+                }
+            }
+        }
+    }
+    // ---- transform, combine with the parent's score, write the child block
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) {
+        const uint32_t qi = wave * (uint32_t)QW + (uint32_t)r * 8u + ql;
+        if (qi >= nq) continue;
+        const uint32_t out0 = sOut[qi]; const float ps = sPs[qi];
+#pragma unroll
+        for (int cc = 0; cc < RC; ++cc) {
+            if (!cval[cc]) continue;
+            float v = pp_transform<PPC>(a.pp_kind, a.pp_p, acc[r][cc]);
+            if (!a.first_layer) v = pp_combine(a.pp_kind, v, ps);
+            a.cand[(size_t)out0 + (coff[cc] - td.col_begin)] = v;
+        }
+    }
+}
+
+template <int RQ, int RC> struct K1GShape {
+    static constexpr uint32_t QB = 32 * RQ;
+    static constexpr size_t lds() { return ((size_t)KC * 8 * RC + (size_t)QB * LDK + 3 * (size_t)QB) * 4; }
+};
+
+// padded columns a workgroup must cover, or 0 when K1G cannot serve the layer
+uint32_t k1g_cols(const LayerDev& L) {
+    if (!L.wd || !L.tile_parent || L.max_tiles_per_parent != 1) return 0;
+    const uint32_t wp = L.d_max_tiles << L.d_gp_log2;
+    return wp <= 128 ? wp : 0u;
+}
+
+uint32_t k1g_queries_per_block(const LayerDev& L) {
+    const uint32_t wp = k1g_cols(L);
+    return wp <= 8 ? 256u : wp <= 16 ? 256u : wp <= 32 ? 128u : 64u;
+}
+
+void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
+                uint32_t* blk_start, float* cand, hipStream_t s) {
+    if (P.nrows == 0) return;
+    const uint32_t wp = k1g_cols(L);
+    if (wp == 0 || !X.dense) fail("k1g: layer not eligible");
+    const uint32_t qb = k1g_queries_per_block(L);
+    hipLaunchKernelGGL(k1g_count_blocks, dim3((L.n_tiles + 255u) / 256u), dim3(256), 0, s, start, L.n_tiles, qb, blk_start);
+    hipLaunchKernelGGL(k1g_scan_kernel, dim3(1), dim3(1024), 0, s, blk_start, L.n_tiles);
+    K1GArgs a;
+    a.L = L; a.X = X; a.items = static_cast<const ItemDescG*>(items_sorted); a.start = start; a.blk_start = blk_start; a.cand = cand;
+    a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
+    const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
+    const uint64_t blocks = (n_slots + qb - 1) / qb + L.n_tiles;      // every tile adds at most one partial workgroup
+    if (blocks > 0x7FFFFFFFull) fail("k1g: grid too large; lower max_batch_rows");
+    const int ppc = pp_class(P.pp);
+    const bool miss = !L.d_full;
+#define XRL_K1G_GO(RQ, RC, MM, PP) do { \
+        auto kern = &k1g_kernel<RQ, RC, MM, PP>; const size_t lds = K1GShape<RQ, RC>::lds(); \
+        if (lds > 48 * 1024) XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), lds, s, a); } while (0)
+#define XRL_K1G(RQ, RC) do { \
+        if (miss) { if (ppc) XRL_K1G_GO(RQ, RC, true, 1); else XRL_K1G_GO(RQ, RC, true, 0); } \
+        else { if (ppc) XRL_K1G_GO(RQ, RC, false, 1); else XRL_K1G_GO(RQ, RC, false, 0); } } while (0)
+    if (wp <= 8) XRL_K1G(8, 1);
+    else if (wp <= 16) XRL_K1G(8, 2);
+    else if (wp <= 32) XRL_K1G(4, 4);
+    else if (wp <= 64) XRL_K1G(2, 8);
+    else if (wp <= 96) XRL_K1G(2, 12);
+    else XRL_K1G(2, 16);
+#undef XRL_K1G
+#undef XRL_K1G_GO
+    XRL_LAUNCH_CHECK();
+}
+
+}  // namespace xrl

@@ -76,6 +76,10 @@ void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const 
                         const QueriesDev& X, const uint32_t* pair_q, const uint32_t* node, const uint32_t* ppos,
                         const uint64_t* prev_off, const float* prev_val, float* out_val, uint64_t n_pairs,
                         const PostProc& pp, int first_layer, hipStream_t s);
+// K1G (xrl_k1g.hip): dense queries against a dense-format layer as a tiled, k-ordered SGEMM over tile-sorted items
+uint32_t k1g_cols(const LayerDev& L);                 // 0: the layer cannot be served by K1G
+void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
+                uint32_t* blk_start, float* cand, hipStream_t s);
 // K1C (xrl_pairs.hip): the CSC route of a layer (w_ops<csc_t>, inference.hpp:1081-1149) over the candidates K0 laid out
 void launch_k1c_csc(const LayerDev& L, const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const LayerPlan& P,
                     const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* ncand, float* cand, hipStream_t s);

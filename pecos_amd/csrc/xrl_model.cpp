@@ -467,6 +467,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     //      XRL_DENSE_MAX_MB caps one layer's matrix (default 64 GiB, and never more than a quarter of the free HBM).
     std::vector<uint32_t> d_ptile, d_tcol;
     uint32_t d_gp_log2 = 0, d_max_tiles = 0; uint64_t d_ld = 0;
+    bool d_full = false;
     {
         const char* de = std::getenv("XRL_DENSE");
         bool want = !(de && de[0] == '0') && c_nnz > 0 && W.rows > 0 && !structure_only;
@@ -510,6 +511,18 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
             XRL_HIP(hipStreamSynchronize(nullptr));
             L->d_dptile.upload(d_ptile); L->d_dtcol.upload(d_tcol);
             L->dense_bytes = L->d_wd.cap;
+            // does every kept child hold a weight for every feature row (dense-input models do)?
+            const uint32_t n_feat = has_bias ? W.rows - 1 : W.rows;
+            d_full = true;
+            for (uint32_t c = 0; d_full && c < (uint32_t)c_nnz; ++c) {
+                const uint32_t oc = src_col[c];
+                uint64_t n = W.col_ptr[oc + 1] - W.col_ptr[oc];
+                if (has_bias && n > 0 && W.row_idx[W.col_ptr[oc + 1] - 1] == W.rows - 1) --n;
+                d_full = n == n_feat;
+            }
+            std::vector<uint32_t> tile_parent(T, 0);
+            for (uint32_t p = 0; p < P; ++p) for (uint32_t t = ptile[p]; t < ptile[p + 1]; ++t) tile_parent[t] = p;
+            L->d_tile_parent.upload(tile_parent);
         } else {
             d_ptile.clear(); d_tcol.clear();
         }
@@ -557,6 +570,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     d.bias = bias; d.has_bias = has_bias ? 1 : 0;
     d.wd = L->dense_bytes ? L->d_wd.as<uint32_t>() : nullptr; d.d_ld = d_ld; d.d_gp_log2 = d_gp_log2; d.d_max_tiles = d_max_tiles;
     d.d_ptile = L->dense_bytes ? L->d_dptile.as<uint32_t>() : nullptr; d.d_tcol = L->dense_bytes ? L->d_dtcol.as<uint32_t>() : nullptr;
+    d.d_full = d_full ? 1 : 0; d.tile_parent = L->dense_bytes ? L->d_tile_parent.as<uint32_t>() : nullptr;
     return L;
 }
 

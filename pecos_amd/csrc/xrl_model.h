@@ -84,6 +84,8 @@ struct LayerDev {
     uint32_t d_max_tiles;        // max dense tiles per parent
     const uint32_t* d_ptile;     // [n_parents+1] dense tiles of parent p
     const uint32_t* d_tcol;      // [n_dtiles+1] first child column of every dense tile (children are contiguous)
+    int d_full;                  // every (feature, kept child) cell of the dense matrix holds a weight (no kMissing): K1G's 2-op inner loop
+    const uint32_t* tile_parent; // [n_tiles] parent of every tile-format tile (K1G walks tile-sorted items)
 };
 
 struct Layer {
@@ -108,7 +110,7 @@ struct Layer {
     // device storage
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
     DevBuf d_img, d_img_off, d_bucket, d_bitmap64;
-    DevBuf d_wd, d_dptile, d_dtcol;          // dense row format (see LayerDev::wd)
+    DevBuf d_wd, d_dptile, d_dtcol, d_tile_parent;   // dense row format (see LayerDev::wd)
     uint64_t dense_bytes = 0;
     uint32_t bk_shift = 0, bk_n = 0, bk_levels = 0;
     LayerDev dev{};
@@ -125,6 +127,7 @@ struct LaneWs {      // scratch of one row batch in flight
     DevBuf beam_idx[2], beam_val[2], beam_cnt[2];
     DevBuf cand_off, ncand, cand;
     DevBuf items, items_sorted, sort_hist, sort_start;   // item descriptors (K0) and their tile-sorted copy
+    DevBuf blk_start;                                    // K1G: first workgroup of every tile
 };
 struct Workspace {
     LaneWs lane[2];      // two row batches are in flight on two streams (xrl_predict.cpp)
@@ -160,6 +163,7 @@ struct Model {
     int k1t_items_per_block = 1024;
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
+    int k1g_min_items = 16;                 // dense X: run a dense-format layer as the tiled SGEMM K1G once a parent serves this many queries on average (0 = never)
     int k2_legacy = 0;                      // A/B and tests: 1 = round-1 insertion top-k kernels instead of the ballot-bisection K2
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
     bool profiling = false;

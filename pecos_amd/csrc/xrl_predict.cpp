@@ -53,7 +53,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         pp[l] = o.post_processor ? parse_post_processor(o.post_processor) : L.pp;
         uint64_t bin = (l == 0) ? (has_init ? std::max<uint32_t>(1, o.initial_max) : 1)
                                 : std::min<uint64_t>(k[l - 1], cstride[l - 1]);
-        bin = std::min<uint64_t>(bin, L.c_cols ? L.c_cols : 1);
+        if (!(l == 0 && has_init)) bin = std::min<uint64_t>(bin, L.c_cols ? L.c_cols : 1);   // explicit codes may list a parent more than once
         beam_in[l] = (uint32_t)std::max<uint64_t>(1, bin);
         const uint64_t cb = std::max<uint64_t>(1, (l == 0 && has_init && o.initial_cand_bound) ? o.initial_cand_bound : L.cand_bound(beam_in[l]));
         if (cb > 0x7FFFFFFFull) fail("candidate row too long; lower beam_size");
@@ -94,6 +94,9 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         const Layer& L = *m.layers[l];
         if (L.n_tiles > sort_max_tiles()) return 0;
         const uint64_t slots = rows * beam_in[l] * L.max_tiles_per_parent;
+        // 3 = K1G: dense queries against a dense-format layer as a tiled SGEMM over tile-sorted items
+        if (X.dense && m.dense_layers && m.k1g_min_items > 0 && !csc && k1g_cols(L.dev) != 0 && k[l] <= k2_max_k() &&
+            slots / std::max<uint32_t>(1, L.n_tiles) >= (uint64_t)m.k1g_min_items) return 3;
         if (!X.dense && m.k1t_min_items > 0 && k1t_waves(L.dev) > 0 && slots / L.n_tiles >= (uint64_t)m.k1t_min_items) return 2;
         if (m.sort_min_tiles > 0 && L.n_tiles >= (uint32_t)m.sort_min_tiles) return 1;
         return 0;
@@ -108,7 +111,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 tiles_max = std::max(tiles_max, L.n_tiles);
             }
         }
-        if (any) for (int ln = 0; ln < lanes; ++ln) { LaneWs& lw = ws.lane[ln]; lw.items_sorted.reserve(slots_max * k0_item_bytes()); lw.sort_hist.reserve(hist_max); lw.sort_start.reserve(((size_t)tiles_max + 1) * 4); }
+        if (any) for (int ln = 0; ln < lanes; ++ln) { LaneWs& lw = ws.lane[ln]; lw.items_sorted.reserve(slots_max * k0_item_bytes()); lw.sort_hist.reserve(hist_max); lw.sort_start.reserve(((size_t)tiles_max + 1) * 4); lw.blk_start.reserve(((size_t)tiles_max + 1) * 4); }
     }
     for (int ln = 0; ln < lanes; ++ln) { LaneWs& lw = ws.lane[ln]; lw.cand_off.reserve(nb * bin_max * 4); lw.ncand.reserve(nb * 4); lw.cand.reserve(nb * (uint64_t)cs_max * 4); }
     if (o.stats_out) {
@@ -176,6 +179,14 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
                 timed("k1c_csc", (uint32_t)l, [&] { launch_k1c_csc(L.dev, Lm.d_csc_ptr.as<uint64_t>(), Lm.d_csc_idx.as<uint32_t>(), Lm.d_csc_val.as<float>(), P, X, prev,
                                                                    lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), S); });
+                timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
+                continue;
+            }
+            if (!o.stats_out && layer_mode(l, nrows) == 3) {
+                timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
+                const uint64_t n_slots3 = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
+                timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots3, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
+                timed("k1g_dense_x", (uint32_t)l, [&] { launch_k1g(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.cand.as<float>(), S); });
                 timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
                 continue;
             }

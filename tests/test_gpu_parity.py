@@ -159,11 +159,14 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         del mb
     if X.shape[1] <= 6000:
         Xd = np.ascontiguousarray(X[:64].toarray())
-        for dl in (1, 0):
+        for dl, g in ((1, 0), (1, 1), (0, 0)):     # K1Q / the tiled SGEMM K1G forced on every eligible layer / tile format
             clib.set_option(m.model.model_chain, "dense_layers", dl)
-            assert_same_topk(m.predict(Xd, beam_size=4, only_topk=6), ref.predict(Xd, beam_size=4, only_topk=6),
-                             exact_scores=True, what=f"dense X, dense_layers={dl}")
+            clib.set_option(m.model.model_chain, "k1g_min_items", g)
+            for kw in (dict(beam_size=4, only_topk=6), dict(beam_size=cfg["beam"], only_topk=10, post_processor="sigmoid"), dict(beam_size=70, only_topk=100)):
+                assert_same_topk(m.predict(Xd, **kw), ref.predict(Xd, **kw), exact_scores=EXACT_PP(kw.get("post_processor")),
+                                 what=f"dense X, dense_layers={dl} k1g_min_items={g} {kw}")
         clib.set_option(m.model.model_chain, "dense_layers", 1)
+        clib.set_option(m.model.model_chain, "k1g_min_items", 16)
 
 
 def test_full_width_rows_every_lookup(XLM, clib, oracle_mod, tmp_path):
@@ -524,6 +527,14 @@ def test_dense_input_config_vs_reference(XLM, clib, oracle_mod, tmp_path):
     want = ref.predict(X[:ns], threads=32, **kw) if oracle_mod.ref_available() else ref.predict(X[:ns], **kw)
     got = smat.csr_matrix((P.data[:P.indptr[ns]], P.indices[:P.indptr[ns]], P.indptr[:ns + 1]), shape=(ns, P.shape[1]))
     assert_same_topk(got, want, exact_scores=True, what="dense-768 vs reference")
-    clib.set_option(m.model.model_chain, "dense_layers", 0)
-    Pt = m.predict(X[:8192], **kw)
-    assert np.array_equal(Pt.indices, P.indices[:P.indptr[8192]]) and np.array_equal(Pt.data.view(np.uint32), P.data[:P.indptr[8192]].view(np.uint32))
+    # the default above ran the tiled SGEMM K1G on every layer (50k dense queries share few parents); the query-stationary
+    # kernel K1Q and the tile-format kernels must give the same bits
+    clib.profile_enable(m.model.model_chain, True); clib.profile_reset(m.model.model_chain)
+    m.predict(X[:8192], **kw)
+    names = {r["name"] for r in clib.profile_get(m.model.model_chain)}
+    clib.profile_enable(m.model.model_chain, False)
+    assert "k1g_dense_x" in names, names
+    for opt, val in (("k1g_min_items", 0), ("dense_layers", 0)):
+        clib.set_option(m.model.model_chain, opt, val)
+        Pt = m.predict(X[:8192], **kw)
+        assert np.array_equal(Pt.indices, P.indices[:P.indptr[8192]]) and np.array_equal(Pt.data.view(np.uint32), P.data[:P.indptr[8192]].view(np.uint32)), opt
