@@ -241,8 +241,13 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
 
     def matched_bytes(name, layer):
         s, li = st[layer], linfo[layer]
+        if name.startswith("k1q_fused"):                          # several dense-format layers in one launch: "k1q_fused[_x]_<first>_<last>"
+            l0, l1 = (int(v) for v in name.split("_")[-2:])
+            return x_bytes_q + sum(4.0 * st[ll]["x_cols"] for ll in range(l0, l1 + 1)) + 16.0 * k * rows
         if name.startswith("k1q"):                                # dense row format, query-stationary
             return x_bytes_q + 4.0 * s["x_cols"] + 16.0 * k * rows
+        if name.startswith("k1g"):                                # dense X, tiled SGEMM: per item the query row + the parent's weight panel + scores
+            return 4.0 * s["probes"] + 4.0 * s["x_cols"] + 4.0 * s["item_cols"]
         if name.startswith("k1"):                                 # tile format: per item x row + lookups + extents + matched entries + scores
             probe = {0: 8.0, 1: 8.0 + 4.0 * li["bucket_levels"], 2: 16.0}[li["lookup"]]
             if not sparse:                                        # dense X walks every tile row: row id + x value instead of lookups
@@ -283,6 +288,19 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
                 l2 = dict(bound="l2", read_requests_per_launch=req, request_bytes=64, achieved=round(l2b, 1), peak=L2_PEAK_GBPS, unit="GB/s",
                           frac=round(l2b / L2_PEAK_GBPS, 4), requests_per_s_G=round(req / (avg_ms * 1e-3) / 1e9, 1),
                           note="TCP_TCC_READ_REQ (L1->L2 read requests) x 64 B / launch time; the gathers of this kernel use 8-16 B of every request")
+    if dom.startswith("k1g") and st:
+        # dense queries: the dominant kernel is a k-ordered fp32 SGEMM -> flops roofline.  2 flops per multiply-add over the
+        # (feature, padded column) cells the items address; peak = the dense fp32 matrix/vector rate (MI355X_MICROARCH.md: 157.3 TF).
+        # The reference's arithmetic is a separately rounded multiply and add (no FMA), so 78.6 TFLOP/s is the rate this
+        # instruction mix can reach at best (frac_of_reachable).
+        flops = sum(2.0 * st[r["layer"]]["x_cols"] * r["launches"] for r in prof if r["name"] == dom) / max(1, fam[dom]["launches"])
+        tf = flops / (avg_ms * 1e-3) / 1e12
+        return dict(bound="mfma", kernel=dom, achieved=round(tf, 2), peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4), frac_of_reachable=round(tf / 78.6, 4),
+                    traffic=traffic, flops_per_launch=flops, avg_launch_ms=round(avg_ms, 4), launches_per_step=launches_per_step,
+                    model="2 flops per multiply-add of every (query feature, candidate column) cell; fp32 multiply and add rounded separately (the reference carries no FMA), "
+                          "so MFMA (fused) cannot be used and half the fp32 peak is the reachable rate",
+                    per_kernel_ms_per_step={n: round(v["ms"] / max(1, args.steps), 4) for n, v in fam.items()}, kernels=kernels,
+                    work=[dict(layer=l, **{kk: st[l][kk] for kk in ("items", "probes", "hit_rows", "hit_entries", "candidates")}) for l in range(len(st))])
     return dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
                 traffic=traffic, traffic_source=tsrc, l2=l2,
                 alg_bytes_per_launch=per_launch, avg_launch_ms=round(avg_ms, 4), launches_per_step=launches_per_step,

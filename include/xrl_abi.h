@@ -253,6 +253,8 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *                         pinned memory and uploaded on a copy stream while batch b computes; 0: one synchronous upload
  *   "dense_layers"        1 (default): layers that carry the dense row format run the fused query-stationary kernel K1Q
  *                         whenever the beam's candidates fit its registers; 0: tile-format kernels K0 -> K1 -> K2 everywhere
+ *   "k1q_fuse"            1 (default): consecutive dense-format layers run in ONE K1Q launch, the wavefront that owns a query carries
+ *                         its beam through them in LDS; 0: one launch per layer
  *   "k1g_min_items"       dense X: a dense-format layer runs the tiled, k-ordered SGEMM K1G (tile-sorted items, weight and query
  *                         panels staged in LDS) once a parent serves this many queries on average (default 16; 0 = never: K1Q)
  *   "k2_legacy"           1: round-1 insertion top-k kernels instead of the ballot-bisection K2 (A/B, tests)

@@ -861,6 +861,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
         else if (!std::strcmp(key, "sort_min_tiles")) m.sort_min_tiles = (int)value;
         else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;   // 0: the host ABI uploads X in one piece before computing
+        else if (!std::strcmp(key, "k1q_fuse")) m.k1q_fuse = (int)value;           // 0: one K1Q launch per dense-format layer
         else if (!std::strcmp(key, "k1g_min_items")) m.k1g_min_items = (int)value;   // dense X: queries per parent from which a dense-format layer runs the tiled SGEMM K1G (0 = never)
         else if (!std::strcmp(key, "dense_layers")) m.dense_layers = (int)value;   // 0: never run the fused dense-format kernel K1Q
         else if (!std::strcmp(key, "k2_legacy")) m.k2_legacy = (int)value;        // debug / A-B: round-1 insertion top-k

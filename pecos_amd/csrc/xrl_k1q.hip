@@ -32,33 +32,38 @@ namespace xrl {
 
 #define XRL_LAUNCH_CHECK() XRL_HIP(hipGetLastError())
 
+// what K1Q needs of one layer (a compact copy of LayerDev's dense-format fields + the layer's plan)
+struct K1QLayer {
+    const uint32_t* wd; uint64_t d_ld;
+    const uint32_t* d_ptile; const uint32_t* d_tcol; const float* bias_prod; const uint32_t* perm_inv;
+    uint32_t d_gp_log2, d_max_tiles, n_parents, w_rows;
+    uint32_t beam_in, k, ns;          // ns: candidate registers per lane this layer needs
+    int has_bias, pp_kind, pp_p, first_layer, implicit_root;
+};
+constexpr int kK1QMaxLayers = 8;
+
 struct K1QArgs {
-    LayerDev L;
+    K1QLayer layer[kK1QMaxLayers];
+    int n_layers;                     // consecutive dense-format layers run back to back by the same wavefront: the beam stays in LDS
     QueriesDev X;
     const uint32_t* p_idx; const float* p_val; const uint32_t* p_cnt; uint32_t p_stride;
     uint32_t* out_idx; float* out_val; uint32_t* out_cnt; uint32_t out_stride;
-    uint32_t row0, nrows, beam_in, k;
-    int pp_kind, pp_p, first_layer, implicit_root;
+    uint32_t row0, nrows;
 };
 
 template <int NS> struct K1QCfg {
     // weight rows (features) whose loads are in flight together: U * NS loads per lane
-    static constexpr int U = NS <= 2 ? 16 : NS <= 4 ? 8 : NS <= 8 ? 4 : 2;
+    static constexpr int U = NS <= 1 ? 16 : NS <= 3 ? 8 : NS <= 6 ? 4 : 2;
 };
 
+// One layer for one query (one wavefront): beam in s_bidx / s_bval[0..cnt) -> beam out in the same arrays; returns the new count.
 template <int NS, int PPC, bool DENSEX>
-__global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
+__device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesDev& X, uint64_t xrow, uint32_t cnt_in,
+                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane) {
     constexpr int U = K1QCfg<NS>::U;
-    __shared__ uint2 sc_all[4 * 64];
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar control flow below
-    const uint32_t q = blockIdx.x * 4u + wave;
-    if (q >= a.nrows) return;
-    uint2* sc = sc_all + wave * 64u;
-
     // ---- prolongate: which (parent, dense tile, column) does each of this lane's candidates stand for
-    const uint32_t gl = a.L.d_gp_log2, gmask = (1u << gl) - 1u, TT = a.L.d_max_tiles;
-    const uint32_t cnt = a.implicit_root ? 1u : min(a.p_cnt[q], a.beam_in);
+    const uint32_t gl = Ly.d_gp_log2, gmask = (1u << gl) - 1u, TT = Ly.d_max_tiles;
+    const uint32_t cnt = Ly.implicit_root ? 1u : min(cnt_in, Ly.beam_in);
     uint32_t woff[NS], child[NS]; float ps[NS], acc[NS]; bool valid[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
@@ -68,27 +73,25 @@ __global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
         const uint32_t tt = TT == 1u ? 0u : slot - j * TT;
         bool v = j < cnt;
         uint32_t parent = 0; float pscore = 1.0f;
-        if (!a.implicit_root) {
-            const size_t at = (size_t)q * a.p_stride + (v ? j : 0u);
-            parent = a.p_idx[at]; pscore = a.p_val[at];
-        }
-        v = v && parent < a.L.n_parents;
+        if (!Ly.implicit_root) { parent = s_bidx[v ? j : 0u]; pscore = s_bval[v ? j : 0u]; }
+        v = v && parent < Ly.n_parents;
         if (!v) parent = 0;
-        const uint32_t dt = a.L.d_ptile[parent] + tt;
-        v = v && dt < a.L.d_ptile[parent + 1];
+        const uint32_t dt = Ly.d_ptile[parent] + tt;
+        v = v && dt < Ly.d_ptile[parent + 1];
         const uint32_t dtc = v ? dt : 0u;
-        const uint32_t cb = a.L.d_tcol[dtc], ce = a.L.d_tcol[dtc + 1];
+        const uint32_t cb = Ly.d_tcol[dtc], ce = Ly.d_tcol[dtc + 1];
         v = v && col < ce - cb;
         woff[r] = v ? ((dtc << gl) + col) * 4u : 0u;                   // BYTE offset inside a feature row (d_ld < 2^30)
         child[r] = v ? cb + col : 0u;
         ps[r] = pscore; valid[r] = v;
         // dense queries: bias FIRST (inference.hpp:824-830); bias_prod holds fl32(bias * w) or +0.0
-        acc[r] = (DENSEX && a.L.has_bias) ? a.L.bias_prod[child[r]] : 0.0f;
+        acc[r] = (DENSEX && Ly.has_bias) ? Ly.bias_prod[child[r]] : 0.0f;
     }
+    wave_sync_lds();                                                   // the beam has been read: the arrays may be overwritten below
 
-    const uint32_t* __restrict__ wd = a.L.wd;
-    const uint64_t ld = a.L.d_ld;
-    const uint32_t w_rows = a.L.w_rows;
+    const uint32_t* __restrict__ wd = Ly.wd;
+    const uint64_t ld = Ly.d_ld;
+    const uint32_t w_rows = Ly.w_rows;
 
     // U features per batch: their U*NS weight loads are issued together (addresses depend only on the
     // feature ids: scalar row base + this lane's column offset), then applied in feature order
@@ -116,21 +119,21 @@ __global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
 
     if (DENSEX) {
         // chunk_ops<drm, bin_search> (inference.hpp:815-839): every chunk row except the bias row, x gathered by row id
-        const float* __restrict__ xd = a.X.val + ((uint64_t)a.row0 + q) * a.X.cols;
-        const uint32_t n_feat = a.L.has_bias ? w_rows - 1u : w_rows;
+        const float* __restrict__ xd = X.val + xrow * X.cols;
+        const uint32_t n_feat = Ly.has_bias ? w_rows - 1u : w_rows;
         for (uint32_t t0 = 0; t0 < n_feat; t0 += 64u) {
             const uint32_t f = t0 + (uint32_t)lane;
-            const float xv = f < a.X.cols ? xd[f] : 0.0f;
+            const float xv = f < X.cols ? xd[f] : 0.0f;
             const uint32_t fv = f < n_feat ? f : 0xFFFFFFFFu;
             const uint32_t n = min(64u, n_feat - t0);
             for (uint32_t t = 0; t < n; t += (uint32_t)U) batch(fv, __float_as_uint(xv), t, n_feat);
         }
     } else {
         // chunk_ops<csr, bin_search> (inference.hpp:769-813): the query's features in ascending order
-        const uint64_t xb = a.X.row_ptr[(uint64_t)a.row0 + q];
-        const uint32_t xl = (uint32_t)(a.X.row_ptr[(uint64_t)a.row0 + q + 1] - xb);
-        const uint32_t* __restrict__ xi = a.X.col_idx + xb;
-        const float* __restrict__ xv = a.X.val + xb;
+        const uint64_t xb = X.row_ptr[xrow];
+        const uint32_t xl = (uint32_t)(X.row_ptr[xrow + 1] - xb);
+        const uint32_t* __restrict__ xi = X.col_idx + xb;
+        const float* __restrict__ xv = X.val + xb;
         uint32_t fv = 0xFFFFFFFFu, vb = 0u;
         if (xl) { const bool ok = (uint32_t)lane < xl; const uint32_t t = ok ? (uint32_t)lane : 0u; fv = ok ? xi[t] : 0xFFFFFFFFu; vb = __float_as_uint(xv[t]); }
         for (uint32_t t0 = 0; t0 < xl; t0 += 64u) {
@@ -151,21 +154,62 @@ __global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
         float s = acc[r];
-        if (!DENSEX && a.L.has_bias) s = __fadd_rn(s, a.L.bias_prod[child[r]]);
-        float v = pp_transform<PPC>(a.pp_kind, a.pp_p, s);
-        if (!a.first_layer) v = pp_combine(a.pp_kind, v, ps[r]);
+        if (!DENSEX && Ly.has_bias) s = __fadd_rn(s, Ly.bias_prod[child[r]]);
+        float v = pp_transform<PPC>(Ly.pp_kind, Ly.pp_p, s);
+        if (!Ly.first_layer) v = pp_combine(Ly.pp_kind, v, ps[r]);
         sbits[r] = __float_as_uint(v);
         key[r] = valid[r] ? score_key(v) : 0u;
     }
-    // ---- top-k (value desc, position asc) and reorder_prediction
+    // ---- top-k (value desc, position asc) and reorder_prediction: the next beam, best first
     uint32_t rank, sb, ch;
-    const uint32_t kk = wave_topk<NS>(key, sbits, child, a.k, sc, lane, rank, sb, ch);
+    const uint32_t kk = wave_topk<NS>(key, sbits, child, Ly.k, sc, lane, rank, sb, ch);
     if ((uint32_t)lane < kk) {
-        const size_t o = (size_t)q * a.out_stride + rank;
-        a.out_idx[o] = a.L.perm_inv ? a.L.perm_inv[ch] : ch;
-        a.out_val[o] = __uint_as_float(sb);
+        s_bidx[rank] = Ly.perm_inv ? Ly.perm_inv[ch] : ch;
+        s_bval[rank] = __uint_as_float(sb);
     }
-    if (lane == 0) a.out_cnt[q] = kk;
+    wave_sync_lds();
+    return kk;
+}
+
+template <int NSMAX, int PPC, bool DENSEX>
+__global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
+    __shared__ uint2 sc_all[4 * 64];
+    __shared__ uint32_t bidx_all[4 * 64];
+    __shared__ float bval_all[4 * 64];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar control flow below
+    const uint32_t q = blockIdx.x * 4u + wave;
+    if (q >= a.nrows) return;
+    uint2* sc = sc_all + wave * 64u;
+    uint32_t* s_bidx = bidx_all + wave * 64u; float* s_bval = bval_all + wave * 64u;
+
+    // incoming beam -> LDS (k <= 64 entries); the implicit root needs none
+    uint32_t cnt = 1;
+    if (!a.layer[0].implicit_root) {
+        cnt = min(a.p_cnt[q], a.layer[0].beam_in);
+        if ((uint32_t)lane < cnt) { s_bidx[lane] = a.p_idx[(size_t)q * a.p_stride + lane]; s_bval[lane] = a.p_val[(size_t)q * a.p_stride + lane]; }
+    }
+    wave_sync_lds();
+    const uint64_t xrow = (uint64_t)a.row0 + q;
+    for (int l = 0; l < a.n_layers; ++l) {
+        const K1QLayer& Ly = a.layer[l];
+        const uint32_t ns = Ly.ns;
+        // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
+        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+    }
+    if ((uint32_t)lane < cnt) {
+        const size_t o = (size_t)q * a.out_stride + (uint32_t)lane;
+        a.out_idx[o] = s_bidx[lane];
+        a.out_val[o] = s_bval[lane];
+    }
+    if (lane == 0) a.out_cnt[q] = cnt;
 }
 
 // registers per lane a layer needs with `beam_in` parents per query, or 0 when K1Q cannot serve it
@@ -176,30 +220,41 @@ uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k) {
     return ns <= 16 ? (uint32_t)std::max<uint64_t>(1, ns) : 0u;
 }
 
-void launch_k1q(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
+static uint32_t k1q_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 3 ? 3 : ns <= 4 ? 4 : ns <= 6 ? 6 : ns <= 8 ? 8 : ns <= 12 ? 12 : 16; }
+static uint32_t k1q_kernel_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 3 ? 3 : ns <= 6 ? 6 : 16; }   // kernels are compiled for these maxima
+
+// n consecutive dense-format layers (n <= kK1QMaxLayers) in ONE launch: previous beam in, the last layer's beam out
+void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
                 uint32_t* out_cnt, uint32_t out_stride, hipStream_t s) {
-    if (P.nrows == 0) return;
-    const uint32_t ns = k1q_regs(L, P.beam_in, P.k);
-    if (ns == 0) fail("k1q: layer not eligible");
+    if (n <= 0 || n > kK1QMaxLayers) fail("k1q: bad layer count");
+    if (Ps[0].nrows == 0) return;
     K1QArgs a;
-    a.L = L; a.X = X;
+    uint32_t nsmax = 1; int ppc = 0;
+    for (int l = 0; l < n; ++l) {
+        const LayerDev& L = *Ls[l]; const LayerPlan& P = Ps[l];
+        const uint32_t ns = k1q_regs(L, P.beam_in, P.k);
+        if (ns == 0) fail("k1q: layer not eligible");
+        K1QLayer& y = a.layer[l];
+        y.wd = L.wd; y.d_ld = L.d_ld; y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
+        y.d_gp_log2 = L.d_gp_log2; y.d_max_tiles = L.d_max_tiles; y.n_parents = L.n_parents; y.w_rows = L.w_rows;
+        y.beam_in = P.beam_in; y.k = P.k; y.ns = k1q_bucket(ns);
+        y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root;
+        nsmax = std::max(nsmax, y.ns); ppc |= pp_class(P.pp);
+    }
+    a.n_layers = n; a.X = X;
     a.p_idx = prev.idx; a.p_val = prev.val; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
     a.out_idx = out_idx; a.out_val = out_val; a.out_cnt = out_cnt; a.out_stride = out_stride;
-    a.row0 = P.row0; a.nrows = P.nrows; a.beam_in = P.beam_in; a.k = P.k;
-    a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer; a.implicit_root = P.implicit_root;
-    const dim3 grid((P.nrows + 3u) / 4u), block(256);
-    const int ppc = pp_class(P.pp);
+    a.row0 = Ps[0].row0; a.nrows = Ps[0].nrows;
+    const dim3 grid((a.nrows + 3u) / 4u), block(256);
 #define XRL_K1Q(NN) do { \
         if (X.dense) { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, true>), grid, block, 0, s, a); } \
         else { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, false>), grid, block, 0, s, a); } } while (0)
-    if (ns <= 1) XRL_K1Q(1);
-    else if (ns <= 2) XRL_K1Q(2);
-    else if (ns <= 3) XRL_K1Q(3);
-    else if (ns <= 4) XRL_K1Q(4);
-    else if (ns <= 6) XRL_K1Q(6);
-    else if (ns <= 8) XRL_K1Q(8);
-    else if (ns <= 12) XRL_K1Q(12);
-    else XRL_K1Q(16);
+    switch (k1q_kernel_bucket(nsmax)) {
+    case 1: XRL_K1Q(1); break;
+    case 3: XRL_K1Q(3); break;
+    case 6: XRL_K1Q(6); break;
+    default: XRL_K1Q(16); break;
+    }
 #undef XRL_K1Q
     XRL_LAUNCH_CHECK();
 }

@@ -1067,6 +1067,12 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     const uint32_t n = min(a.ncand[q], (uint32_t)(64 * NS));
     const float* __restrict__ cv = a.cand + q * a.cand_stride;
     const uint32_t nlast = n ? n - 1 : 0;
+    // the beam's block offsets and parents, one per lane (beams of up to 64 parents): in flight while the candidates are ranked,
+    // so that mapping a winner's position back to its child needs no dependent loads afterwards
+    const uint32_t bcnt = a.implicit_root ? 1u : min(a.p_cnt[q], a.beam_in);
+    const bool lane_beam = !a.implicit_root && bcnt <= 64u;
+    uint32_t b_off = 0xFFFFFFFFu, b_par = 0u;
+    if (lane_beam && (uint32_t)lane < bcnt) { b_off = a.cand_off[q * a.beam_in + lane]; b_par = a.p_idx[q * a.p_stride + lane]; }
     uint32_t key[NS], sbits[NS], pos[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
@@ -1077,8 +1083,18 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     }
     uint32_t rank, sb, pp;
     const uint32_t kk = wave_topk<NS>(key, sbits, pos, a.k, sc_all + wave * 64u, lane, rank, sb, pp);
+    uint32_t child;
+    if (lane_beam) {
+        uint32_t jj = 0;                                            // last beam slot whose block starts at or before the position
+        for (uint32_t j = 1; j < bcnt; ++j) jj = ((uint32_t)__builtin_amdgcn_readlane((int)b_off, (int)j) <= pp) ? j : jj;
+        const uint32_t off = (uint32_t)__shfl((int)b_off, (int)jj, 64), parent = (uint32_t)__shfl((int)b_par, (int)jj, 64);
+        child = a.chunk_col[(uint32_t)lane < kk ? parent : 0u] + (pp - off);
+        if ((uint32_t)lane < kk && a.perm_inv) child = a.perm_inv[child];
+    } else {
+        child = (uint32_t)lane < kk ? k2_child_id(a, q, pp) : 0u;
+    }
     if ((uint32_t)lane < kk) {
-        a.out_idx[q * a.out_stride + rank] = k2_child_id(a, q, pp);
+        a.out_idx[q * a.out_stride + rank] = child;
         a.out_val[q * a.out_stride + rank] = __uint_as_float(sb);
     }
     if (lane == 0) a.out_cnt[q] = kk;

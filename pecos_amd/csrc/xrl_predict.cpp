@@ -190,8 +190,26 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
                 continue;
             }
-            if (m.dense_layers && !o.stats_out && k1q_regs(L.dev, beam_in[l], k[l]) != 0) {
-                timed(X.dense ? "k1q_dense_x" : "k1q_dense", (uint32_t)l, [&] { launch_k1q(L.dev, P, X, prev, oi, ov, oc, os, S); });
+            auto runs_k1q = [&](size_t ll) { return m.dense_layers && !o.stats_out && !csc && layer_mode(ll, nrows) != 3 && k1q_regs(m.layers[ll]->dev, beam_in[ll], k[ll]) != 0; };
+            if (runs_k1q(l)) {
+                // consecutive dense-format layers run in ONE launch: the wavefront that owns a query carries its beam through them in LDS
+                size_t l1 = l;
+                while (m.k1q_fuse && l1 + 1 < T && l1 + 1 - l < 8 && runs_k1q(l1 + 1)) ++l1;
+                const LayerDev* Ls[8]; LayerPlan Ps[8];
+                for (size_t ll = l; ll <= l1; ++ll) {
+                    Ls[ll - l] = &m.layers[ll]->dev;
+                    LayerPlan Q = P;
+                    Q.layer = (int)ll; Q.beam_in = beam_in[ll]; Q.k = k[ll]; Q.cand_stride = cstride[ll]; Q.pp = pp[ll];
+                    Q.first_layer = (ll == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;
+                    Q.implicit_root = (ll == 0 && !has_init) ? 1 : 0;
+                    Ps[ll - l] = Q;
+                }
+                uint32_t *qi, *qc; float* qv; uint32_t qs;
+                if (l1 == T - 1) { qi = d_out_idx + row0 * out_stride; qv = d_out_val + row0 * out_stride; qc = d_out_cnt + row0; qs = out_stride; }
+                else { const int b = (int)(l1 & 1); qi = lw.beam_idx[b].as<uint32_t>(); qv = lw.beam_val[b].as<float>(); qc = lw.beam_cnt[b].as<uint32_t>(); qs = beam_stride; }
+                const std::string nm = (l1 > l) ? std::string(X.dense ? "k1q_fused_x_" : "k1q_fused_") + std::to_string(l) + "_" + std::to_string(l1) : std::string(X.dense ? "k1q_dense_x" : "k1q_dense");
+                timed(nm.c_str(), (uint32_t)l, [&] { launch_k1q(Ls, Ps, (int)(l1 - l + 1), X, prev, qi, qv, qc, qs, S); });
+                l = l1;
                 continue;
             }
             int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
