@@ -96,13 +96,14 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     // U features per batch: their U*NS weight loads are issued together (addresses depend only on the
     // feature ids: scalar row base + this lane's column offset), then applied in feature order
     auto batch = [&](uint32_t fv, uint32_t vbits, uint32_t t, uint32_t f_end) {
-        uint32_t wb[U][NS]; float xs[U]; bool sk[U];
+        uint32_t wb[U][NS]; float xs[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)(t + (uint32_t)u));
             xs[u] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)vbits, (int)(t + (uint32_t)u)));
-            sk[u] = f >= f_end;                                        // padding lanes carry f = 0xFFFFFFFF
-            const char* __restrict__ row = reinterpret_cast<const char*>(wd + (uint64_t)(sk[u] ? 0u : f) * ld);
+            // features outside the layer (and the padding lanes, f = 0xFFFFFFFF) read the all-kMissing row the model compiler
+            // appends after the last feature row: no separate "skip" state to carry
+            const char* __restrict__ row = reinterpret_cast<const char*>(wd + (uint64_t)min(f, f_end) * ld);
 #pragma unroll
             for (int r = 0; r < NS; ++r) wb[u][r] = *reinterpret_cast<const uint32_t*>(row + woff[r]);   // scalar base + 32-bit lane offset
         }
@@ -112,7 +113,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
             for (int r = 0; r < NS; ++r) {
                 // scalar * val, then add: no fma (inference.hpp:512-517); no entry -> no operation
                 const float s = __fadd_rn(acc[r], __fmul_rn(xs[u], __uint_as_float(wb[u][r])));
-                acc[r] = (sk[u] || wb[u][r] == kMissing) ? acc[r] : s;
+                acc[r] = (wb[u][r] == kMissing) ? acc[r] : s;
             }
         }
     };
@@ -126,7 +127,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
             const float xv = f < X.cols ? xd[f] : 0.0f;
             const uint32_t fv = f < n_feat ? f : 0xFFFFFFFFu;
             const uint32_t n = min(64u, n_feat - t0);
-            for (uint32_t t = 0; t < n; t += (uint32_t)U) batch(fv, __float_as_uint(xv), t, n_feat);
+            for (uint32_t t = 0; t < n; t += (uint32_t)U) batch(fv, __float_as_uint(xv), t, w_rows);   // fv >= n_feat only on padding lanes (0xFFFFFFFF)
         }
     } else {
         // chunk_ops<csr, bin_search> (inference.hpp:769-813): the query's features in ascending order
@@ -171,7 +172,9 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     return kk;
 }
 
-template <int NSMAX, int PPC, bool DENSEX>
+// MULTI = false: exactly one layer (layer[0]); the layer loop and its run-time descriptor indexing cost ~20 VGPRs, which the
+// single-layer launches (wide layers, k1q_fuse = 0) do not pay.
+template <int NSMAX, int PPC, bool DENSEX, bool MULTI>
 __global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
     __shared__ uint2 sc_all[4 * 64];
     __shared__ uint32_t bidx_all[4 * 64];
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
     }
     wave_sync_lds();
     const uint64_t xrow = (uint64_t)a.row0 + q;
-    for (int l = 0; l < a.n_layers; ++l) {
+    for (int l = 0; l < (MULTI ? a.n_layers : 1); ++l) {
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
 
 // registers per lane a layer needs with `beam_in` parents per query, or 0 when K1Q cannot serve it
 uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k) {
-    if (!L.wd || k == 0 || k > 64) return 0;
+    if (!L.wd || k == 0 || k > 64 || beam_in > 64) return 0;      // the beam lives in 64-entry LDS arrays on its way through the layers
     const uint64_t cands = ((uint64_t)beam_in * L.d_max_tiles) << L.d_gp_log2;
     const uint64_t ns = (cands + 63) / 64;
     return ns <= 16 ? (uint32_t)std::max<uint64_t>(1, ns) : 0u;
@@ -227,6 +230,7 @@ static uint32_t k1q_kernel_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 3 ? 
 void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
                 uint32_t* out_cnt, uint32_t out_stride, hipStream_t s) {
     if (n <= 0 || n > kK1QMaxLayers) fail("k1q: bad layer count");
+    if (n > 1) for (int l = 0; l < n; ++l) if (k1q_regs(*Ls[l], Ps[l].beam_in, Ps[l].k) > 3) fail("k1q: only layers of <= 3 candidate registers can share a launch");
     if (Ps[0].nrows == 0) return;
     K1QArgs a;
     uint32_t nsmax = 1; int ppc = 0;
@@ -246,16 +250,18 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     a.out_idx = out_idx; a.out_val = out_val; a.out_cnt = out_cnt; a.out_stride = out_stride;
     a.row0 = Ps[0].row0; a.nrows = Ps[0].nrows;
     const dim3 grid((a.nrows + 3u) / 4u), block(256);
-#define XRL_K1Q(NN) do { \
-        if (X.dense) { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, true>), grid, block, 0, s, a); } \
-        else { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, false>), grid, block, 0, s, a); } } while (0)
+#define XRL_K1Q_M(NN, MM) do { \
+        if (X.dense) { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, true, MM>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, true, MM>), grid, block, 0, s, a); } \
+        else { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, false, MM>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, false, MM>), grid, block, 0, s, a); } } while (0)
+#define XRL_K1Q(NN) do { if (n > 1) XRL_K1Q_M(NN, true); else XRL_K1Q_M(NN, false); } while (0)
     switch (k1q_kernel_bucket(nsmax)) {
     case 1: XRL_K1Q(1); break;
     case 3: XRL_K1Q(3); break;
-    case 6: XRL_K1Q(6); break;
-    default: XRL_K1Q(16); break;
+    case 6: XRL_K1Q_M(6, false); break;      // only narrow layers (<= 3 registers) are fused (xrl_predict.cpp)
+    default: XRL_K1Q_M(16, false); break;
     }
 #undef XRL_K1Q
+#undef XRL_K1Q_M
     XRL_LAUNCH_CHECK();
 }
 
@@ -277,7 +283,8 @@ densify_kernel(const uint64_t* __restrict__ col_ptr, const uint32_t* __restrict_
 
 void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,
                     const uint32_t* dst_off, uint32_t n_children, uint32_t w_rows, uint64_t ld, uint32_t* wd, hipStream_t s) {
-    XRL_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wd), (int)kMissing, (size_t)w_rows * ld, s));
+    // w_rows + 1 rows: the extra last row stays all-kMissing (K1Q sends out-of-range features there)
+    XRL_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wd), (int)kMissing, ((size_t)w_rows + 1) * ld, s));
     if (n_children) {
         hipLaunchKernelGGL(densify_kernel, dim3((n_children + 3u) / 4u), dim3(256), 0, s, col_ptr, row_idx, val, src_col, dst_off,
                            n_children, ld, wd);

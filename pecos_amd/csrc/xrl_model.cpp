@@ -492,7 +492,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
             d_tcol.push_back((uint32_t)c_nnz);                     // one readable element past the end
             while ((1u << d_gp_log2) < gp) ++d_gp_log2;
             d_ld = (n_dt * gp + 31) & ~31ull;
-            const uint64_t bytes = (uint64_t)W.rows * d_ld * 4;
+            const uint64_t bytes = ((uint64_t)W.rows + 1) * d_ld * 4;        // + one all-kMissing row (features outside the layer)
             uint64_t cap_b = 64ull << 30;
             if (const char* mb = std::getenv("XRL_DENSE_MAX_MB")) cap_b = std::strtoull(mb, nullptr, 10) << 20;
             size_t free_b = 0, total_b = 0;
@@ -505,7 +505,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
                 for (uint32_t c = d_tcol[dt]; c < d_tcol[dt + 1]; ++c) { src_col[c] = orig_col(c); dst_off[c] = (uint32_t)(dt << d_gp_log2) + (c - d_tcol[dt]); }
             DevBuf t_ptr, t_idx, t_val, t_src, t_dst;
             t_ptr.upload(W.col_ptr); t_idx.upload(W.row_idx); t_val.upload(W.val); t_src.upload(src_col); t_dst.upload(dst_off);
-            L->d_wd.reserve((size_t)W.rows * d_ld * 4);
+            L->d_wd.reserve(((size_t)W.rows + 1) * d_ld * 4);
             launch_densify(t_ptr.as<uint64_t>(), t_idx.as<uint32_t>(), t_val.as<float>(), t_src.as<uint32_t>(), t_dst.as<uint32_t>(),
                            (uint32_t)c_nnz, W.rows, d_ld, L->d_wd.as<uint32_t>(), nullptr);
             XRL_HIP(hipStreamSynchronize(nullptr));

@@ -76,7 +76,8 @@ struct LayerDev {
     float bias;
     int has_bias;
     // DENSE row format (K1Q, xrl_k1q.hip), nullptr when the layer is held in the tile format only:
-    //   wd[feature * d_ld + (dense tile << d_gp_log2) + column] = weight bits, kMissing where W has no entry.
+    //   wd[feature * d_ld + (dense tile << d_gp_log2) + column] = weight bits, kMissing where W has no entry; w_rows + 1 rows,
+    //   the last one all kMissing (where K1Q sends features the layer does not know).
     // Dense tiles partition every parent's children into runs of <= 2^d_gp_log2 columns (their own tiling: <= 64 wide).
     const uint32_t* wd;
     uint64_t d_ld;               // padded columns per feature row (a multiple of 32: rows start on 128-byte lines)

@@ -194,7 +194,9 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             if (runs_k1q(l)) {
                 // consecutive dense-format layers run in ONE launch: the wavefront that owns a query carries its beam through them in LDS
                 size_t l1 = l;
-                while (m.k1q_fuse && l1 + 1 < T && l1 + 1 - l < 8 && runs_k1q(l1 + 1)) ++l1;
+                // (only narrow layers share a launch: a fused kernel is compiled for -- and holds the registers of -- its widest layer)
+                auto narrow = [&](size_t ll) { return k1q_regs(m.layers[ll]->dev, beam_in[ll], k[ll]) <= 3; };
+                while (m.k1q_fuse && narrow(l) && l1 + 1 < T && l1 + 1 - l < 8 && runs_k1q(l1 + 1) && narrow(l1 + 1)) ++l1;
                 const LayerDev* Ls[8]; LayerPlan Ps[8];
                 for (size_t ll = l; ll <= l1; ++ll) {
                     Ls[ll - l] = &m.layers[ll]->dev;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 2, GPU run 5: fused multi-layer K1Q -- parity + A/B
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r02e; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r02f; mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 > $O/pytest_gpu.log; cat $O/pytest_gpu.log
 for v in "" "--opt k1q_fuse=0"; do
