@@ -59,7 +59,7 @@ class PackedTopk:
         self.k, self.world, self.max_rows = int(k), int(world), int(max_rows)
         self.buf = torch.zeros((self.max_rows, 2 * self.k + 1), dtype=torch.int32, device=device)
         self.cnt = torch.zeros((self.max_rows,), dtype=torch.int32, device=device)
-        self.gathered = torch.empty((self.world, self.max_rows, 2 * self.k + 1), dtype=torch.int32, device=device) if self.world > 1 else None
+        self.gathered = torch.empty((self.world, self.max_rows, 2 * self.k + 1), dtype=torch.int32, device=device)
 
     def pointers(self):
         """(idx_ptr, val_ptr, cnt_ptr, row_stride) for ``clib.predict_device``."""
@@ -77,9 +77,9 @@ class PackedTopk:
         import torch
         import torch.distributed as dist
         self.buf[:, 2 * self.k] = self.cnt
-        if self.world == 1:
+        if not dist.is_initialized():          # single process without a process group: nothing to exchange
             return self.buf.unsqueeze(0)
-        try:
+        try:                                   # (a one-rank group still runs the collective: tests exercise RCCL that way)
             dist.all_gather_into_tensor(self.gathered, self.buf, group=group)
         except (RuntimeError, NotImplementedError):  # backends without the fused form
             parts = [torch.empty_like(self.buf) for _ in range(self.world)]
