@@ -205,6 +205,13 @@ int xrl_predict_device(void* model, void* queries, uint32_t beam_size, const cha
                        uint32_t only_topk, uint32_t* d_out_idx, float* d_out_val,
                        uint32_t* d_out_cnt, uint32_t out_stride, void* hip_stream, int sync);
 
+/* The same for rows [row_begin, row_begin + row_count) of the queries only; results land at the SAME rows of the output buffers.
+ * Lets a caller pipeline a shard in pieces (bench.py: the all-gather of the first half runs under the second half's kernels). */
+int xrl_predict_device_rows(void* model, void* queries, uint32_t beam_size, const char* post_processor,
+                            uint32_t only_topk, uint32_t* d_out_idx, float* d_out_val,
+                            uint32_t* d_out_cnt, uint32_t out_stride, void* hip_stream, int sync,
+                            uint32_t row_begin, uint32_t row_count);
+
 /* Effective only_topk of the last layer for the given override (0 = model default). */
 uint32_t xrl_effective_topk(void* model, uint32_t only_topk);
 

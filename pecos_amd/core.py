@@ -199,6 +199,7 @@ class corelib(object):
             "xrl_queries_concat_device": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_void_p]),
             "xrl_queries_free": (None, [c_void_p]),
             "xrl_predict_device": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int]),
+            "xrl_predict_device_rows": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int, c_uint32, c_uint32]),
             "xrl_predict_stats": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, POINTER(c_double), c_uint32]),
             "xrl_effective_topk": (c_uint32, [c_void_p, c_uint32]),
             "xrl_profile_enable": (None, [c_void_p, c_int]),
@@ -445,6 +446,17 @@ class corelib(object):
             c_void_p(c_model), c_void_p(queries), beam_size or 0,
             post_processor.encode("utf-8") if post_processor else None, only_topk or 0,
             c_void_p(d_idx), c_void_p(d_val), c_void_p(d_cnt), out_stride, c_void_p(stream or 0), 1 if sync else 0)
+        self._check()
+        return rc
+
+    def predict_device_rows(self, c_model, queries, beam_size, post_processor, only_topk, d_idx, d_val, d_cnt, out_stride,
+                            row_begin, row_count, stream=None, sync=True):
+        """predict_device for rows [row_begin, row_begin + row_count) only; results land at the same rows of the output buffers."""
+        rc = self.clib_float32.xrl_predict_device_rows(
+            c_void_p(c_model), c_void_p(queries), beam_size or 0,
+            post_processor.encode("utf-8") if post_processor else None, only_topk or 0,
+            c_void_p(d_idx), c_void_p(d_val), c_void_p(d_cnt), out_stride, c_void_p(stream or 0), 1 if sync else 0,
+            int(row_begin), int(row_count))
         self._check()
         return rc
 

@@ -793,6 +793,24 @@ int xrl_predict_device(void* model, void* queries, uint32_t beam_size, const cha
     return rc;
 }
 
+int xrl_predict_device_rows(void* model, void* queries, uint32_t beam_size, const char* post_processor, uint32_t only_topk,
+                            uint32_t* d_out_idx, float* d_out_val, uint32_t* d_out_cnt, uint32_t out_stride,
+                            void* hip_stream, int sync, uint32_t row_begin, uint32_t row_count) {
+    int rc = -1;
+    guarded([&] {
+        Model& m = *as_model(model);
+        if (!queries || !d_out_idx || !d_out_val || !d_out_cnt) fail("xrl_predict_device_rows: null argument");
+        std::lock_guard<std::mutex> g(m.mu);
+        use_device(m.device);
+        PredictOpts o; o.beam_size = beam_size; o.only_topk = only_topk; o.post_processor = post_processor;
+        o.reserve_rows = static_cast<Queries*>(queries)->dev.rows;     // scratch sized once for any row range of these queries
+        predict_device(m, static_cast<Queries*>(queries)->dev, o, d_out_idx, d_out_val, d_out_cnt, out_stride,
+                       static_cast<hipStream_t>(hip_stream), sync != 0, row_begin, row_count);
+        rc = 0;
+    });
+    return rc;
+}
+
 int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char* post_processor, uint32_t only_topk,
                       double* stats_out, uint32_t stats_cap) {
     int rc = -1;

@@ -132,6 +132,7 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     const float* __restrict__ xg = a.X.val;
     const uint32_t xcols = a.X.cols;
     const uint32_t padw = MISS ? kMissing : 0u;
+    const bool x16 = (xcols & 3u) == 0u && (reinterpret_cast<uintptr_t>(xg) & 15u) == 0u;
 
     for (uint32_t k0 = 0; k0 < n_feat; k0 += (uint32_t)KC) {
         __syncthreads();                                        // the previous step's readers are done (and sRow is visible)
@@ -146,12 +147,22 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
             }
             *reinterpret_cast<uint4*>(sW + (size_t)e * 4) = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        // ---- query panel: X[row, k0..k0+63] of the workgroup's queries (coalesced along the features)
-        for (uint32_t e = tid; e < (uint32_t)(QB * KC); e += 256u) {
-            const uint32_t qq = e / (uint32_t)KC, k = e % (uint32_t)KC, f = k0 + k;
-            float v = 0.0f;
-            if (qq < nq && f < n_feat && f < xcols) v = xg[((uint64_t)a.row0 + sRow[qq]) * xcols + f];
-            sX[qq * LDK + k] = v;
+        // ---- query panel: X[row, k0..k0+63] of the workgroup's queries (coalesced along the features; 16 bytes per lane when
+        //      the rows are 16-byte aligned and the step lies inside the layer's features)
+        if (x16 && k0 + (uint32_t)KC <= min(n_feat, xcols)) {
+            for (uint32_t e = tid; e < (uint32_t)(QB * KC / 4); e += 256u) {
+                const uint32_t qq = e / (uint32_t)(KC / 4), k4 = e % (uint32_t)(KC / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (qq < nq) v = *reinterpret_cast<const float4*>(xg + ((uint64_t)a.row0 + sRow[qq]) * xcols + k0 + k4 * 4u);
+                *reinterpret_cast<float4*>(sX + qq * LDK + k4 * 4u) = v;
+            }
+        } else {
+            for (uint32_t e = tid; e < (uint32_t)(QB * KC); e += 256u) {
+                const uint32_t qq = e / (uint32_t)KC, k = e % (uint32_t)KC, f = k0 + k;
+                float v = 0.0f;
+                if (qq < nq && f < n_feat && f < xcols) v = xg[((uint64_t)a.row0 + sRow[qq]) * xcols + f];
+                sX[qq * LDK + k] = v;
+            }
         }
         __syncthreads();
         // ---- RQ x RC register tile, 4 features per step; every accumulator takes its features in ascending order

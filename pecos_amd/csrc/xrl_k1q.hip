@@ -53,7 +53,7 @@ struct K1QArgs {
 
 template <int NS> struct K1QCfg {
     // weight rows (features) whose loads are in flight together: U * NS loads per lane
-    static constexpr int U = NS <= 1 ? 16 : NS <= 3 ? 8 : NS <= 6 ? 4 : 2;
+    static constexpr int U = NS <= 1 ? 16 : NS <= 3 ? 8 : NS <= 12 ? 4 : 2;
 };
 
 // One layer for one query (one wavefront): beam in s_bidx / s_bval[0..cnt) -> beam out in the same arrays; returns the new count.

@@ -47,51 +47,72 @@ def rows_to_csr(idx, val, cnt, n_cols):
 
 
 class PackedTopk:
-    """Fixed-stride result rows ``[idx(k) | val(k) | cnt]`` of one rank's shard held as ONE int32 tensor, so that a
-    single ``all_gather_into_tensor`` moves labels, scores and row lengths together (shards are padded to the largest).
+    """Fixed-stride result rows ``[idx(k) | val(k) | cnt]`` of one rank's shard held as int32 tensors, so that ONE
+    ``all_gather_into_tensor`` per PART moves labels, scores and row lengths together (shards are padded to the largest).
 
-    The compute writes labels / scores through :meth:`pointers` (row stride 2k+1) and row lengths into ``cnt``;
-    :meth:`gather` folds ``cnt`` into column 2k and runs the collective on the CURRENT stream of the backend's
+    ``parts`` = 1: the whole shard is one part.  ``parts`` = 2: every rank's rows are cut in two halves, each with its own send /
+    receive buffer, so that the gather of the first half can run (on another stream) under the kernels of the second half.
+    The compute writes labels / scores through :meth:`pointers` (row stride 2k+1, ABSOLUTE local row indexing) and row lengths
+    into ``cnt``; :meth:`gather` folds ``cnt`` into column 2k and runs the collective on the CURRENT stream of the backend's
     device, :meth:`unpack` cuts the padding away."""
 
-    def __init__(self, max_rows, k, world, device, dtype_check=True):
+    def __init__(self, bounds, rank, k, device, parts=1):
         import torch
-        self.k, self.world, self.max_rows = int(k), int(world), int(max_rows)
-        self.buf = torch.zeros((self.max_rows, 2 * self.k + 1), dtype=torch.int32, device=device)
-        self.cnt = torch.zeros((self.max_rows,), dtype=torch.int32, device=device)
-        self.gathered = torch.empty((self.world, self.max_rows, 2 * self.k + 1), dtype=torch.int32, device=device)
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        self.sizes = np.diff(self.bounds)
+        self.world, self.rank, self.k, self.parts = len(self.sizes), int(rank), int(k), int(parts)
+        # part p of rank r = its local rows [cut[r][p], cut[r][p+1])
+        self.cut = [[int(n * p // self.parts) for p in range(self.parts)] + [int(n)] for n in self.sizes]
+        self.max_part = [max(max(c[p + 1] - c[p] for c in self.cut), 1) for p in range(self.parts)]
+        self.buf = [torch.zeros((self.max_part[p], 2 * self.k + 1), dtype=torch.int32, device=device) for p in range(self.parts)]
+        self.gathered = [torch.empty((self.world, self.max_part[p], 2 * self.k + 1), dtype=torch.int32, device=device) for p in range(self.parts)]
+        self.cnt = torch.zeros((max(int(self.sizes.max()), 1),), dtype=torch.int32, device=device)
 
-    def pointers(self):
-        """(idx_ptr, val_ptr, cnt_ptr, row_stride) for ``clib.predict_device``."""
-        return self.buf.data_ptr(), self.buf.data_ptr() + 4 * self.k, self.cnt.data_ptr(), 2 * self.k + 1
+    def rows(self, part):
+        """local row range [begin, end) of this rank's part"""
+        c = self.cut[self.rank]
+        return c[part], c[part + 1]
+
+    def pointers(self, part=0):
+        """(idx_ptr, val_ptr, cnt_ptr, row_stride) for ``clib.predict_device[_rows]``: addresses such that ABSOLUTE local row r of the
+        part lands in row r - begin of the part's buffer."""
+        begin = self.cut[self.rank][part]
+        base = self.buf[part].data_ptr() - begin * (2 * self.k + 1) * 4
+        return base, base + 4 * self.k, self.cnt.data_ptr(), 2 * self.k + 1
 
     def store(self, idx, val, cnt):
         """Fill from separate tensors (CPU stand-ins in tests): idx int32 [n,k], val float32 [n,k], cnt int32 [n]."""
         import torch
-        n = idx.shape[0]
-        self.buf[:n, : self.k] = idx
-        self.buf[:n, self.k: 2 * self.k] = val.contiguous().view(torch.int32)
-        self.cnt[:n] = cnt
+        for p in range(self.parts):
+            b, e = self.rows(p)
+            self.buf[p][: e - b, : self.k] = idx[b:e]
+            self.buf[p][: e - b, self.k: 2 * self.k] = val[b:e].contiguous().view(torch.int32)
+        self.cnt[: idx.shape[0]] = cnt
 
-    def gather(self, group=None):
+    def gather(self, part=0, group=None):
         import torch
         import torch.distributed as dist
-        self.buf[:, 2 * self.k] = self.cnt
+        b, e = self.rows(part)
+        self.buf[part][: e - b, 2 * self.k] = self.cnt[b:e]
         if not dist.is_initialized():          # single process without a process group: nothing to exchange
-            return self.buf.unsqueeze(0)
+            self.gathered[part][0].copy_(self.buf[part])
+            return
         try:                                   # (a one-rank group still runs the collective: tests exercise RCCL that way)
-            dist.all_gather_into_tensor(self.gathered, self.buf, group=group)
+            dist.all_gather_into_tensor(self.gathered[part], self.buf[part], group=group)
         except (RuntimeError, NotImplementedError):  # backends without the fused form
-            parts = [torch.empty_like(self.buf) for _ in range(self.world)]
-            dist.all_gather(parts, self.buf, group=group)
-            self.gathered.copy_(torch.stack(parts))
-        return self.gathered
+            chunks = [torch.empty_like(self.buf[part]) for _ in range(self.world)]
+            dist.all_gather(chunks, self.buf[part], group=group)
+            self.gathered[part].copy_(torch.stack(chunks))
 
-    def unpack(self, gathered, bounds):
-        """-> global (idx int32 [N,k], val float32 [N,k], cnt int32 [N]) in row order."""
+    def unpack(self):
+        """-> global (idx int32 [N,k], val float32 [N,k], cnt int32 [N]) in row order (after every part has been gathered)."""
         import torch
-        sizes = np.diff(bounds)
-        rows = torch.cat([gathered[r, : int(sizes[r])] for r in range(gathered.shape[0])], dim=0)
+        pieces = []
+        for r in range(self.world):
+            for p in range(self.parts):
+                n = self.cut[r][p + 1] - self.cut[r][p]
+                pieces.append(self.gathered[p][r, :n])
+        rows = torch.cat(pieces, dim=0)
         return rows[:, : self.k].contiguous(), rows[:, self.k: 2 * self.k].contiguous().view(torch.float32), rows[:, 2 * self.k].contiguous()
 
 
@@ -148,7 +169,9 @@ class ShardedXLinear:
             raise ValueError("X_local does not hold the rows bounds assign to this rank")
         idx, val, cnt = self._fn(X_local, beam_size, only_topk, post_processor)
         if self.world > 1:
-            pk = PackedTopk(int(np.diff(bounds).max()), idx.shape[1], self.world, idx.device)
+            pk = PackedTopk(bounds, self.rank, idx.shape[1], idx.device, parts=2 if X_local.shape[0] >= 4 else 1)
             pk.store(idx, val, cnt)
-            idx, val, cnt = pk.unpack(pk.gather(self.group), bounds)
+            for p in range(pk.parts):
+                pk.gather(p, self.group)
+            idx, val, cnt = pk.unpack()
         return rows_to_csr(idx.cpu().numpy().view(np.uint32), val.cpu().numpy(), cnt.cpu().numpy(), self.model.nr_pred_cols)

@@ -149,3 +149,57 @@ def test_model_compiler_tile_split_and_row_placement():
     # a row longer than a tile is wide is a compiler bug: loud error, not a bad layout
     with pytest.raises(RuntimeError):
         clib.debug_layout_rows([3, 200, 1])
+
+
+def test_native_reader_survives_corrupt_files(tmp_path):
+    # a truncated or corrupt model file must end in an xrl_last_error, never in an out-of-bounds access.  The host-only
+    # parser (xrl_inspect_model -> load_csc_npz) is run over systematically damaged copies of a valid W.npz: truncations, byte
+    # flips all over the zip central directory / local headers / npy headers, and index arrays that break the CSC invariants.
+    import shutil
+    import xrl_synth
+    from pecos_amd import clib
+    src = str(tmp_path / "good")
+    xrl_synth.make_model(src, 60, 40, [12, 6], seed=3, shape=[5, 40])
+    assert len(clib.inspect_model(os.path.join(src, "ranker"))) == 2
+    wpath = os.path.join("ranker", "1.model", "W.npz")
+    good = open(os.path.join(src, wpath), "rb").read()
+    rng = np.random.default_rng(0)
+
+    def check(blob, what):
+        dst = str(tmp_path / "bad")
+        shutil.rmtree(dst, ignore_errors=True)
+        shutil.copytree(src, dst)
+        open(os.path.join(dst, wpath), "wb").write(blob)
+        try:
+            clib.inspect_model(os.path.join(dst, "ranker"))      # either parses (the damage hit a don't-care byte) ...
+        except RuntimeError:
+            pass                                                  # ... or reports; a crash would kill the test process
+
+    for cut in (0, 10, 21, 22, 100, len(good) // 2, len(good) - 30, len(good) - 1):
+        check(good[:cut], f"truncated at {cut}")
+    eocd = good.rfind(b"PK\x05\x06"); cd = good.find(b"PK\x01\x02")
+    regions = [(eocd, len(good)), (cd, eocd), (0, 400)]
+    for lo, hi in regions:
+        for _ in range(120):
+            b = bytearray(good)
+            for pos in rng.integers(lo, hi, size=int(rng.integers(1, 4))):
+                b[int(pos)] = int(rng.integers(0, 256))
+            check(bytes(b), "byte flips")
+    # structurally valid archives with broken CSC content
+    W = smat.load_npz(os.path.join(src, wpath)).tocsc()
+    for kind in ("indptr_decreasing", "indptr_start", "row_out_of_range", "nnz_mismatch"):
+        ip, ix, da = W.indptr.copy(), W.indices.copy(), W.data.copy()
+        if kind == "indptr_decreasing":
+            ip[3], ip[4] = ip[4] + 2, ip[3]
+        elif kind == "indptr_start":
+            ip[0] = 1
+        elif kind == "row_out_of_range":
+            ix[5] = W.shape[0] + 7
+        else:
+            ip[-1] += 3
+        p = str(tmp_path / "w.npz")
+        np.savez(p, indptr=ip, indices=ix, data=da, shape=np.array(W.shape), format=np.array("csc"))
+        dst = str(tmp_path / "bad2")
+        shutil.rmtree(dst, ignore_errors=True); shutil.copytree(src, dst); shutil.copy(p, os.path.join(dst, wpath))
+        with pytest.raises(RuntimeError):
+            clib.inspect_model(os.path.join(dst, "ranker"))
