@@ -17,9 +17,13 @@
 // reference's chain -- and what the matrix cores would have bought, operand reuse, comes from the LDS/register tiling.
 // Roofline: 2 VALU lane-ops per multiply-add -> 39 T multiply-adds/s at 2.4 GHz (half the 157 TFLOP/s fp32 vector peak).
 //
-// Layers whose dense matrix holds kMissing cells (W has no entry there: sparse weight columns under dense X) run the MISS
-// variant, which skips those cells exactly like the reference's row walk does (select on the bit pattern, 4 lane-ops).
+// Layers whose dense matrix holds kMissing cells (W has no entry there: sparse weight columns under dense X): with FINITE x a
+// missing weight is staged as +0.0 (the product is +-0 and leaves every reachable accumulator unchanged), so the same 2-op loop
+// serves them; a workgroup that holds a query with an inf / NaN (xfinite_kernel flags them once per predict) takes the exact
+// loop, which skips those cells like the reference's row walk does (select on the bit pattern, 4 lane-ops).
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "xrl_device.h"
 #include "xrl_kernels.h"
@@ -43,9 +47,29 @@ struct K1GArgs {
     const uint32_t* start;        // [n_tiles+1] first sorted item of every tile
     const uint32_t* blk_start;    // [n_tiles+1] first workgroup of every tile
     float* cand;
+    const uint32_t* x_ok;         // [rows of the batch] 1 = every value of the query row is finite
     uint32_t row0;
     int pp_kind, pp_p, first_layer;
 };
+
+// one wavefront per dense query row: 1 = all values finite.  With finite x a missing weight may be multiplied as +0.0 -- the
+// product is +-0 and leaves every reachable accumulator unchanged (it is never -0.0: it starts at +0.0 + bias and x*w + (-x*w)
+// rounds to +0.0) -- so K1G's inner loop needs no select; rows with an inf / NaN take the exact loop.
+__global__ void __launch_bounds__(256) xfinite_kernel(const float* __restrict__ x, uint32_t rows, uint32_t cols, uint32_t row0, uint32_t* __restrict__ ok) {
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (r >= rows) return;
+    const float* __restrict__ p = x + ((uint64_t)row0 + r) * cols;
+    bool fin = true;
+    for (uint32_t c = lane; c < cols; c += 64u) { const uint32_t b = __float_as_uint(p[c]); fin = fin && ((b & 0x7F800000u) != 0x7F800000u); }
+    const bool all_fin = __all(fin);
+    if (lane == 0) ok[r] = all_fin ? 1u : 0u;
+}
+
+void launch_xfinite(const QueriesDev& X, uint32_t row0, uint32_t nrows, uint32_t* ok, hipStream_t s) {
+    if (nrows == 0) return;
+    hipLaunchKernelGGL(xfinite_kernel, dim3((nrows + 3u) / 4u), dim3(256), 0, s, X.val, nrows, X.cols, row0, ok);
+    XRL_LAUNCH_CHECK();
+}
 
 // per tile: number of workgroups = ceil(items / qb)   (exclusive-scanned afterwards)
 __global__ void __launch_bounds__(256) k1g_count_blocks(const uint32_t* __restrict__ start, uint32_t n_tiles, uint32_t qb, uint32_t* __restrict__ blk) {
@@ -78,7 +102,7 @@ __global__ void __launch_bounds__(1024) k1g_scan_kernel(uint32_t* __restrict__ v
     if (threadIdx.x == 0) v[n] = carry;
 }
 
-template <int RQ, int RC, bool MISS, int PPC>
+template <int RQ, int RC, int PPC>
 __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     constexpr int QW = 8 * RQ, QB = 4 * QW, WPC = 8 * RC;     // queries per wavefront / workgroup, padded columns per workgroup
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -87,6 +111,7 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     uint32_t* sRow = reinterpret_cast<uint32_t*>(sX + QB * LDK);   // [QB] query row of every item of the workgroup
     uint32_t* sOut = sRow + QB;                                 // [QB] first candidate slot of the item's child block
     float* sPs = reinterpret_cast<float*>(sOut + QB);           // [QB] parent score
+    __shared__ int s_exact;
 
     const uint32_t T = a.L.n_tiles, b = blockIdx.x;
     if (b >= a.blk_start[T]) return;
@@ -103,10 +128,14 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     const uint64_t wbase = (uint64_t)dt0 << gl;
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, cl = lane & 7u, ql = lane >> 3;
+    if (tid == 0) s_exact = 0;
+    __syncthreads();
     for (uint32_t i = tid; i < (uint32_t)QB; i += 256u) {
         ItemDescG it{}; it.tile = kNoTileG;
         if (i < nq) it = a.items[i0 + i];
         sRow[i] = it.q; sOut[i] = it.out_off; sPs[i] = it.pscore;
+        // the layer has cells without a weight AND this query holds an inf / NaN: the whole workgroup takes the exact loop
+        if (i < nq && !a.L.d_full && !(a.x_ok && a.x_ok[it.q])) s_exact = 1;
     }
 
     // this lane's columns: c = cc*8 + cl -> dense tile c >> gl, column c & gmask -> child
@@ -131,41 +160,77 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     const uint32_t* __restrict__ wd = a.L.wd;
     const float* __restrict__ xg = a.X.val;
     const uint32_t xcols = a.X.cols;
-    const uint32_t padw = MISS ? kMissing : 0u;
     const bool x16 = (xcols & 3u) == 0u && (reinterpret_cast<uintptr_t>(xg) & 15u) == 0u;
 
-    for (uint32_t k0 = 0; k0 < n_feat; k0 += (uint32_t)KC) {
-        __syncthreads();                                        // the previous step's readers are done (and sRow is visible)
-        // ---- weight panel: rows k0..k0+63, the parent's WP padded columns -> sW[k/4][col][k%4] (one 16-byte store per thread step)
-        for (uint32_t e = tid; e < (uint32_t)(KC / 4 * WPC); e += 256u) {
+    // Register-staged pipeline (issue early / write late): the global loads of step s+1 are in flight while step s is multiplied
+    // out of LDS; one set of staging registers, written to LDS right after the barrier that retires step s.
+    uint32_t padw = 0u;                                         // set below once the workgroup knows whether it runs the exact loop
+    constexpr int WIT = (KC / 4 * WPC + 255) / 256;             // weight-panel float4 groups per thread
+    constexpr int XIT = QB * KC / 4 / 256;                      // query-panel float4 per thread
+    uint4 wreg[WIT]; float4 xreg[XIT];
+    auto issue_loads = [&](uint32_t k0) {
+        // weight panel: rows k0..k0+63, the parent's WP padded columns; thread e -> (feature group g = e / WPC, column e % WPC)
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const uint32_t e = tid + (uint32_t)it * 256u;
             const uint32_t g = e / (uint32_t)WPC, col = e % (uint32_t)WPC;
             uint32_t w[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const uint32_t f = k0 + g * 4u + (uint32_t)j;
-                w[j] = (col < WP && f < n_feat) ? wd[(uint64_t)f * ld + wbase + col] : padw;
+                w[j] = (e < (uint32_t)(KC / 4 * WPC) && col < WP && f < n_feat) ? wd[(uint64_t)f * ld + wbase + col] : padw;
+                if (padw == 0u && w[j] == kMissing) w[j] = 0u;        // fast loop: no entry -> +0.0 (finite x only, see xfinite_kernel)
             }
-            *reinterpret_cast<uint4*>(sW + (size_t)e * 4) = make_uint4(w[0], w[1], w[2], w[3]);
+            wreg[it] = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        // ---- query panel: X[row, k0..k0+63] of the workgroup's queries (coalesced along the features; 16 bytes per lane when
-        //      the rows are 16-byte aligned and the step lies inside the layer's features)
-        if (x16 && k0 + (uint32_t)KC <= min(n_feat, xcols)) {
-            for (uint32_t e = tid; e < (uint32_t)(QB * KC / 4); e += 256u) {
-                const uint32_t qq = e / (uint32_t)(KC / 4), k4 = e % (uint32_t)(KC / 4);
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (qq < nq) v = *reinterpret_cast<const float4*>(xg + ((uint64_t)a.row0 + sRow[qq]) * xcols + k0 + k4 * 4u);
-                *reinterpret_cast<float4*>(sX + qq * LDK + k4 * 4u) = v;
+        // query panel: X[row, k0..k0+63] of the workgroup's queries (coalesced along the features; 16 bytes per lane when the
+        // rows are 16-byte aligned and the step lies inside the layer's features)
+        const bool fast = x16 && k0 + (uint32_t)KC <= min(n_feat, xcols);
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const uint32_t e = tid + (uint32_t)it * 256u;
+            const uint32_t qq = e / (uint32_t)(KC / 4), k4 = e % (uint32_t)(KC / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (qq < nq) {
+                const float* __restrict__ xr = xg + ((uint64_t)a.row0 + sRow[qq]) * xcols;
+                if (fast) v = *reinterpret_cast<const float4*>(xr + k0 + k4 * 4u);
+                else {
+                    const uint32_t f = k0 + k4 * 4u;
+                    v.x = (f + 0u < n_feat && f + 0u < xcols) ? xr[f + 0u] : 0.0f;
+                    v.y = (f + 1u < n_feat && f + 1u < xcols) ? xr[f + 1u] : 0.0f;
+                    v.z = (f + 2u < n_feat && f + 2u < xcols) ? xr[f + 2u] : 0.0f;
+                    v.w = (f + 3u < n_feat && f + 3u < xcols) ? xr[f + 3u] : 0.0f;
+                }
             }
-        } else {
-            for (uint32_t e = tid; e < (uint32_t)(QB * KC); e += 256u) {
-                const uint32_t qq = e / (uint32_t)KC, k = e % (uint32_t)KC, f = k0 + k;
-                float v = 0.0f;
-                if (qq < nq && f < n_feat && f < xcols) v = xg[((uint64_t)a.row0 + sRow[qq]) * xcols + f];
-                sX[qq * LDK + k] = v;
-            }
+            xreg[it] = v;
         }
+    };
+    auto store_panels = [&]() {
+#pragma unroll
+        for (int it = 0; it < WIT; ++it) {
+            const uint32_t e = tid + (uint32_t)it * 256u;
+            if (e < (uint32_t)(KC / 4 * WPC)) *reinterpret_cast<uint4*>(sW + (size_t)e * 4) = wreg[it];   // sW[k/4][col][k%4]
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const uint32_t e = tid + (uint32_t)it * 256u;
+            const uint32_t qq = e / (uint32_t)(KC / 4), k4 = e % (uint32_t)(KC / 4);
+            *reinterpret_cast<float4*>(sX + qq * LDK + k4 * 4u) = xreg[it];
+        }
+    };
+
+    __syncthreads();                                            // sRow / sOut / sPs / s_exact are visible
+    const bool exact = s_exact != 0;                            // workgroup-uniform
+    padw = exact ? kMissing : 0u;
+    issue_loads(0u);
+    for (uint32_t k0 = 0; k0 < n_feat; k0 += (uint32_t)KC) {
+        __syncthreads();                                        // the previous step's readers are done
+        store_panels();
         __syncthreads();
+        if (k0 + (uint32_t)KC < n_feat) issue_loads(k0 + (uint32_t)KC);      // in flight during the arithmetic below
         // ---- RQ x RC register tile, 4 features per step; every accumulator takes its features in ascending order
+        auto multiply = [&](auto exact_tag) {
+        constexpr bool EXACT = decltype(exact_tag)::value;
 #pragma unroll 2
         for (int kk = 0; kk < KC; kk += 4) {
             float4 wv[RC], xv[RQ];
@@ -182,12 +247,14 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
                     for (int cc = 0; cc < RC; ++cc) {
                         const float w = j == 0 ? wv[cc].x : j == 1 ? wv[cc].y : j == 2 ? wv[cc].z : wv[cc].w;
                         const float s = acc[r][cc] + x * w;     // built with -ffp-contract=off: multiply, round, add, round
-                        if (MISS) acc[r][cc] = (__float_as_uint(w) == kMissing) ? acc[r][cc] : s;
+                        if (EXACT) acc[r][cc] = (__float_as_uint(w) == kMissing) ? acc[r][cc] : s;
                         else acc[r][cc] = s;
                     }
                 }
             }
         }
+        };
+        if (exact) multiply(std::true_type{}); else multiply(std::false_type{});
     }
     // ---- transform, combine with the parent's score, write the child block
     __syncthreads();
@@ -224,7 +291,7 @@ uint32_t k1g_queries_per_block(const LayerDev& L) {
 }
 
 void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
-                uint32_t* blk_start, float* cand, hipStream_t s) {
+                uint32_t* blk_start, const uint32_t* x_ok, float* cand, hipStream_t s) {
     if (P.nrows == 0) return;
     const uint32_t wp = k1g_cols(L);
     if (wp == 0 || !X.dense) fail("k1g: layer not eligible");
@@ -232,20 +299,17 @@ void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, cons
     hipLaunchKernelGGL(k1g_count_blocks, dim3((L.n_tiles + 255u) / 256u), dim3(256), 0, s, start, L.n_tiles, qb, blk_start);
     hipLaunchKernelGGL(k1g_scan_kernel, dim3(1), dim3(1024), 0, s, blk_start, L.n_tiles);
     K1GArgs a;
-    a.L = L; a.X = X; a.items = static_cast<const ItemDescG*>(items_sorted); a.start = start; a.blk_start = blk_start; a.cand = cand;
+    a.L = L; a.X = X; a.items = static_cast<const ItemDescG*>(items_sorted); a.start = start; a.blk_start = blk_start; a.cand = cand; a.x_ok = x_ok;
     a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
     const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
     const uint64_t blocks = (n_slots + qb - 1) / qb + L.n_tiles;      // every tile adds at most one partial workgroup
     if (blocks > 0x7FFFFFFFull) fail("k1g: grid too large; lower max_batch_rows");
     const int ppc = pp_class(P.pp);
-    const bool miss = !L.d_full;
-#define XRL_K1G_GO(RQ, RC, MM, PP) do { \
-        auto kern = &k1g_kernel<RQ, RC, MM, PP>; const size_t lds = K1GShape<RQ, RC>::lds(); \
+#define XRL_K1G_GO(RQ, RC, PP) do { \
+        auto kern = &k1g_kernel<RQ, RC, PP>; const size_t lds = K1GShape<RQ, RC>::lds(); \
         if (lds > 48 * 1024) XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), lds, s, a); } while (0)
-#define XRL_K1G(RQ, RC) do { \
-        if (miss) { if (ppc) XRL_K1G_GO(RQ, RC, true, 1); else XRL_K1G_GO(RQ, RC, true, 0); } \
-        else { if (ppc) XRL_K1G_GO(RQ, RC, false, 1); else XRL_K1G_GO(RQ, RC, false, 0); } } while (0)
+#define XRL_K1G(RQ, RC) do { if (ppc) XRL_K1G_GO(RQ, RC, 1); else XRL_K1G_GO(RQ, RC, 0); } while (0)
     if (wp <= 8) XRL_K1G(8, 1);
     else if (wp <= 16) XRL_K1G(8, 2);
     else if (wp <= 32) XRL_K1G(4, 4);

@@ -79,7 +79,8 @@ void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const 
 // K1G (xrl_k1g.hip): dense queries against a dense-format layer as a tiled, k-ordered SGEMM over tile-sorted items
 uint32_t k1g_cols(const LayerDev& L);                 // 0: the layer cannot be served by K1G
 void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
-                uint32_t* blk_start, float* cand, hipStream_t s);
+                uint32_t* blk_start, const uint32_t* x_ok, float* cand, hipStream_t s);
+void launch_xfinite(const QueriesDev& X, uint32_t row0, uint32_t nrows, uint32_t* ok, hipStream_t s);   // per dense query row: all values finite?
 // K1C (xrl_pairs.hip): the CSC route of a layer (w_ops<csc_t>, inference.hpp:1081-1149) over the candidates K0 laid out
 void launch_k1c_csc(const LayerDev& L, const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const LayerPlan& P,
                     const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* ncand, float* cand, hipStream_t s);

@@ -128,7 +128,7 @@ struct LaneWs {      // scratch of one row batch in flight
     DevBuf beam_idx[2], beam_val[2], beam_cnt[2];
     DevBuf cand_off, ncand, cand;
     DevBuf items, items_sorted, sort_hist, sort_start;   // item descriptors (K0) and their tile-sorted copy
-    DevBuf blk_start;                                    // K1G: first workgroup of every tile
+    DevBuf blk_start, x_ok;                              // K1G: first workgroup of every tile; per-row "all x finite" flags
 };
 struct Workspace {
     LaneWs lane[2];      // two row batches are in flight on two streams (xrl_predict.cpp)

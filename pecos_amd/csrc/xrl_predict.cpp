@@ -150,6 +150,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             XRL_HIP(hipEventRecord(ev.b, S));
             m.pending.push_back(ev);
         };
+        bool x_ok_done = false;
         for (size_t l = 0; l < T; ++l) {
             const Layer& L = *m.layers[l];
             LayerPlan P{};
@@ -186,7 +187,12 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
                 const uint64_t n_slots3 = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
                 timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots3, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
-                timed("k1g_dense_x", (uint32_t)l, [&] { launch_k1g(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.cand.as<float>(), S); });
+                if (!x_ok_done) {   // once per row batch: which dense query rows are finite (K1G's fast loop needs it on layers with missing cells)
+                    lw.x_ok.reserve((size_t)nb * 4);
+                    launch_xfinite(X, (uint32_t)row0, nrows, lw.x_ok.as<uint32_t>(), S);
+                    x_ok_done = true;
+                }
+                timed("k1g_dense_x", (uint32_t)l, [&] { launch_k1g(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.x_ok.as<uint32_t>(), lw.cand.as<float>(), S); });
                 timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
                 continue;
             }

@@ -231,6 +231,21 @@ def test_edge_cases(XLM, clib, oracle_mod, tmp_path):
         m.predict(X.astype(np.float64))
     with pytest.raises(AssertionError):
         m.predict(smat.csr_matrix((3, 299), dtype=np.float32))
+    # a NON-FINITE query value on a feature no weight column uses: the reference never multiplies it (the row is in no chunk), so the
+    # results stay finite -- the dense-format kernels must SKIP cells without a weight, not multiply by zero (K1G's exact loop, K1Q's
+    # kMissing select), sparse and dense X
+    Wcols = [smat.load_npz(os.path.join(folder, "ranker", f"{d}.model", "W.npz")).tocsr() for d in range(3)]
+    unused = [f for f in range(300) if all(W.indptr[f + 1] == W.indptr[f] for W in Wcols)]
+    if unused:
+        Xi = np.ascontiguousarray(X.toarray()); Xi[::3, unused[0]] = np.inf; Xi[1::3, unused[0]] = np.nan
+        Xs_inf = smat.csr_matrix(Xi); Xs_inf.sort_indices()
+        want = om.predict(Xi, beam_size=4, only_topk=6)
+        assert np.all(np.isfinite(want.data))
+        for g in (1, 0):
+            clib.set_option(m.model.model_chain, "k1g_min_items", g)
+            assert_same_topk(m.predict(Xi, beam_size=4, only_topk=6), want, exact_scores=True, what=f"non-finite x on an unused feature, dense X, k1g_min_items={g}")
+        clib.set_option(m.model.model_chain, "k1g_min_items", 16)
+        assert_same_topk(m.predict(Xs_inf, beam_size=4, only_topk=6), om.predict(Xs_inf, beam_size=4, only_topk=6), exact_scores=True, what="non-finite x, sparse X")
     # all scores tie (zero weights): order must follow candidate position, not label id
     folder2 = str(tmp_path / "ties")
     xrl_synth.make_model(folder2, 50, 120, [10, 5], seed=13, shape=[6, 120])
