@@ -8,9 +8,10 @@
 //   * the layer's items are tile-sorted (counting sort of xrl_kernels.hip), so the queries that share a parent are adjacent;
 //   * a workgroup owns ONE parent and up to QB of its queries: the parent's weight panel W[k0..k0+64, cols] and the queries'
 //     X[q, k0..k0+64] are staged in LDS once per 64-feature step and every weight is reused QB times, every x value WP times;
-//   * lane (cl, ql) holds an RQ x RC register tile of accumulators: queries {ql + 8 r}, columns {cl + 8 c}; per 4 features it
-//     reads RQ + RC float4 from LDS (conflict-free: 8 column lanes x 16 B and 8 query lanes x 16 B cover distinct banks) for
-//     4 RQ RC multiply-adds.
+//   * lane (cl, ql) holds an RQ x RC register tile of accumulators: queries {ql + 8 r}, column PAIRS {16 c2 + 2 cl, +1}; per 4
+//     features it reads RQ float4 (queries) and 4 RC/2 float2 (weights of one feature for a column pair) from LDS --
+//     conflict-free: 8 column lanes x 8 B are contiguous, 8 query lanes x 16 B cover distinct banks -- for 4 RQ RC
+//     multiply-adds; adjacent columns in adjacent registers let v_pk_mul_f32 / v_pk_add_f32 work on pairs without moves.
 // It is NOT an MFMA kernel: v_mfma_f32_* fuses the multiply and the add (one rounding), the reference rounds twice
 // (`output[c] += x * w` compiled without FMA), and the round's contract is bit-identical label order.  Each accumulator
 // therefore walks k in ascending order with a separate fp32 multiply and add (-ffp-contract=off), bias first -- exactly the
@@ -31,6 +32,8 @@
 namespace xrl {
 
 #define XRL_LAUNCH_CHECK() XRL_HIP(hipGetLastError())
+
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct alignas(16) ItemDescG {   // == ItemDesc of xrl_kernels.hip (K0 writes it)
     uint32_t q, tile, out_off; float pscore;
@@ -104,10 +107,13 @@ __global__ void __launch_bounds__(1024) k1g_scan_kernel(uint32_t* __restrict__ v
 
 template <int RQ, int RC, int PPC>
 __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
+    static_assert(RC % 2 == 0, "a lane owns column PAIRS");
     constexpr int QW = 8 * RQ, QB = 4 * QW, WPC = 8 * RC;     // queries per wavefront / workgroup, padded columns per workgroup
+    constexpr int RP = RC / 2;                                 // column pairs per lane
+    constexpr int WLD = WPC;                                   // row stride of the weight panel in LDS (floats)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sW = smem;                                           // [KC/4][WPC][4]: float4 groups of 4 consecutive features
-    float* sX = smem + KC * WPC;                                // [QB][LDK]
+    float* sW = smem;                                           // [KC][WPC]: feature-major, columns contiguous (a lane reads COLUMN PAIRS: packed math without moves)
+    float* sX = smem + KC * WLD;                                // [QB][LDK]
     uint32_t* sRow = reinterpret_cast<uint32_t*>(sX + QB * LDK);   // [QB] query row of every item of the workgroup
     uint32_t* sOut = sRow + QB;                                 // [QB] first candidate slot of the item's child block
     float* sPs = reinterpret_cast<float*>(sOut + QB);           // [QB] parent score
@@ -140,10 +146,10 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
 
     // this lane's columns: c = cc*8 + cl -> dense tile c >> gl, column c & gmask -> child
     uint32_t coff[RC]; bool cval[RC];
-    float acc[RQ][RC];
+    v2f acc[RQ][RP];
 #pragma unroll
     for (int cc = 0; cc < RC; ++cc) {
-        const uint32_t c = (uint32_t)cc * 8u + cl;
+        const uint32_t c = (uint32_t)(cc >> 1) * 16u + 2u * cl + (uint32_t)(cc & 1);     // lane cl owns the column pairs {16 c2 + 2 cl, +1}
         const uint32_t dt = c >> gl, within = c & gmask;
         bool v = c < WP;
         const uint32_t dtc = v ? dt0 + dt : 0u;
@@ -152,7 +158,7 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
         cval[cc] = v; coff[cc] = v ? cb + within : 0u;
         const float b0 = (v && a.L.has_bias) ? a.L.bias_prod[coff[cc]] : 0.0f;       // bias FIRST (inference.hpp:824-830)
 #pragma unroll
-        for (int r = 0; r < RQ; ++r) acc[r][cc] = b0;
+        for (int r = 0; r < RQ; ++r) { if (cc & 1) acc[r][cc >> 1].y = b0; else acc[r][cc >> 1].x = b0; }
     }
 
     const uint32_t w_rows = a.L.w_rows, n_feat = a.L.has_bias ? w_rows - 1u : w_rows;
@@ -161,27 +167,32 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     const float* __restrict__ xg = a.X.val;
     const uint32_t xcols = a.X.cols;
     const bool x16 = (xcols & 3u) == 0u && (reinterpret_cast<uintptr_t>(xg) & 15u) == 0u;
+    const bool w16 = ((ld | wbase) & 3ull) == 0ull && (reinterpret_cast<uintptr_t>(wd) & 15u) == 0u;
 
     // Register-staged pipeline (issue early / write late): the global loads of step s+1 are in flight while step s is multiplied
     // out of LDS; one set of staging registers, written to LDS right after the barrier that retires step s.
     uint32_t padw = 0u;                                         // set below once the workgroup knows whether it runs the exact loop
-    constexpr int WIT = (KC / 4 * WPC + 255) / 256;             // weight-panel float4 groups per thread
+    constexpr int WQ = (WPC + 3) / 4;                           // 16-byte column groups per feature row of the panel
+    constexpr int WIT = (KC * WQ + 255) / 256;                  // weight-panel float4 per thread
     constexpr int XIT = QB * KC / 4 / 256;                      // query-panel float4 per thread
     uint4 wreg[WIT]; float4 xreg[XIT];
     auto issue_loads = [&](uint32_t k0) {
-        // weight panel: rows k0..k0+63, the parent's WP padded columns; thread e -> (feature group g = e / WPC, column e % WPC)
+        // weight panel: rows k0..k0+63, the parent's WP padded columns; thread e -> (feature k = e / (WPC/4), 4 columns from (e % (WPC/4)) * 4)
+        // (dense tiles start at multiples of Gp >= ... columns and d_ld is a multiple of 32: 16-byte aligned whenever WPC >= 4)
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const uint32_t e = tid + (uint32_t)it * 256u;
-            const uint32_t g = e / (uint32_t)WPC, col = e % (uint32_t)WPC;
-            uint32_t w[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t f = k0 + g * 4u + (uint32_t)j;
-                w[j] = (e < (uint32_t)(KC / 4 * WPC) && col < WP && f < n_feat) ? wd[(uint64_t)f * ld + wbase + col] : padw;
-                if (padw == 0u && w[j] == kMissing) w[j] = 0u;        // fast loop: no entry -> +0.0 (finite x only, see xfinite_kernel)
+            const uint32_t kq = e / (uint32_t)WQ, col = (e % (uint32_t)WQ) * 4u, f = k0 + kq;
+            uint4 w = make_uint4(padw, padw, padw, padw);
+            if (e < (uint32_t)(KC * WQ) && f < n_feat) {
+                const uint32_t* __restrict__ src = wd + (uint64_t)f * ld + wbase + col;
+                if (w16 && col + 4u <= WP) w = *reinterpret_cast<const uint4*>(src);
+                else { if (col + 0u < WP) w.x = src[0]; if (col + 1u < WP) w.y = src[1]; if (col + 2u < WP) w.z = src[2]; if (col + 3u < WP) w.w = src[3]; }
             }
-            wreg[it] = make_uint4(w[0], w[1], w[2], w[3]);
+            if (padw == 0u) {                                     // fast loop: no entry -> +0.0 (finite x only, see xfinite_kernel)
+                w.x = w.x == kMissing ? 0u : w.x; w.y = w.y == kMissing ? 0u : w.y; w.z = w.z == kMissing ? 0u : w.z; w.w = w.w == kMissing ? 0u : w.w;
+            }
+            wreg[it] = w;
         }
         // query panel: X[row, k0..k0+63] of the workgroup's queries (coalesced along the features; 16 bytes per lane when the
         // rows are 16-byte aligned and the step lies inside the layer's features)
@@ -209,7 +220,7 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
 #pragma unroll
         for (int it = 0; it < WIT; ++it) {
             const uint32_t e = tid + (uint32_t)it * 256u;
-            if (e < (uint32_t)(KC / 4 * WPC)) *reinterpret_cast<uint4*>(sW + (size_t)e * 4) = wreg[it];   // sW[k/4][col][k%4]
+            if (e < (uint32_t)(KC * WQ)) *reinterpret_cast<uint4*>(sW + ((size_t)(e / (uint32_t)WQ) * WLD + (size_t)(e % (uint32_t)WQ) * 4)) = wreg[it];   // sW[k][col]
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
@@ -233,22 +244,26 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
         constexpr bool EXACT = decltype(exact_tag)::value;
 #pragma unroll 2
         for (int kk = 0; kk < KC; kk += 4) {
-            float4 wv[RC], xv[RQ];
-#pragma unroll
-            for (int cc = 0; cc < RC; ++cc) wv[cc] = *reinterpret_cast<const float4*>(sW + ((size_t)(kk >> 2) * WPC + (size_t)cc * 8 + cl) * 4);
+            float4 xv[RQ];
 #pragma unroll
             for (int r = 0; r < RQ; ++r) xv[r] = *reinterpret_cast<const float4*>(sX + (size_t)(wave * QW + r * 8 + ql) * LDK + kk);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                // this lane's column pairs at feature kk+j: 8-byte reads, 8 lanes x 8 B contiguous (conflict-free), the other lanes broadcast
+                v2f wv[RP];
+#pragma unroll
+                for (int c2 = 0; c2 < RP; ++c2) wv[c2] = *reinterpret_cast<const v2f*>(sW + (size_t)(kk + j) * WLD + (size_t)c2 * 16 + 2 * cl);
 #pragma unroll
                 for (int r = 0; r < RQ; ++r) {
                     const float x = j == 0 ? xv[r].x : j == 1 ? xv[r].y : j == 2 ? xv[r].z : xv[r].w;
+                    const v2f x2 = {x, x};
 #pragma unroll
-                    for (int cc = 0; cc < RC; ++cc) {
-                        const float w = j == 0 ? wv[cc].x : j == 1 ? wv[cc].y : j == 2 ? wv[cc].z : wv[cc].w;
-                        const float s = acc[r][cc] + x * w;     // built with -ffp-contract=off: multiply, round, add, round
-                        if (EXACT) acc[r][cc] = (__float_as_uint(w) == kMissing) ? acc[r][cc] : s;
-                        else acc[r][cc] = s;
+                    for (int c2 = 0; c2 < RP; ++c2) {
+                        const v2f s2 = acc[r][c2] + x2 * wv[c2];  // built with -ffp-contract=off: v_pk_mul_f32, v_pk_add_f32 (multiply, round, add, round)
+                        if (EXACT) {
+                            acc[r][c2].x = (__float_as_uint(wv[c2].x) == kMissing) ? acc[r][c2].x : s2.x;
+                            acc[r][c2].y = (__float_as_uint(wv[c2].y) == kMissing) ? acc[r][c2].y : s2.y;
+                        } else acc[r][c2] = s2;
                     }
                 }
             }
@@ -266,7 +281,7 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
 #pragma unroll
         for (int cc = 0; cc < RC; ++cc) {
             if (!cval[cc]) continue;
-            float v = pp_transform<PPC>(a.pp_kind, a.pp_p, acc[r][cc]);
+            float v = pp_transform<PPC>(a.pp_kind, a.pp_p, (cc & 1) ? acc[r][cc >> 1].y : acc[r][cc >> 1].x);
             if (!a.first_layer) v = pp_combine(a.pp_kind, v, ps);
             a.cand[(size_t)out0 + (coff[cc] - td.col_begin)] = v;
         }
@@ -287,7 +302,7 @@ uint32_t k1g_cols(const LayerDev& L) {
 
 uint32_t k1g_queries_per_block(const LayerDev& L) {
     const uint32_t wp = k1g_cols(L);
-    return wp <= 8 ? 256u : wp <= 16 ? 256u : wp <= 32 ? 128u : 64u;
+    return wp <= 32 ? 128u : 64u;
 }
 
 void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
@@ -310,8 +325,7 @@ void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, cons
         if (lds > 48 * 1024) XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), lds, s, a); } while (0)
 #define XRL_K1G(RQ, RC) do { if (ppc) XRL_K1G_GO(RQ, RC, 1); else XRL_K1G_GO(RQ, RC, 0); } while (0)
-    if (wp <= 8) XRL_K1G(8, 1);
-    else if (wp <= 16) XRL_K1G(8, 2);
+    if (wp <= 16) XRL_K1G(4, 2);
     else if (wp <= 32) XRL_K1G(4, 4);
     else if (wp <= 64) XRL_K1G(2, 8);
     else if (wp <= 96) XRL_K1G(2, 12);

@@ -198,7 +198,11 @@ __global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
-        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        if (NSMAX > 16) {     // the widest kernel serves only layers of 17..24 registers (beam 20 x 64 children, ...)
+            if (ns <= 20) cnt = k1q_layer<(NSMAX > 16 ? 20 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+            else cnt = k1q_layer<(NSMAX > 16 ? 24 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        }
+        else if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
         else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
         else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
         else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
@@ -220,11 +224,11 @@ uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k) {
     if (!L.wd || k == 0 || k > 64 || beam_in > 64) return 0;      // the beam lives in 64-entry LDS arrays on its way through the layers
     const uint64_t cands = ((uint64_t)beam_in * L.d_max_tiles) << L.d_gp_log2;
     const uint64_t ns = (cands + 63) / 64;
-    return ns <= 16 ? (uint32_t)std::max<uint64_t>(1, ns) : 0u;
+    return ns <= 24 ? (uint32_t)std::max<uint64_t>(1, ns) : 0u;
 }
 
-static uint32_t k1q_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 3 ? 3 : ns <= 4 ? 4 : ns <= 6 ? 6 : ns <= 8 ? 8 : ns <= 12 ? 12 : 16; }
-static uint32_t k1q_kernel_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 3 ? 3 : ns <= 6 ? 6 : 16; }   // kernels are compiled for these maxima
+static uint32_t k1q_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 3 ? 3 : ns <= 4 ? 4 : ns <= 6 ? 6 : ns <= 8 ? 8 : ns <= 12 ? 12 : ns <= 16 ? 16 : ns <= 20 ? 20 : 24; }
+static uint32_t k1q_kernel_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 3 ? 3 : ns <= 6 ? 6 : ns <= 16 ? 16 : 24; }   // kernels are compiled for these maxima
 
 // n consecutive dense-format layers (n <= kK1QMaxLayers) in ONE launch: previous beam in, the last layer's beam out
 void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
@@ -258,7 +262,8 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     case 1: XRL_K1Q(1); break;
     case 3: XRL_K1Q(3); break;
     case 6: XRL_K1Q_M(6, false); break;      // only narrow layers (<= 3 registers) are fused (xrl_predict.cpp)
-    default: XRL_K1Q_M(16, false); break;
+    case 16: XRL_K1Q_M(16, false); break;
+    default: XRL_K1Q_M(24, false); break;
     }
 #undef XRL_K1Q
 #undef XRL_K1Q_M
