@@ -259,7 +259,9 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *   "host_pipeline"       1 (default): c_xlinear_predict_* cut a large X into nnz-balanced row batches; batch b+1 is staged into
  *                         pinned memory and uploaded on a copy stream while batch b computes; 0: one synchronous upload
  *   "dense_layers"        1 (default): layers that carry the dense row format run the fused query-stationary kernel K1Q
- *                         whenever the beam's candidates fit its registers; 0: tile-format kernels K0 -> K1 -> K2 everywhere
+ *                         whenever the beam's candidates fit its registers and, for sparse X, the format moves fewer lines than the
+ *                         tile format's row lookup (parents of <= 32 padded columns, or >= 1 weight per (feature, parent) segment);
+ *                         2: whenever they fit (tests); 0: tile-format kernels K0 -> K1 -> K2 everywhere
  *   "k1q_fuse"            1 (default): consecutive dense-format layers run in ONE K1Q launch, the wavefront that owns a query carries
  *                         its beam through them in LDS; 0: one launch per layer
  *   "k1g_min_items"       dense X: a dense-format layer runs the tiled, k-ordered SGEMM K1G (tile-sorted items, weight and query

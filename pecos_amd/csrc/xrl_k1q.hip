@@ -198,11 +198,7 @@ __global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
-        if (NSMAX > 16) {     // the widest kernel serves only layers of 17..24 registers (beam 20 x 64 children, ...)
-            if (ns <= 20) cnt = k1q_layer<(NSMAX > 16 ? 20 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-            else cnt = k1q_layer<(NSMAX > 16 ? 24 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        }
-        else if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
         else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
         else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
         else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
@@ -220,27 +216,30 @@ __global__ void __launch_bounds__(256) k1q_kernel(K1QArgs a) {
 }
 
 // registers per lane a layer needs with `beam_in` parents per query, or 0 when K1Q cannot serve it
-uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k) {
+uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k, bool dense_x) {
+    if (!dense_x && !L.d_sparse_ok) return 0;                         // sparse X, wide parents, near-empty segments: the tile format wins
     if (!L.wd || k == 0 || k > 64 || beam_in > 64) return 0;      // the beam lives in 64-entry LDS arrays on its way through the layers
     const uint64_t cands = ((uint64_t)beam_in * L.d_max_tiles) << L.d_gp_log2;
     const uint64_t ns = (cands + 63) / 64;
-    return ns <= 24 ? (uint32_t)std::max<uint64_t>(1, ns) : 0u;
+    // (17..24 registers were tried for Wiki10-31K's leaf -- beam 20 x 64 children -- and lost to the tile kernels, 4.2 vs 2.7 ms:
+    //  with 418 features per query and 0.3 % dense columns the dense format reads two lines per (feature, parent) for nothing)
+    return ns <= 16 ? (uint32_t)std::max<uint64_t>(1, ns) : 0u;
 }
 
-static uint32_t k1q_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 3 ? 3 : ns <= 4 ? 4 : ns <= 6 ? 6 : ns <= 8 ? 8 : ns <= 12 ? 12 : ns <= 16 ? 16 : ns <= 20 ? 20 : 24; }
-static uint32_t k1q_kernel_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 3 ? 3 : ns <= 6 ? 6 : ns <= 16 ? 16 : 24; }   // kernels are compiled for these maxima
+static uint32_t k1q_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 3 ? 3 : ns <= 4 ? 4 : ns <= 6 ? 6 : ns <= 8 ? 8 : ns <= 12 ? 12 : 16; }
+static uint32_t k1q_kernel_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 3 ? 3 : ns <= 6 ? 6 : 16; }   // kernels are compiled for these maxima
 
 // n consecutive dense-format layers (n <= kK1QMaxLayers) in ONE launch: previous beam in, the last layer's beam out
 void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
                 uint32_t* out_cnt, uint32_t out_stride, hipStream_t s) {
     if (n <= 0 || n > kK1QMaxLayers) fail("k1q: bad layer count");
-    if (n > 1) for (int l = 0; l < n; ++l) if (k1q_regs(*Ls[l], Ps[l].beam_in, Ps[l].k) > 3) fail("k1q: only layers of <= 3 candidate registers can share a launch");
+    if (n > 1) for (int l = 0; l < n; ++l) if (k1q_regs(*Ls[l], Ps[l].beam_in, Ps[l].k, true) > 3) fail("k1q: only layers of <= 3 candidate registers can share a launch");
     if (Ps[0].nrows == 0) return;
     K1QArgs a;
     uint32_t nsmax = 1; int ppc = 0;
     for (int l = 0; l < n; ++l) {
         const LayerDev& L = *Ls[l]; const LayerPlan& P = Ps[l];
-        const uint32_t ns = k1q_regs(L, P.beam_in, P.k);
+        const uint32_t ns = k1q_regs(L, P.beam_in, P.k, true);      // capacity check only; whether sparse X SHOULD use the format is the caller's policy
         if (ns == 0) fail("k1q: layer not eligible");
         K1QLayer& y = a.layer[l];
         y.wd = L.wd; y.d_ld = L.d_ld; y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
@@ -262,8 +261,7 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     case 1: XRL_K1Q(1); break;
     case 3: XRL_K1Q(3); break;
     case 6: XRL_K1Q_M(6, false); break;      // only narrow layers (<= 3 registers) are fused (xrl_predict.cpp)
-    case 16: XRL_K1Q_M(16, false); break;
-    default: XRL_K1Q_M(24, false); break;
+    default: XRL_K1Q_M(16, false); break;
     }
 #undef XRL_K1Q
 #undef XRL_K1Q_M

@@ -90,7 +90,7 @@ void launch_concat_csr(const uint64_t* in_ptr, const uint32_t* in_idx, const flo
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
 // K1Q (xrl_k1q.hip): a whole layer -- prolongate, chunk products against the DENSE row format, post-processor,
 // combine, top-k, child re-ordering -- in one query-stationary kernel: previous beam in, next beam out.
-uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k);   // 0: the layer / beam / k cannot be served by K1Q
+uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k, bool dense_x);   // 0: the layer / beam / k cannot (or should not) be served by K1Q
 // n consecutive dense-format layers in ONE launch (the beam stays in LDS between them); n <= 8
 void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
                 uint32_t* out_cnt, uint32_t out_stride, hipStream_t s);

@@ -570,6 +570,11 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     d.bias = bias; d.has_bias = has_bias ? 1 : 0;
     d.wd = L->dense_bytes ? L->d_wd.as<uint32_t>() : nullptr; d.d_ld = d_ld; d.d_gp_log2 = d_gp_log2; d.d_max_tiles = d_max_tiles;
     d.d_ptile = L->dense_bytes ? L->d_dptile.as<uint32_t>() : nullptr; d.d_tcol = L->dense_bytes ? L->d_dtcol.as<uint32_t>() : nullptr;
+    {
+        const uint64_t wp = (uint64_t)d_max_tiles << d_gp_log2;
+        const double per_segment = (P && W.rows) ? (double)L->nnz / ((double)W.rows * (double)P) : 0.0;   // weights per (feature, parent)
+        d.d_sparse_ok = (wp <= 32 || per_segment >= 1.0) ? 1 : 0;
+    }
     d.d_full = d_full ? 1 : 0; d.tile_parent = L->dense_bytes ? L->d_tile_parent.as<uint32_t>() : nullptr;
     return L;
 }

@@ -85,6 +85,9 @@ struct LayerDev {
     uint32_t d_max_tiles;        // max dense tiles per parent
     const uint32_t* d_ptile;     // [n_parents+1] dense tiles of parent p
     const uint32_t* d_tcol;      // [n_dtiles+1] first child column of every dense tile (children are contiguous)
+    int d_sparse_ok;             // sparse X may use the dense format (K1Q): parents of <= 32 padded columns (half a line / one line per
+                                 // (feature, parent)), or wider ones whose (feature, parent) segments hold >= 1 weight on average; otherwise the
+                                 // tile format's row lookup moves fewer lines (Wiki10-31K's leaf: 0.18 weights per 64-column segment)
     int d_full;                  // every (feature, kept child) cell of the dense matrix holds a weight (no kMissing): K1G's 2-op inner loop
     const uint32_t* tile_parent; // [n_tiles] parent of every tile-format tile (K1G walks tile-sorted items)
 };

@@ -196,12 +196,12 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
                 continue;
             }
-            auto runs_k1q = [&](size_t ll) { return m.dense_layers && !o.stats_out && !csc && layer_mode(ll, nrows) != 3 && k1q_regs(m.layers[ll]->dev, beam_in[ll], k[ll]) != 0; };
+            auto runs_k1q = [&](size_t ll) { return m.dense_layers && !o.stats_out && !csc && layer_mode(ll, nrows) != 3 && k1q_regs(m.layers[ll]->dev, beam_in[ll], k[ll], X.dense != 0 || m.dense_layers >= 2) != 0; };
             if (runs_k1q(l)) {
                 // consecutive dense-format layers run in ONE launch: the wavefront that owns a query carries its beam through them in LDS
                 size_t l1 = l;
                 // (only narrow layers share a launch: a fused kernel is compiled for -- and holds the registers of -- its widest layer)
-                auto narrow = [&](size_t ll) { return k1q_regs(m.layers[ll]->dev, beam_in[ll], k[ll]) <= 3; };
+                auto narrow = [&](size_t ll) { return k1q_regs(m.layers[ll]->dev, beam_in[ll], k[ll], X.dense != 0 || m.dense_layers >= 2) <= 3; };
                 while (m.k1q_fuse && narrow(l) && l1 + 1 < T && l1 + 1 - l < 8 && runs_k1q(l1 + 1) && narrow(l1 + 1)) ++l1;
                 const LayerDev* Ls[8]; LayerPlan Ps[8];
                 for (size_t ll = l; ll <= l1; ++ll) {

@@ -95,7 +95,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         if pp is not None:
             kw["post_processor"] = str(pp)
         # layers that carry the dense row format: fused kernel K1Q (when the beam's candidates fit its registers) / tile-format kernels
-        clib.set_option(m.model.model_chain, "dense_layers", 1 if trial % 2 == 0 else 0)
+        clib.set_option(m.model.model_chain, "dense_layers", (2, 0, 1, 0)[trial])
         clib.set_option(m.model.model_chain, "k2_legacy", 1 if trial == 3 else 0)
         clib.set_option(m.model.model_chain, "k1g_min_items", 1 if trial == 0 else 16)   # dense X: tiled SGEMM forced / by batch size
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))

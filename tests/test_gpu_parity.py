@@ -71,8 +71,10 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
         X = load_X(os.path.join(GOLDEN, "synth", c["model"] + "__X.npz"), c["x"])
         G = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"]))
         assert clib.xlinear_get_int_attr(m.model.model_chain, "nr_dense_layers") > 0
-        P = m.predict(X, **c["kwargs"])        # default: fused query-stationary kernel K1Q on the dense row format
-        assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} dense format (K1Q)")
+        for dl in (1, 2):                      # default policy / K1Q wherever the candidates fit its registers
+            clib.set_option(m.model.model_chain, "dense_layers", dl)
+            P = m.predict(X, **c["kwargs"])
+            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} dense format (K1Q), dense_layers={dl}")
         clib.set_option(m.model.model_chain, "dense_layers", 0)     # tile format: K0 -> K1 -> K2
         for g in (0, 1, 2, 8, 64):
             clib.set_option(m.model.model_chain, "k1_group", g)
@@ -113,10 +115,13 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
     for kw in (dict(beam_size=cfg["beam"], only_topk=10), dict(beam_size=3, only_topk=64), dict(beam_size=70, only_topk=100),
                dict(beam_size=200, only_topk=5, post_processor="log-sigmoid")):
         a = m.predict(X, **kw)
+        clib.set_option(m.model.model_chain, "dense_layers", 2)
+        a2 = m.predict(X, **kw)
         clib.set_option(m.model.model_chain, "dense_layers", 0)
         b = m.predict(X, **kw)
         clib.set_option(m.model.model_chain, "dense_layers", 1)
         assert_same_topk(a, b, exact_scores=True, what=f"{name} dense vs tile format {kw}")
+        assert_same_topk(a2, b, exact_scores=True, what=f"{name} dense (forced) vs tile format {kw}")
     clib.set_option(m.model.model_chain, "dense_layers", 0)     # the remaining checks are about the tile-format kernels
     # two row batches in flight on two streams (default only for large X): same results, also with a ragged tail batch
     for rows in (2, 150):
@@ -519,7 +524,7 @@ def test_full_size_vs_reference(name, XLM, clib, oracle_mod, tmp_path):
     kw = dict(beam_size=cfg["beam"], only_topk=10)
     want = ref.predict(X, threads=32, **kw) if oracle_mod.ref_available() else ref.predict(X, **kw)
     assert want.shape == (X.shape[0], ks[-1])
-    for dl in (1, 0):
+    for dl in (1, 2, 0):
         clib.set_option(m.model.model_chain, "dense_layers", dl)
         assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{name} full size, dense_layers={dl}")
 
