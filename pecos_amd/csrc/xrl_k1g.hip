@@ -35,14 +35,17 @@ namespace xrl {
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+#ifndef XRL_K1G_UNROLL
+#define XRL_K1G_UNROLL 2
+#endif
+
 struct alignas(16) ItemDescG {   // == ItemDesc of xrl_kernels.hip (K0 writes it)
     uint32_t q, tile, out_off; float pscore;
     uint64_t x_begin; uint32_t x_len, pad;
 };
 constexpr uint32_t kNoTileG = 0xFFFFFFFFu;
 
-constexpr int KC = 64;            // features per LDS step
-constexpr int LDK = KC + 4;       // row stride of the x panel in LDS (floats): 16-byte aligned rows on distinct banks
+// KC features per LDS step (template parameter); the x panel's row stride in LDS is KC + 4 floats: 16-byte aligned rows on distinct banks
 
 struct K1GArgs {
     LayerDev L; QueriesDev X;
@@ -105,10 +108,15 @@ __global__ void __launch_bounds__(1024) k1g_scan_kernel(uint32_t* __restrict__ v
     if (threadIdx.x == 0) v[n] = carry;
 }
 
-template <int RQ, int RC, int PPC>
+// RQ x RC: register tile of a lane (queries x columns); CS: wavefronts of the workgroup side by side along the COLUMNS (1 or 2; the
+// other 4 / CS stack along the queries); KC: features per LDS step.
+template <int RQ, int RC, int CS, int KC, int PPC>
 __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     static_assert(RC % 2 == 0, "a lane owns column PAIRS");
-    constexpr int QW = 8 * RQ, QB = 4 * QW, WPC = 8 * RC;     // queries per wavefront / workgroup, padded columns per workgroup
+    static_assert(CS == 1 || CS == 2 || CS == 4, "wavefronts along the columns");
+    constexpr int LDK = KC + 4;
+    constexpr int QW = 8 * RQ, QB = (4 / CS) * QW;            // queries per wavefront / workgroup
+    constexpr int WCW = 8 * RC, WPC = WCW * CS;                // padded columns per wavefront / workgroup
     constexpr int RP = RC / 2;                                 // column pairs per lane
     constexpr int WLD = WPC;                                   // row stride of the weight panel in LDS (floats)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -134,6 +142,7 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     const uint64_t wbase = (uint64_t)dt0 << gl;
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u, cl = lane & 7u, ql = lane >> 3;
+    const uint32_t wq = wave % (uint32_t)(4 / CS), wc = wave / (uint32_t)(4 / CS);     // this wavefront's query block / column block
     if (tid == 0) s_exact = 0;
     __syncthreads();
     for (uint32_t i = tid; i < (uint32_t)QB; i += 256u) {
@@ -144,19 +153,23 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
         if (i < nq && !a.L.d_full && !(a.x_ok && a.x_ok[it.q])) s_exact = 1;
     }
 
-    // this lane's columns: c = cc*8 + cl -> dense tile c >> gl, column c & gmask -> child
-    uint32_t coff[RC]; bool cval[RC];
-    v2f acc[RQ][RP];
-#pragma unroll
-    for (int cc = 0; cc < RC; ++cc) {
-        const uint32_t c = (uint32_t)(cc >> 1) * 16u + 2u * cl + (uint32_t)(cc & 1);     // lane cl owns the column pairs {16 c2 + 2 cl, +1}
+    // this lane's columns -> dense tile c >> gl, column c & gmask -> child (recomputed in the epilogue: not kept live across the loop)
+    auto column = [&](int cc, uint32_t& child) -> bool {
+        const uint32_t c = wc * (uint32_t)WCW + (uint32_t)(cc >> 1) * 16u + 2u * cl + (uint32_t)(cc & 1);   // lane cl owns the column pairs {16 c2 + 2 cl, +1} of its wavefront's block
         const uint32_t dt = c >> gl, within = c & gmask;
         bool v = c < WP;
         const uint32_t dtc = v ? dt0 + dt : 0u;
         const uint32_t cb = a.L.d_tcol[dtc], ce = a.L.d_tcol[dtc + 1];
         v = v && within < ce - cb;
-        cval[cc] = v; coff[cc] = v ? cb + within : 0u;
-        const float b0 = (v && a.L.has_bias) ? a.L.bias_prod[coff[cc]] : 0.0f;       // bias FIRST (inference.hpp:824-830)
+        child = v ? cb + within : 0u;
+        return v;
+    };
+    v2f acc[RQ][RP];
+#pragma unroll
+    for (int cc = 0; cc < RC; ++cc) {
+        uint32_t child;
+        const bool v = column(cc, child);
+        const float b0 = (v && a.L.has_bias) ? a.L.bias_prod[child] : 0.0f;          // bias FIRST (inference.hpp:824-830)
 #pragma unroll
         for (int r = 0; r < RQ; ++r) { if (cc & 1) acc[r][cc >> 1].y = b0; else acc[r][cc >> 1].x = b0; }
     }
@@ -175,6 +188,7 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     constexpr int WQ = (WPC + 3) / 4;                           // 16-byte column groups per feature row of the panel
     constexpr int WIT = (KC * WQ + 255) / 256;                  // weight-panel float4 per thread
     constexpr int XIT = QB * KC / 4 / 256;                      // query-panel float4 per thread
+    static_assert(XIT >= 1 && XIT * 256 * 4 == QB * KC, "the query panel must divide among the threads");
     uint4 wreg[WIT]; float4 xreg[XIT];
     auto issue_loads = [&](uint32_t k0) {
         // weight panel: rows k0..k0+63, the parent's WP padded columns; thread e -> (feature k = e / (WPC/4), 4 columns from (e % (WPC/4)) * 4)
@@ -240,33 +254,45 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
         __syncthreads();
         if (k0 + (uint32_t)KC < n_feat) issue_loads(k0 + (uint32_t)KC);      // in flight during the arithmetic below
         // ---- RQ x RC register tile, 4 features per step; every accumulator takes its features in ascending order
+        // LDS reads are software-pipelined: the weights of feature f+1 and the query values of the next 4 features are in flight
+        // while feature f is multiplied (the last prefetches read the x rows' padding / the row after the weight panel: inside
+        // the allocation, never used).
         auto multiply = [&](auto exact_tag) {
         constexpr bool EXACT = decltype(exact_tag)::value;
-#pragma unroll 2
-        for (int kk = 0; kk < KC; kk += 4) {
-            float4 xv[RQ];
+        const float* __restrict__ xl = sX + (size_t)(wq * QW + ql) * LDK;
+        const float* __restrict__ wl = sW + (size_t)(wc * WCW + 2 * cl);
+        float4 xv[RQ]; v2f wv[2][RP];
 #pragma unroll
-            for (int r = 0; r < RQ; ++r) xv[r] = *reinterpret_cast<const float4*>(sX + (size_t)(wave * QW + r * 8 + ql) * LDK + kk);
+        for (int r = 0; r < RQ; ++r) xv[r] = *reinterpret_cast<const float4*>(xl + (size_t)r * 8 * LDK);
+#pragma unroll
+        for (int c2 = 0; c2 < RP; ++c2) wv[0][c2] = *reinterpret_cast<const v2f*>(wl + (size_t)c2 * 16);
+#pragma unroll XRL_K1G_UNROLL
+        for (int kk = 0; kk < KC; kk += 4) {
+            float4 xn[RQ];
+#pragma unroll
+            for (int r = 0; r < RQ; ++r) xn[r] = *reinterpret_cast<const float4*>(xl + (size_t)r * 8 * LDK + kk + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // this lane's column pairs at feature kk+j: 8-byte reads, 8 lanes x 8 B contiguous (conflict-free), the other lanes broadcast
-                v2f wv[RP];
+                // this lane's column pairs at feature kk+j+1: 8-byte reads, 8 lanes x 8 B contiguous (conflict-free), the other lanes broadcast
 #pragma unroll
-                for (int c2 = 0; c2 < RP; ++c2) wv[c2] = *reinterpret_cast<const v2f*>(sW + (size_t)(kk + j) * WLD + (size_t)c2 * 16 + 2 * cl);
+                for (int c2 = 0; c2 < RP; ++c2) wv[(j + 1) & 1][c2] = *reinterpret_cast<const v2f*>(wl + (size_t)(kk + j + 1) * WLD + (size_t)c2 * 16);
 #pragma unroll
                 for (int r = 0; r < RQ; ++r) {
                     const float x = j == 0 ? xv[r].x : j == 1 ? xv[r].y : j == 2 ? xv[r].z : xv[r].w;
                     const v2f x2 = {x, x};
 #pragma unroll
                     for (int c2 = 0; c2 < RP; ++c2) {
-                        const v2f s2 = acc[r][c2] + x2 * wv[c2];  // built with -ffp-contract=off: v_pk_mul_f32, v_pk_add_f32 (multiply, round, add, round)
+                        const v2f w2 = wv[j & 1][c2];
+                        const v2f s2 = acc[r][c2] + x2 * w2;      // built with -ffp-contract=off: v_pk_mul_f32, v_pk_add_f32 (multiply, round, add, round)
                         if (EXACT) {
-                            acc[r][c2].x = (__float_as_uint(wv[c2].x) == kMissing) ? acc[r][c2].x : s2.x;
-                            acc[r][c2].y = (__float_as_uint(wv[c2].y) == kMissing) ? acc[r][c2].y : s2.y;
+                            acc[r][c2].x = (__float_as_uint(w2.x) == kMissing) ? acc[r][c2].x : s2.x;
+                            acc[r][c2].y = (__float_as_uint(w2.y) == kMissing) ? acc[r][c2].y : s2.y;
                         } else acc[r][c2] = s2;
                     }
                 }
             }
+#pragma unroll
+            for (int r = 0; r < RQ; ++r) xv[r] = xn[r];
         }
         };
         if (exact) multiply(std::true_type{}); else multiply(std::false_type{});
@@ -274,24 +300,19 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     // ---- transform, combine with the parent's score, write the child block
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RQ; ++r) {
-        const uint32_t qi = wave * (uint32_t)QW + (uint32_t)r * 8u + ql;
-        if (qi >= nq) continue;
-        const uint32_t out0 = sOut[qi]; const float ps = sPs[qi];
+    for (int cc = 0; cc < RC; ++cc) {
+        uint32_t child;
+        if (!column(cc, child)) continue;
 #pragma unroll
-        for (int cc = 0; cc < RC; ++cc) {
-            if (!cval[cc]) continue;
+        for (int r = 0; r < RQ; ++r) {
+            const uint32_t qi = wq * (uint32_t)QW + (uint32_t)r * 8u + ql;
+            if (qi >= nq) continue;
             float v = pp_transform<PPC>(a.pp_kind, a.pp_p, (cc & 1) ? acc[r][cc >> 1].y : acc[r][cc >> 1].x);
-            if (!a.first_layer) v = pp_combine(a.pp_kind, v, ps);
-            a.cand[(size_t)out0 + (coff[cc] - td.col_begin)] = v;
+            if (!a.first_layer) v = pp_combine(a.pp_kind, v, sPs[qi]);
+            a.cand[(size_t)sOut[qi] + (child - td.col_begin)] = v;
         }
     }
 }
-
-template <int RQ, int RC> struct K1GShape {
-    static constexpr uint32_t QB = 32 * RQ;
-    static constexpr size_t lds() { return ((size_t)KC * 8 * RC + (size_t)QB * LDK + 3 * (size_t)QB) * 4; }
-};
 
 // padded columns a workgroup must cover, or 0 when K1G cannot serve the layer
 uint32_t k1g_cols(const LayerDev& L) {
@@ -300,9 +321,24 @@ uint32_t k1g_cols(const LayerDev& L) {
     return wp <= 128 ? wp : 0u;
 }
 
-uint32_t k1g_queries_per_block(const LayerDev& L) {
-    const uint32_t wp = k1g_cols(L);
-    return wp <= 32 ? 128u : 64u;
+template <int RQ, int RC, int CS, int KC> struct K1GShape {
+    static constexpr uint32_t QB = (4 / CS) * 8 * RQ;
+    static constexpr size_t lds() { return ((size_t)KC * 8 * RC * CS + (size_t)QB * (KC + 4) + 3 * (size_t)QB) * 4; }
+};
+
+template <int RQ, int RC, int CS, int KC>
+static void k1g_go(K1GArgs& a, const LayerDev& L, const LayerPlan& P, uint32_t* blk_start, hipStream_t s) {
+    constexpr uint32_t qb = K1GShape<RQ, RC, CS, KC>::QB;
+    hipLaunchKernelGGL(k1g_count_blocks, dim3((L.n_tiles + 255u) / 256u), dim3(256), 0, s, a.start, L.n_tiles, qb, blk_start);
+    hipLaunchKernelGGL(k1g_scan_kernel, dim3(1), dim3(1024), 0, s, blk_start, L.n_tiles);
+    const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
+    const uint64_t blocks = (n_slots + qb - 1) / qb + L.n_tiles;      // every tile adds at most one partial workgroup
+    if (blocks > 0x7FFFFFFFull) fail("k1g: grid too large; lower max_batch_rows");
+    auto kern = pp_class(P.pp) ? &k1g_kernel<RQ, RC, CS, KC, 1> : &k1g_kernel<RQ, RC, CS, KC, 0>;
+    constexpr size_t lds = K1GShape<RQ, RC, CS, KC>::lds();
+    static_assert(lds <= 160 * 1024, "panel sizes exceed the LDS");
+    if (lds > 48 * 1024) XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), lds, s, a);
 }
 
 void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
@@ -310,28 +346,19 @@ void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, cons
     if (P.nrows == 0) return;
     const uint32_t wp = k1g_cols(L);
     if (wp == 0 || !X.dense) fail("k1g: layer not eligible");
-    const uint32_t qb = k1g_queries_per_block(L);
-    hipLaunchKernelGGL(k1g_count_blocks, dim3((L.n_tiles + 255u) / 256u), dim3(256), 0, s, start, L.n_tiles, qb, blk_start);
-    hipLaunchKernelGGL(k1g_scan_kernel, dim3(1), dim3(1024), 0, s, blk_start, L.n_tiles);
     K1GArgs a;
     a.L = L; a.X = X; a.items = static_cast<const ItemDescG*>(items_sorted); a.start = start; a.blk_start = blk_start; a.cand = cand; a.x_ok = x_ok;
     a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
-    const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
-    const uint64_t blocks = (n_slots + qb - 1) / qb + L.n_tiles;      // every tile adds at most one partial workgroup
-    if (blocks > 0x7FFFFFFFull) fail("k1g: grid too large; lower max_batch_rows");
-    const int ppc = pp_class(P.pp);
-#define XRL_K1G_GO(RQ, RC, PP) do { \
-        auto kern = &k1g_kernel<RQ, RC, PP>; const size_t lds = K1GShape<RQ, RC>::lds(); \
-        if (lds > 48 * 1024) XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(256), lds, s, a); } while (0)
-#define XRL_K1G(RQ, RC) do { if (ppc) XRL_K1G_GO(RQ, RC, 1); else XRL_K1G_GO(RQ, RC, 0); } while (0)
-    if (wp <= 16) XRL_K1G(4, 2);
-    else if (wp <= 32) XRL_K1G(4, 4);
-    else if (wp <= 64) XRL_K1G(2, 8);
-    else if (wp <= 96) XRL_K1G(2, 12);
-    else XRL_K1G(2, 16);
+    // shapes per class of padded parent width; tune.k1g_variant (xrl_set_option "k1g_variant") selects the alternatives measured in
+    // profiles/ (0 = default)
+    const int v = P.tune.k1g_variant;
+#define XRL_K1G(RQ, RC, CS, KC) k1g_go<RQ, RC, CS, KC>(a, L, P, blk_start, s)
+    if (wp <= 16) { if (v == 1) XRL_K1G(8, 2, 1, 32); else if (v == 2) XRL_K1G(8, 2, 1, 64); else if (v == 3) XRL_K1G(4, 2, 1, 32); else XRL_K1G(4, 2, 1, 64); }
+    else if (wp <= 32) { if (v == 1) XRL_K1G(8, 4, 1, 32); else if (v == 3) XRL_K1G(4, 4, 1, 32); else XRL_K1G(4, 4, 1, 64); }
+    else if (wp <= 64) { if (v == 1) XRL_K1G(4, 4, 2, 64); else if (v == 2) XRL_K1G(4, 8, 1, 32); else if (v == 3) XRL_K1G(4, 4, 2, 32); else XRL_K1G(2, 8, 1, 64); }
+    else if (wp <= 96) { if (v == 1) XRL_K1G(4, 6, 2, 64); else if (v == 2) XRL_K1G(4, 12, 1, 32); else if (v == 3) XRL_K1G(4, 6, 2, 32); else XRL_K1G(2, 12, 1, 64); }
+    else { if (v == 1) XRL_K1G(4, 8, 2, 64); else if (v == 2) XRL_K1G(4, 16, 1, 32); else if (v == 3) XRL_K1G(4, 8, 2, 32); else XRL_K1G(2, 16, 1, 64); }
 #undef XRL_K1G
-#undef XRL_K1G_GO
     XRL_LAUNCH_CHECK();
 }
 

@@ -164,14 +164,16 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         del mb
     if X.shape[1] <= 6000:
         Xd = np.ascontiguousarray(X[:64].toarray())
-        for dl, g in ((1, 0), (1, 1), (0, 0)):     # K1Q / the tiled SGEMM K1G forced on every eligible layer / tile format
+        for dl, g, gv in ((1, 0, 0), (1, 1, 0), (1, 1, 1), (1, 1, 2), (1, 1, 3), (0, 0, 0)):     # K1Q / the tiled SGEMM K1G forced on every eligible layer (each tile shape) / tile format
             clib.set_option(m.model.model_chain, "dense_layers", dl)
             clib.set_option(m.model.model_chain, "k1g_min_items", g)
+            clib.set_option(m.model.model_chain, "k1g_variant", gv)
             for kw in (dict(beam_size=4, only_topk=6), dict(beam_size=cfg["beam"], only_topk=10, post_processor="sigmoid"), dict(beam_size=70, only_topk=100)):
                 assert_same_topk(m.predict(Xd, **kw), ref.predict(Xd, **kw), exact_scores=EXACT_PP(kw.get("post_processor")),
                                  what=f"dense X, dense_layers={dl} k1g_min_items={g} {kw}")
         clib.set_option(m.model.model_chain, "dense_layers", 1)
         clib.set_option(m.model.model_chain, "k1g_min_items", 16)
+        clib.set_option(m.model.model_chain, "k1g_variant", 0)
 
 
 def test_full_width_rows_every_lookup(XLM, clib, oracle_mod, tmp_path):
@@ -554,7 +556,7 @@ def test_dense_input_config_vs_reference(XLM, clib, oracle_mod, tmp_path):
     names = {r["name"] for r in clib.profile_get(m.model.model_chain)}
     clib.profile_enable(m.model.model_chain, False)
     assert "k1g_dense_x" in names, names
-    for opt, val in (("k1g_min_items", 0), ("dense_layers", 0)):
+    for opt, val in (("k1g_variant", 1), ("k1g_variant", 2), ("k1g_variant", 3), ("k1g_min_items", 0), ("dense_layers", 0)):
         clib.set_option(m.model.model_chain, opt, val)
         Pt = m.predict(X[:8192], **kw)
         assert np.array_equal(Pt.indices, P.indices[:P.indptr[8192]]) and np.array_equal(Pt.data.view(np.uint32), P.data[:P.indptr[8192]].view(np.uint32)), opt
