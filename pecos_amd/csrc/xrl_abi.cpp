@@ -149,10 +149,17 @@ void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, u
     const uint32_t rows = is_csr ? Xs->rows : Xd->rows;
     const uint64_t elems = is_csr ? (rows ? Xs->row_ptr[rows] : 0) : (uint64_t)rows * Xd->cols;
     const uint64_t bytes = elems * (is_csr ? 8u : 4u);
-    const uint32_t n_batch = (m.host_pipeline && bytes >= (32ull << 20) && rows >= 8192)
-                                 ? (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, bytes / (24ull << 20))) : 1u;
+    // compute batches: CSR -- ~24 MB of nnz each (the kernels' cost follows nnz); dense -- at least 64 k rows each, because the
+    // tiled SGEMM K1G needs many queries per parent (a 24 MB batch of 768-float rows would leave ~10 per leaf parent and fall
+    // back to the query-stationary kernel, 5x slower).  The upload itself always moves in <= 32 MB chunks through two pinned
+    // staging buffers, whatever the batch size.
+    const bool staged = m.host_pipeline && bytes >= (32ull << 20);
+    uint32_t n_batch = 1;
+    if (staged && rows >= 8192)
+        n_batch = is_csr ? (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, bytes / (24ull << 20)))
+                         : (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, rows / 65536u));
     QueriesDev X{};
-    if (n_batch == 1) {
+    if (!staged) {
         if (is_csr) upload_csr(Xs, ws.x_ptr, ws.x_idx, ws.x_val, X);
         else upload_drm(Xd, ws.x_val, X);
         run_and_emit(m, X, o, alloc);
@@ -180,30 +187,35 @@ void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, u
         X.rows = rows; X.cols = Xd->cols; X.dense = 1; X.nnz = 0;
     }
     for (uint32_t b = 0; b < n_batch; ++b) o.reserve_rows = std::max(o.reserve_rows, rb[b + 1] - rb[b]);
-    for (int s2 = 0; s2 < 2; ++s2) ws.stage[s2].reserve(max_elems * (is_csr ? 8u : 4u));
+    const uint64_t chunk_elems = (32ull << 20) / (is_csr ? 8u : 4u);      // elements per staged upload chunk
+    for (int s2 = 0; s2 < 2; ++s2) ws.stage[s2].reserve(std::min(max_elems, chunk_elems) * (is_csr ? 8u : 4u));
     if (!m.copy_stream) XRL_HIP(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
     hipEvent_t up[2];
     for (auto& e : up) XRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const uint32_t k = effective_topk(m, o.only_topk);
     reserve_outputs(m, rows, k);
     try {
+        uint64_t chunk = 0;                                                 // staged chunks so far: slot = chunk & 1
         for (uint32_t b = 0; b < n_batch; ++b) {
-            const int slot = (int)(b & 1u);
-            const uint64_t e0 = elem_at(rb[b]), n = elem_at(rb[b + 1]) - e0;
-            if (b >= 2) XRL_HIP(hipEventSynchronize(up[slot]));        // the slot's previous upload has left the staging buffer
-            char* st = ws.stage[slot].as<char>();
-            if (n) {
+            const uint64_t e0 = elem_at(rb[b]), e1 = elem_at(rb[b + 1]);
+            int last_slot = -1;
+            for (uint64_t c0 = e0; c0 < e1; c0 += chunk_elems, ++chunk) {
+                const int slot = (int)(chunk & 1u);
+                const uint64_t n = std::min(chunk_elems, e1 - c0);
+                if (chunk >= 2) XRL_HIP(hipEventSynchronize(up[slot]));    // the slot's previous upload has left the staging buffer
+                char* st = ws.stage[slot].as<char>();
                 if (is_csr) {
-                    parallel_copy(st, Xs->col_idx + e0, n * 4); parallel_copy(st + n * 4, Xs->val + e0, n * 4);
-                    XRL_HIP(hipMemcpyAsync(ws.x_idx.as<uint32_t>() + e0, st, n * 4, hipMemcpyHostToDevice, m.copy_stream));
-                    XRL_HIP(hipMemcpyAsync(ws.x_val.as<float>() + e0, st + n * 4, n * 4, hipMemcpyHostToDevice, m.copy_stream));
+                    parallel_copy(st, Xs->col_idx + c0, n * 4); parallel_copy(st + n * 4, Xs->val + c0, n * 4);
+                    XRL_HIP(hipMemcpyAsync(ws.x_idx.as<uint32_t>() + c0, st, n * 4, hipMemcpyHostToDevice, m.copy_stream));
+                    XRL_HIP(hipMemcpyAsync(ws.x_val.as<float>() + c0, st + n * 4, n * 4, hipMemcpyHostToDevice, m.copy_stream));
                 } else {
-                    parallel_copy(st, Xd->val + e0, n * 4);
-                    XRL_HIP(hipMemcpyAsync(ws.x_val.as<float>() + e0, st, n * 4, hipMemcpyHostToDevice, m.copy_stream));
+                    parallel_copy(st, Xd->val + c0, n * 4);
+                    XRL_HIP(hipMemcpyAsync(ws.x_val.as<float>() + c0, st, n * 4, hipMemcpyHostToDevice, m.copy_stream));
                 }
+                XRL_HIP(hipEventRecord(up[slot], m.copy_stream));
+                last_slot = slot;
             }
-            XRL_HIP(hipEventRecord(up[slot], m.copy_stream));
-            XRL_HIP(hipStreamWaitEvent(m.stream, up[slot], 0));         // batch b's kernels start when its rows have arrived
+            if (last_slot >= 0) XRL_HIP(hipStreamWaitEvent(m.stream, up[last_slot], 0));   // batch b's kernels start when its rows have arrived (the copy stream is in order)
             if (rb[b + 1] > rb[b]) {
                 predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, false,
                                rb[b], rb[b + 1] - rb[b]);
@@ -886,6 +898,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
         else if (!std::strcmp(key, "k1t_min_items")) m.k1t_min_items = (int)value;
         else if (!std::strcmp(key, "k1t_items_per_block")) m.k1t_items_per_block = (int)value;
+        else if (!std::strcmp(key, "k1g_grouped")) m.k1g_grouped = (int)value;   // K1G, narrow layers: XCD-aware workgroup order (A/B; results identical)
         else if (!std::strcmp(key, "k1g_variant")) m.k1g_variant = (int)value;   // K1G tile-shape alternative (tuning; results identical)
         else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
         else if (!std::strcmp(key, "k1_lds_pad")) m.k1_lds_pad = (int)value;   // debug: occupancy experiments
