@@ -266,9 +266,7 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *                         its beam through them in LDS; 0: one launch per layer
  *   "k1g_min_items"       dense X: a dense-format layer runs the tiled, k-ordered SGEMM K1G (tile-sorted items, weight and query
  *                         panels staged in LDS) once a parent serves this many queries on average (default 16; 0 = never: K1Q)
- *   "k1g_grouped"         1 (default): K1G orders the workgroups of narrow layers (parents of <= 32 padded columns) so that the ones
- *                         reading the same range of query rows run on the same XCD (shared L2); 0: tile order
- *   "k1g_variant"         0 (default) .. 3: alternative register-tile / panel shapes of K1G (tuning, A/B; results identical)
+ *   "k1g_variant"         1: the alternative register-tile / panel shapes of K1G (A/B, tests; results identical)
  *   "k2_legacy"           1: round-1 insertion top-k kernels instead of the ballot-bisection K2 (A/B, tests)
  *   "k1_wpb", "k1_lds_pad", "k1_ablate"   debug: wavefronts per K1 workgroup, extra LDS per wavefront, phase ablation
  * Environment read at model load: XRL_K1T=1 (build K1T tile images), XRL_LOOKUP=bitmap|bitmap64|bucket (force the row

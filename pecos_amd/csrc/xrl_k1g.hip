@@ -52,7 +52,6 @@ struct K1GArgs {
     const ItemDescG* items;       // tile-sorted, all active
     const uint32_t* start;        // [n_tiles+1] first sorted item of every tile
     const uint32_t* blk_start;    // [n_tiles+1] first workgroup of every tile
-    const uint32_t* grp;          // XCD-aware order (narrow layers): grp[0] = #groups NG (0: plain order), grp[1..NG+1] = first workgroup of every group
     float* cand;
     const uint32_t* x_ok;         // [rows of the batch] 1 = every value of the query row is finite
     uint32_t row0;
@@ -109,51 +108,6 @@ __global__ void __launch_bounds__(1024) k1g_scan_kernel(uint32_t* __restrict__ v
     if (threadIdx.x == 0) v[n] = carry;
 }
 
-// XCD-aware workgroup order for NARROW layers.  A parent of 16 columns reuses every x value 16 times only, so at full VALU rate
-// the query panels alone need ~10 TB/s -- more than the fabric delivers (measured: 4.3 TB/s, the kernel's bound) -- while every
-// query row is read by `beam` different workgroups (one per parent it visits).  Workgroups are therefore ordered
-//     (j / 8, tile, j % 8)        j = index of the workgroup inside its tile (items of a tile are in ascending query order)
-// and since the hardware deals consecutive workgroups round-robin to the 8 XCDs, XCD x runs the j = 8 jg + x workgroup of EVERY
-// tile back to back: the workgroups that read the same range of query rows share one L2.  grp[] is the exclusive scan of
-// min(8, n_t - 8 jg) over (jg, tile); one 1024-thread block builds it.
-constexpr uint32_t kK1GMaxGroups = 16384;
-__global__ void __launch_bounds__(1024) k1g_group_kernel(const uint32_t* __restrict__ start, uint32_t n_tiles, uint32_t qb, uint32_t* __restrict__ grp) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry, maxn;
-    if (threadIdx.x == 0) { carry = 0; maxn = 0; }
-    __syncthreads();
-    uint32_t mx = 0;
-    for (uint32_t t = threadIdx.x; t < n_tiles; t += 1024u) mx = max(mx, (start[t + 1] - start[t] + qb - 1u) / qb);
-    atomicMax(&maxn, mx);
-    __syncthreads();
-    const uint32_t G = (maxn + 7u) / 8u;
-    const uint64_t ng64 = (uint64_t)G * n_tiles;
-    if (ng64 == 0 || ng64 > kK1GMaxGroups) { if (threadIdx.x == 0) grp[0] = 0; return; }   // plain order
-    const uint32_t NG = (uint32_t)ng64;
-    for (uint32_t base = 0; base < NG; base += 1024u) {
-        const uint32_t e = base + threadIdx.x;
-        uint32_t x = 0;
-        if (e < NG) {
-            const uint32_t t = e % n_tiles, jg = e / n_tiles;
-            const uint32_t n = (start[t + 1] - start[t] + qb - 1u) / qb;
-            x = n > 8u * jg ? min(8u, n - 8u * jg) : 0u;
-        }
-        part[threadIdx.x] = x;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024u; off <<= 1) {
-            const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += v;
-            __syncthreads();
-        }
-        if (e < NG) grp[1 + e] = carry + part[threadIdx.x] - x;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += part[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { grp[1 + NG] = carry; grp[0] = NG; }
-}
-
 // RQ x RC: register tile of a lane (queries x columns); CS: wavefronts of the workgroup side by side along the COLUMNS (1 or 2; the
 // other 4 / CS stack along the queries); KC: features per LDS step.
 template <int RQ, int RC, int CS, int KC, int PPC>
@@ -175,18 +129,9 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
 
     const uint32_t T = a.L.n_tiles, b = blockIdx.x;
     if (b >= a.blk_start[T]) return;
-    const uint32_t NG = a.grp ? a.grp[0] : 0u;
-    uint32_t t, j;
-    if (NG) {                                                   // XCD-aware order: largest group e with grp[1 + e] <= b
-        const uint32_t* __restrict__ gs = a.grp + 1;
-        uint32_t lo = 0, hi = NG;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (gs[mid] <= b) lo = mid; else hi = mid; }
-        t = lo % T; j = (lo / T) * 8u + (b - gs[lo]);
-    } else {                                                    // largest t with blk_start[t] <= b (tiles without items share a start)
-        uint32_t lo = 0, hi = T;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.blk_start[mid] <= b) lo = mid; else hi = mid; }
-        t = lo; j = b - a.blk_start[lo];
-    }
+    uint32_t lo = 0, hi = T;                                    // largest t with blk_start[t] <= b (tiles without items share a start)
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (a.blk_start[mid] <= b) lo = mid; else hi = mid; }
+    const uint32_t t = lo, j = b - a.blk_start[lo];
     const uint32_t i0 = a.start[t] + j * (uint32_t)QB;
     const uint32_t nq = min((uint32_t)QB, a.start[t + 1] - i0);
     const TileDesc td = a.L.tiles[t];
@@ -369,9 +314,6 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
     }
 }
 
-// uint32 words launch_k1g needs in `blk_start` for a layer of n_tiles tiles
-size_t k1g_blk_words(uint32_t n_tiles) { return (size_t)n_tiles + 1 + kK1GMaxGroups + 2; }
-
 // padded columns a workgroup must cover, or 0 when K1G cannot serve the layer
 uint32_t k1g_cols(const LayerDev& L) {
     if (!L.wd || !L.tile_parent || L.max_tiles_per_parent != 1) return 0;
@@ -389,12 +331,6 @@ static void k1g_go(K1GArgs& a, const LayerDev& L, const LayerPlan& P, uint32_t* 
     constexpr uint32_t qb = K1GShape<RQ, RC, CS, KC>::QB;
     hipLaunchKernelGGL(k1g_count_blocks, dim3((L.n_tiles + 255u) / 256u), dim3(256), 0, s, a.start, L.n_tiles, qb, blk_start);
     hipLaunchKernelGGL(k1g_scan_kernel, dim3(1), dim3(1024), 0, s, blk_start, L.n_tiles);
-    a.grp = nullptr;
-    if (8 * RC * CS <= 32 && P.tune.k1g_grouped) {                   // narrow parents: XCD-aware workgroup order
-        uint32_t* grp = blk_start + (L.n_tiles + 1);
-        hipLaunchKernelGGL(k1g_group_kernel, dim3(1), dim3(1024), 0, s, a.start, L.n_tiles, qb, grp);
-        a.grp = grp;
-    }
     const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
     const uint64_t blocks = (n_slots + qb - 1) / qb + L.n_tiles;      // every tile adds at most one partial workgroup
     if (blocks > 0x7FFFFFFFull) fail("k1g: grid too large; lower max_batch_rows");
@@ -413,15 +349,15 @@ void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, cons
     K1GArgs a;
     a.L = L; a.X = X; a.items = static_cast<const ItemDescG*>(items_sorted); a.start = start; a.blk_start = blk_start; a.cand = cand; a.x_ok = x_ok;
     a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
-    // shapes per class of padded parent width; tune.k1g_variant (xrl_set_option "k1g_variant") selects the alternatives measured in
-    // profiles/ (0 = default)
-    const int v = P.tune.k1g_variant;
+    // shapes per class of padded parent width, chosen from the measurements in profiles/r02_k1g_shapes.txt; tune.k1g_variant = 1
+    // (xrl_set_option "k1g_variant") runs the one-wavefront-per-64-queries shapes they replaced (A/B, tests)
+    const bool alt = P.tune.k1g_variant == 1;
 #define XRL_K1G(RQ, RC, CS, KC) k1g_go<RQ, RC, CS, KC>(a, L, P, blk_start, s)
-    if (wp <= 16) { if (v == 1) XRL_K1G(8, 2, 1, 32); else if (v == 3) XRL_K1G(4, 2, 1, 32); else XRL_K1G(4, 2, 1, 64); }
-    else if (wp <= 32) { if (v == 1) XRL_K1G(8, 4, 1, 32); else if (v == 3) XRL_K1G(4, 4, 1, 32); else XRL_K1G(4, 4, 1, 64); }
-    else if (wp <= 64) { if (v == 1) XRL_K1G(4, 4, 2, 64); else if (v == 2) XRL_K1G(4, 8, 1, 32); else if (v == 3) XRL_K1G(4, 4, 2, 32); else if (v == 4) XRL_K1G(8, 4, 2, 32); else XRL_K1G(2, 8, 1, 64); }
-    else if (wp <= 96) { if (v == 1) XRL_K1G(4, 6, 2, 64); else if (v == 2) XRL_K1G(2, 12, 1, 64); else if (v == 4) XRL_K1G(8, 6, 2, 32); else if (v == 5) XRL_K1G(4, 6, 2, 16); else XRL_K1G(4, 6, 2, 32); }
-    else { if (v == 1) XRL_K1G(4, 8, 2, 64); else if (v == 2) XRL_K1G(2, 16, 1, 64); else if (v == 3) XRL_K1G(4, 8, 2, 32); else if (v == 4) XRL_K1G(8, 4, 4, 32); else XRL_K1G(2, 16, 1, 64); }
+    if (wp <= 16) { if (alt) XRL_K1G(4, 2, 1, 32); else XRL_K1G(4, 2, 1, 64); }
+    else if (wp <= 32) { if (alt) XRL_K1G(4, 4, 1, 32); else XRL_K1G(4, 4, 1, 64); }
+    else if (wp <= 64) { if (alt) XRL_K1G(2, 8, 1, 64); else XRL_K1G(4, 4, 2, 32); }
+    else if (wp <= 96) { if (alt) XRL_K1G(2, 12, 1, 64); else XRL_K1G(4, 6, 2, 32); }
+    else { if (alt) XRL_K1G(4, 8, 2, 64); else XRL_K1G(4, 8, 2, 32); }
 #undef XRL_K1G
     XRL_LAUNCH_CHECK();
 }

@@ -23,7 +23,7 @@ struct BeamDev {
     uint32_t stride;
 };
 
-struct K1Tune { int wpb = 1, lds_pad = 0, ablate = 0, k1g_variant = 0, k1g_grouped = 1; };   // per-model tuning / debug knobs (xrl_set_option k1_wpb, k1_lds_pad, k1_ablate, k1g_variant)
+struct K1Tune { int wpb = 1, lds_pad = 0, ablate = 0, k1g_variant = 0; };   // per-model tuning / debug knobs (xrl_set_option k1_wpb, k1_lds_pad, k1_ablate, k1g_variant)
 
 struct LayerPlan {
     uint32_t row0, nrows;       // query rows [row0, row0+nrows) of the query matrix
@@ -78,7 +78,6 @@ void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const 
                         const PostProc& pp, int first_layer, hipStream_t s);
 // K1G (xrl_k1g.hip): dense queries against a dense-format layer as a tiled, k-ordered SGEMM over tile-sorted items
 uint32_t k1g_cols(const LayerDev& L);                 // 0: the layer cannot be served by K1G
-size_t k1g_blk_words(uint32_t n_tiles);               // uint32 words of launch_k1g's blk_start scratch
 void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
                 uint32_t* blk_start, const uint32_t* x_ok, float* cand, hipStream_t s);
 void launch_xfinite(const QueriesDev& X, uint32_t row0, uint32_t nrows, uint32_t* ok, hipStream_t s);   // per dense query row: all values finite?

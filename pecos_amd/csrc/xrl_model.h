@@ -160,8 +160,7 @@ struct Model {
     // options
     int k1_group = 0;                       // 0 = auto
     int k1_wpb = 1, k1_lds_pad = 0, k1_ablate = 0;   // K1 tuning / debug knobs (xrl_set_option), per handle
-    int k1g_variant = 0;                            // K1G register-tile / panel shape alternative (0 = default)
-    int k1g_grouped = 1;                            // K1G on narrow layers: XCD-aware workgroup order (0 = tile order)
+    int k1g_variant = 0;                            // 1: K1G's alternative register-tile / panel shapes (A/B, tests)
     int64_t max_batch_rows = 0;             // 0 = auto
     int overlap_min_rows = 0;               // split a predict of at least this many rows into two half batches on two streams so that one half's
                                             // K0/K2 run under the other half's K1; 0 = never (measured on Amazon-670K: 25.9 vs 25.5 ms, no gain)

@@ -111,7 +111,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 tiles_max = std::max(tiles_max, L.n_tiles);
             }
         }
-        if (any) for (int ln = 0; ln < lanes; ++ln) { LaneWs& lw = ws.lane[ln]; lw.items_sorted.reserve(slots_max * k0_item_bytes()); lw.sort_hist.reserve(hist_max); lw.sort_start.reserve(((size_t)tiles_max + 1) * 4); lw.blk_start.reserve(k1g_blk_words(tiles_max) * 4); }
+        if (any) for (int ln = 0; ln < lanes; ++ln) { LaneWs& lw = ws.lane[ln]; lw.items_sorted.reserve(slots_max * k0_item_bytes()); lw.sort_hist.reserve(hist_max); lw.sort_start.reserve(((size_t)tiles_max + 1) * 4); lw.blk_start.reserve(((size_t)tiles_max + 1) * 4); }
     }
     for (int ln = 0; ln < lanes; ++ln) { LaneWs& lw = ws.lane[ln]; lw.cand_off.reserve(nb * bin_max * 4); lw.ncand.reserve(nb * 4); lw.cand.reserve(nb * (uint64_t)cs_max * 4); }
     if (o.stats_out) {
@@ -157,7 +157,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             P.layer = (int)l;
             P.row0 = (uint32_t)row0; P.nrows = nrows; P.beam_in = beam_in[l]; P.k = k[l];
             P.cand_stride = cstride[l]; P.pp = pp[l];
-            P.tune.wpb = m.k1_wpb; P.tune.lds_pad = m.k1_lds_pad; P.tune.ablate = m.k1_ablate; P.tune.k1g_variant = m.k1g_variant; P.tune.k1g_grouped = m.k1g_grouped;
+            P.tune.wpb = m.k1_wpb; P.tune.lds_pad = m.k1_lds_pad; P.tune.ablate = m.k1_ablate; P.tune.k1g_variant = m.k1g_variant;
             P.first_layer = (l == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;   // no_prev_pred
             P.implicit_root = (l == 0 && !has_init) ? 1 : 0;
             BeamDev prev{};

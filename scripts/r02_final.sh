@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-2 measurement on the GPU box (one gpurun call): parity tests, smoke, bench lines of every BASELINE config,
 # PMC passes (fetch / write / L2 requests / VALU) and kernel-trace stats over the timed kernels of the Amazon-670K bench.
+ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r02_final; mkdir -p $O
 cd $R
 timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest_gpu.log; cat $O/pytest_gpu.log

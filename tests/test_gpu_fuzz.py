@@ -98,8 +98,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         clib.set_option(m.model.model_chain, "dense_layers", (2, 0, 1, 0)[trial])
         clib.set_option(m.model.model_chain, "k2_legacy", 1 if trial == 3 else 0)
         clib.set_option(m.model.model_chain, "k1g_min_items", 1 if trial == 0 else 16)   # dense X: tiled SGEMM forced / by batch size
-        clib.set_option(m.model.model_chain, "k1g_variant", int(rng.integers(0, 6)))      # its alternative tile shapes
-        clib.set_option(m.model.model_chain, "k1g_grouped", int(rng.integers(0, 2)))      # XCD-aware / tile order of its workgroups
+        clib.set_option(m.model.model_chain, "k1g_variant", int(rng.integers(0, 2)))      # its alternative tile shapes
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
         # tile-stationary kernel: off / forced for every layer whose tiles fit in LDS, short and long item runs
         clib.set_option(m.model.model_chain, "k1t_min_items", int(rng.choice([0, 1, 1])))
@@ -116,7 +115,6 @@ def test_fuzz(seed, tmp_path, oracle_mod):
     clib.set_option(m.model.model_chain, "k2_legacy", 0)
     clib.set_option(m.model.model_chain, "k1g_min_items", 16)
     clib.set_option(m.model.model_chain, "k1g_variant", 0)
-    clib.set_option(m.model.model_chain, "k1g_grouped", 1)
     clib.set_option(m.model.model_chain, "dense_layers", 1)
     clib.set_option(m.model.model_chain, "k1t_min_items", 1)
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)
