@@ -262,8 +262,9 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *                         whenever the beam's candidates fit its registers and, for sparse X, the format moves fewer lines than the
  *                         tile format's row lookup (parents of <= 32 padded columns, or >= 1 weight per (feature, parent) segment);
  *                         2: whenever they fit (tests); 0: tile-format kernels K0 -> K1 -> K2 everywhere
- *   "k1q_fuse"            1 (default): consecutive dense-format layers run in ONE K1Q launch, the wavefront that owns a query carries
- *                         its beam through them in LDS; 0: one launch per layer
+ *   "k1q_fuse"            3 (default): consecutive dense-format layers of <= 3 candidate registers per lane (<= 192 candidates per
+ *                         query) run in ONE K1Q launch, the wavefront that owns a query carries its beam through them in LDS;
+ *                         1 / 2: only layers of <= 1 / 2 registers share a launch; 0: one launch per layer
  *   "k1g_min_items"       dense X: a dense-format layer runs the tiled, k-ordered SGEMM K1G (tile-sorted items, weight and query
  *                         panels staged in LDS) once a parent serves this many queries on average (default 16; 0 = never: K1Q)
  *   "k1g_variant"         1: the alternative register-tile / panel shapes of K1G (A/B, tests; results identical)

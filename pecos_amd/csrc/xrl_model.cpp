@@ -50,6 +50,7 @@ Model::Model() {}
 Model::~Model() {
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
+    if (ws_done) (void)hipEventDestroy(ws_done);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
 }

@@ -152,6 +152,8 @@ struct Model {
     uint32_t nr_features = 0, nr_labels = 0, nr_codes = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;       // second lane of the batch pipeline
+    hipEvent_t ws_done = nullptr;           // end of the most recent predict that used the workspace, recorded on ws_stream:
+    hipStream_t ws_stream = nullptr;        //   a predict arriving on ANOTHER stream waits for it before touching the scratch buffers
     hipStream_t copy_stream = nullptr;      // H2D of the pipelined host-ABI path
     int host_pipeline = 1;                  // host ABI: cut large X into row batches whose upload overlaps the previous batch's kernels
     std::vector<hipEvent_t> events;         // cross-stream ordering (timing disabled), reused across predicts
@@ -168,7 +170,7 @@ struct Model {
     int k1t_items_per_block = 1024;
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
-    int k1q_fuse = 1;                       // consecutive dense-format layers share one K1Q launch (the beam stays in LDS); 0: one launch per layer
+    int k1q_fuse = 3;                       // consecutive dense-format layers of <= this many candidate registers (1..3) share one K1Q launch (the beam stays in LDS); 0: one launch per layer
     int k1g_min_items = 16;                 // dense X: run a dense-format layer as the tiled SGEMM K1G once a parent serves this many queries on average (0 = never)
     int k2_legacy = 0;                      // A/B and tests: 1 = round-1 insertion top-k kernels instead of the ballot-bisection K2
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)

@@ -32,6 +32,8 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     if (!m.ws) m.ws = std::make_unique<Workspace>();
     Workspace& ws = *m.ws;
     if (!stream) stream = m.stream;
+    // the scratch buffers are shared by every predict of the handle: an asynchronous predict still running on another stream must finish first
+    if (m.ws_done && m.ws_stream != stream) XRL_HIP(hipStreamWaitEvent(stream, m.ws_done, 0));
 
     // MLModel::predict_internal's shape checks live in Python for the reference
     // (xmc/base.py:1603-1607); here a mismatch is a loud error instead of UB.
@@ -201,7 +203,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 // consecutive dense-format layers run in ONE launch: the wavefront that owns a query carries its beam through them in LDS
                 size_t l1 = l;
                 // (only narrow layers share a launch: a fused kernel is compiled for -- and holds the registers of -- its widest layer)
-                auto narrow = [&](size_t ll) { return k1q_regs(m.layers[ll]->dev, beam_in[ll], k[ll], X.dense != 0 || m.dense_layers >= 2) <= 3; };
+                auto narrow = [&](size_t ll) { return k1q_regs(m.layers[ll]->dev, beam_in[ll], k[ll], X.dense != 0 || m.dense_layers >= 2) <= (uint32_t)std::min(3, m.k1q_fuse); };
                 while (m.k1q_fuse && narrow(l) && l1 + 1 < T && l1 + 1 - l < 8 && runs_k1q(l1 + 1) && narrow(l1 + 1)) ++l1;
                 const LayerDev* Ls[8]; LayerPlan Ps[8];
                 for (size_t ll = l; ll <= l1; ++ll) {
@@ -242,6 +244,9 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         XRL_HIP(hipEventRecord(e, m.aux_stream));
         XRL_HIP(hipStreamWaitEvent(stream, e, 0));
     }
+
+    if (!m.ws_done) XRL_HIP(hipEventCreateWithFlags(&m.ws_done, hipEventDisableTiming));
+    XRL_HIP(hipEventRecord(m.ws_done, stream)); m.ws_stream = stream;
 
     if (o.stats_out) {
         // per layer (kStatsPerLayer doubles): [0] algorithmic bytes of the reference chunks streamed (8E + 4R + 4(R+1) each,

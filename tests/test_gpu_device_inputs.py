@@ -66,6 +66,40 @@ def test_device_resident_queries_and_concat():
     assert nrm.shape == host_cat.shape and np.allclose(np.asarray(nrm[:, D - H:].multiply(nrm[:, D - H:]).sum(axis=1)).ravel(), 1.0, atol=1e-5)
 
 
+def test_async_predicts_on_two_streams_share_the_handle():
+    # xrl_predict_device(sync=0) on two caller streams: the handle's scratch buffers are shared, so the second predict must be
+    # ordered after the first (event recorded at the end of every predict); both results equal the synchronous ones
+    import torch
+    from pecos_amd import XLinearModel, clib
+    folder = os.path.join(GOLDEN, "synth", "s_eurlex")
+    X = load_X(os.path.join(GOLDEN, "synth", "s_eurlex__X.npz"))
+    reps = 40                                         # enough rows for the kernels of two predicts to overlap if nothing ordered them
+    Xa = smat.vstack([X] * reps).tocsr(); Xb = smat.vstack([X[::-1]] * reps).tocsr()
+    Xa.sort_indices(); Xb.sort_indices()
+    m = XLinearModel.load(folder)
+    h = m.model.model_chain
+    dev = torch.device("cuda", 0)
+    k = clib.effective_topk(h, 7)
+    want = [m.predict(Xa, beam_size=5, only_topk=7), m.predict(Xb, beam_size=5, only_topk=7)]
+    qs = [clib.queries_upload(h, Xa), clib.queries_upload(h, Xb)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    for trial in range(3):
+        outs = []
+        for q, st, Xq in zip(qs, streams, (Xa, Xb)):
+            n = Xq.shape[0]
+            idx = torch.zeros((n, k), dtype=torch.int32, device=dev); sc = torch.zeros((n, k), dtype=torch.float32, device=dev)
+            cnt = torch.zeros((n,), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            outs.append((idx, sc, cnt))
+        for q, st, o in zip(qs, streams, outs):
+            clib.predict_device(h, q, 5, None, 7, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), k, stream=st.cuda_stream, sync=False)
+        torch.cuda.synchronize()
+        for o, w in zip(outs, want):
+            assert_same_topk(_rows_to_csr(*o, m.nr_pred_cols), w, exact_scores=True, what=f"async predicts on two streams, trial {trial}")
+    for q in qs:
+        clib.queries_free(q)
+
+
 @pytest.mark.timeout(600)
 def test_bench_step_under_rccl_one_rank(tmp_path):
     env = dict(os.environ, XRL_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
