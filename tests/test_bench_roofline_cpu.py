@@ -1,0 +1,87 @@
+"""CPU: bench.py's roofline accounting on recorded work counters (no GPU): the line's `frac` must equal achieved / peak and stay <= 1
+for the shapes measured in profiles/, cache-resident layer structures are counted at their compulsory HBM bytes, and the dense-query
+step is priced against the fp32 vector peak."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as smat
+
+from conftest import REPO
+
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+class _FakeClib:
+    def __init__(self, stats):
+        self._stats = stats
+
+    def predict_stats(self, h, q, beam, pp, topk):
+        return self._stats
+
+
+def _args(config="amazon-670k", scale=1.0, steps=100):
+    return argparse.Namespace(topk=10, no_stats=False, steps=steps, config=config, scale=scale)
+
+
+def _recorded(name):
+    j = json.loads(open(os.path.join(REPO, "profiles", name)).read().strip().splitlines()[-1])
+    return j
+
+
+def test_amazon_line_recomputes_from_recorded_work():
+    j = _recorded("r02_bench_amazon670k_n1.json")
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == bench.HBM_PEAK_GBPS
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] <= 1.0
+    # achieved = algorithmic bytes per launch / average launch duration, as written in the line itself
+    assert abs(r["achieved"] - r["alg_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+    # the whole step's algorithmic bytes over the step time stay under the HBM peak
+    assert r["step_gbps"] <= bench.HBM_PEAK_GBPS
+    # measured fabric traffic (lower bound, FETCH_SIZE x 1) does not exceed the algorithmic bytes
+    assert r["traffic"] is not None and r["traffic"] <= r["alg_bytes_per_launch"]
+    assert r["l2"]["frac"] <= 1.0
+    assert j["cpu_baseline"]["kind"] == "reference" and j["parity"]["scores_bit_identical"]
+
+
+def test_roofline_function_on_synthetic_counters():
+    rows, k, nnz_row = 1000, 10, 50
+    X = smat.random(rows, 5000, density=nnz_row / 5000, format="csr", dtype=np.float32, random_state=0)
+    depth = 2
+    stats = [dict(ref_chunk_bytes=1e9, candidates=rows * 16.0, items=rows * 1.0, probes=float(X.nnz), hit_rows=float(X.nnz) * 0.5,
+                  hit_entries=float(X.nnz) * 4, item_cols=rows * 16.0, x_cols=float(X.nnz) * 16),
+             dict(ref_chunk_bytes=5e10, candidates=rows * 800.0, items=rows * 10.0, probes=float(X.nnz) * 10, hit_rows=float(X.nnz) * 4,
+                  hit_entries=float(X.nnz) * 60, item_cols=rows * 800.0, x_cols=float(X.nnz) * 800)]
+    linfo = [dict(lookup=0, bucket_levels=0, dense=1, dense_bytes=2_000_000, device_bytes=3_000_000),
+             dict(lookup=2, bucket_levels=0, dense=0, dense_bytes=0, device_bytes=3_000_000_000)]
+    prof = [dict(name="k1q_dense", layer=0, ms=0.5, launches=10), dict(name="k0_prolongate", layer=1, ms=0.1, launches=10),
+            dict(name="k1_sparse", layer=1, ms=20.0, launches=10), dict(name="k2_topk", layer=1, ms=1.0, launches=10)]
+    r = bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, _args(config="unit-test", steps=10), k, rows, 1, 2.2)
+    assert r["bound"] == "hbm" and r["kernel"] == "k1_sparse" and r["traffic"] is None
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    kern = {(e["name"], e["layer"]): e for e in r["kernels"]}
+    # the 3 GB tile structure is larger than the on-chip cache: matched work is the HBM-level figure
+    assert kern[("k1_sparse", 1)]["alg_bytes"] == kern[("k1_sparse", 1)]["matched_bytes"]
+    # the 2 MB dense level is cache-resident: its HBM-level bytes are the compulsory ones, far below the matched-work bytes
+    e0 = kern[("k1q_dense", 0)]
+    assert e0["alg_bytes"] < e0["matched_bytes"] and e0["alg_bytes"] >= e0["structure_bytes"]
+    # a cache-resident dominant kernel reports the matched-work rate against the L2 peak
+    prof2 = [dict(name="k1q_dense", layer=0, ms=50.0, launches=10)]
+    r2 = bench.roofline(_FakeClib(stats), None, None, X, prof2, linfo, 10, _args(config="unit-test", steps=10), k, rows, 1, 5.0)
+    assert r2["kernel"] == "k1q_dense" and r2["l2"]["bound"] == "l2" and r2["l2"]["peak"] == bench.L2_PEAK_GBPS
+    assert abs(r2["l2"]["achieved"] - r2["matched_gbps"]) < 0.2
+
+
+def test_dense_query_line_is_priced_on_flops():
+    Xd = np.ones((64, 32), np.float32)
+    stats = [dict(ref_chunk_bytes=1e6, candidates=64 * 16.0, items=64.0, probes=64.0 * 32, hit_rows=64.0 * 32, hit_entries=64.0 * 32 * 16,
+                  item_cols=64 * 16.0, x_cols=64.0 * 32 * 16)]
+    linfo = [dict(lookup=0, bucket_levels=0, dense=1, dense_bytes=4096, device_bytes=8192)]
+    prof = [dict(name="k1g_dense_x", layer=0, ms=1.0, launches=10), dict(name="k2_topk", layer=0, ms=0.1, launches=10)]
+    r = bench.roofline(_FakeClib(stats), None, None, Xd, prof, linfo, 10, _args(config="unit-test", steps=10), 10, 64, 1, 0.2)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["flops_per_launch"] - 2.0 * 64 * 32 * 16) < 1e-6
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
