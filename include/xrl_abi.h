@@ -267,8 +267,6 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *                         1 / 2: only layers of <= 1 / 2 registers share a launch; 0: one launch per layer
  *   "k1g_min_items"       dense X: a dense-format layer runs the tiled, k-ordered SGEMM K1G (tile-sorted items, weight and query
  *                         panels staged in LDS) once a parent serves this many queries on average (default 16; 0 = never: K1Q)
- *   "k1q_pres"            1 (default): K1Q with sparse X looks a (feature, parent) segment up in the layer's presence bits first and
- *                         requests only the segments that hold a weight; 0: every segment is loaded (A/B, tests)
  *   "k1g_variant"         1: the alternative register-tile / panel shapes of K1G (A/B, tests; results identical)
  *   "k2_legacy"           1: round-1 insertion top-k kernels instead of the ballot-bisection K2 (A/B, tests)
  *   "k1_wpb", "k1_lds_pad", "k1_ablate"   debug: wavefronts per K1 workgroup, extra LDS per wavefront, phase ablation
@@ -277,8 +275,7 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  * 64-feature words carrying the first row's extent on sparse tiles, else 32-feature words),
  * XRL_ROW_ALIGN=0 (keep tile rows packed instead of line-aligned), XRL_MAX_TILE_ENTRIES (lower the tile splitter's
  * limit; tests), XRL_DENSE=0 (never build the dense row format), XRL_DENSE_MAX_MB (cap of one layer's dense matrix;
- * default 65536, and never more than a quarter of the free HBM), XRL_PRES=0|1 (never / always build the dense format's
- * presence bits; default: layers with >= 4 dense tiles per feature row of which >= 10 % hold no weight). */
+ * default 65536, and never more than a quarter of the free HBM). */
 int xrl_set_option(void* model, const char* key, int64_t value);
 
 /* Debug: with option k1_ablate bit 6 set, K1 accumulates per-phase shader cycles

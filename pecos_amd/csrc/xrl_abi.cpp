@@ -898,7 +898,6 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
         else if (!std::strcmp(key, "k1t_min_items")) m.k1t_min_items = (int)value;
         else if (!std::strcmp(key, "k1t_items_per_block")) m.k1t_items_per_block = (int)value;
-        else if (!std::strcmp(key, "k1q_pres")) m.k1q_pres = (int)value;           // K1Q: skip weight segments without an entry (A/B; results identical)
         else if (!std::strcmp(key, "k1g_variant")) m.k1g_variant = (int)value;   // K1G tile-shape alternative (tuning; results identical)
         else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
         else if (!std::strcmp(key, "k1_lds_pad")) m.k1_lds_pad = (int)value;   // debug: occupancy experiments

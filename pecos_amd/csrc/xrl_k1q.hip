@@ -36,7 +36,6 @@ namespace xrl {
 struct K1QLayer {
     const uint32_t* wd; uint64_t d_ld;
     const uint32_t* d_ptile; const uint32_t* d_tcol; const float* bias_prod; const uint32_t* perm_inv;
-    const uint32_t* pres; uint32_t pres_ld;   // presence bits per (feature, dense tile), or nullptr
     uint32_t d_gp_log2, d_max_tiles, n_parents, w_rows;
     uint32_t beam_in, k, ns;          // ns: candidate registers per lane this layer needs
     int has_bias, pp_kind, pp_p, first_layer, implicit_root;
@@ -66,7 +65,6 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     const uint32_t gl = Ly.d_gp_log2, gmask = (1u << gl) - 1u, TT = Ly.d_max_tiles;
     const uint32_t cnt = Ly.implicit_root ? 1u : min(cnt_in, Ly.beam_in);
     uint32_t woff[NS], child[NS]; float ps[NS], acc[NS]; bool valid[NS];
-    uint32_t pword[NS], pbit[NS];                                       // presence word / bit of this candidate's dense tile (bit 0: never load)
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
         const uint32_t u = (uint32_t)r * 64u + (uint32_t)lane;
@@ -84,7 +82,6 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         const uint32_t cb = Ly.d_tcol[dtc], ce = Ly.d_tcol[dtc + 1];
         v = v && col < ce - cb;
         woff[r] = v ? ((dtc << gl) + col) * 4u : 0u;                   // BYTE offset inside a feature row (d_ld < 2^30)
-        pword[r] = dtc >> 5; pbit[r] = v ? 1u << (dtc & 31u) : 0u;
         child[r] = v ? cb + col : 0u;
         ps[r] = pscore; valid[r] = v;
         // dense queries: bias FIRST (inference.hpp:824-830); bias_prod holds fl32(bias * w) or +0.0
@@ -98,17 +95,6 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
 
     // U features per batch: their U*NS weight loads are issued together (addresses depend only on the
     // feature ids: scalar row base + this lane's column offset), then applied in feature order
-    auto apply = [&](const uint32_t (&wb)[U][NS], const float (&xs)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int r = 0; r < NS; ++r) {
-                // scalar * val, then add: no fma (inference.hpp:512-517); no entry -> no operation
-                const float s = __fadd_rn(acc[r], __fmul_rn(xs[u], __uint_as_float(wb[u][r])));
-                acc[r] = (wb[u][r] == kMissing) ? acc[r] : s;
-            }
-        }
-    };
     auto batch = [&](uint32_t fv, uint32_t vbits, uint32_t t, uint32_t f_end) {
         uint32_t wb[U][NS]; float xs[U];
 #pragma unroll
@@ -121,35 +107,15 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
 #pragma unroll
             for (int r = 0; r < NS; ++r) wb[u][r] = *reinterpret_cast<const uint32_t*>(row + woff[r]);   // scalar base + 32-bit lane offset
         }
-        apply(wb, xs);
-    };
-    // the same with the layer's presence bits: one 4-byte lookup per (feature, register) -- the beam's parents of a feature share
-    // a 64-byte line of bits -- and the 64-byte weight segments that hold no entry are never requested (a third of all segments on
-    // Amazon-670K's level 3; on the fabric they are the cold ones, i.e. L2 misses)
-    const uint32_t* __restrict__ pres = Ly.pres;
-    const uint32_t pres_ld = Ly.pres_ld;
-    auto batch_pres = [&](uint32_t fv, uint32_t vbits, uint32_t t, uint32_t f_end) {
-        uint32_t wb[U][NS]; float xs[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t f = min((uint32_t)__builtin_amdgcn_readlane((int)fv, (int)(t + (uint32_t)u)), f_end);
-            const uint32_t* __restrict__ prow = pres + (uint64_t)f * pres_ld;
-#pragma unroll
-            for (int r = 0; r < NS; ++r) wb[u][r] = prow[pword[r]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t f = min((uint32_t)__builtin_amdgcn_readlane((int)fv, (int)(t + (uint32_t)u)), f_end);
-            xs[u] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)vbits, (int)(t + (uint32_t)u)));
-            const char* __restrict__ row = reinterpret_cast<const char*>(wd + (uint64_t)f * ld);
 #pragma unroll
             for (int r = 0; r < NS; ++r) {
-                uint32_t w = kMissing;
-                if (wb[u][r] & pbit[r]) w = *reinterpret_cast<const uint32_t*>(row + woff[r]);
-                wb[u][r] = w;
+                // scalar * val, then add: no fma (inference.hpp:512-517); no entry -> no operation
+                const float s = __fadd_rn(acc[r], __fmul_rn(xs[u], __uint_as_float(wb[u][r])));
+                acc[r] = (wb[u][r] == kMissing) ? acc[r] : s;
             }
         }
-        apply(wb, xs);
     };
 
     if (DENSEX) {
@@ -179,8 +145,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                 fn = ok ? xi[tc] : 0xFFFFFFFFu; vn = __float_as_uint(xv[tc]);
             }
             const uint32_t n = min(64u, xl - t0);
-            if (pres) { for (uint32_t t = 0; t < n; t += (uint32_t)U) batch_pres(fv, vb, t, w_rows); }
-            else { for (uint32_t t = 0; t < n; t += (uint32_t)U) batch(fv, vb, t, w_rows); }
+            for (uint32_t t = 0; t < n; t += (uint32_t)U) batch(fv, vb, t, w_rows);
             fv = fn; vb = vn;
         }
     }
@@ -278,7 +243,6 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
         if (ns == 0) fail("k1q: layer not eligible");
         K1QLayer& y = a.layer[l];
         y.wd = L.wd; y.d_ld = L.d_ld; y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
-        y.pres = (X.dense || !P.tune.k1q_pres) ? nullptr : L.pres; y.pres_ld = L.pres_ld;
         y.d_gp_log2 = L.d_gp_log2; y.d_max_tiles = L.d_max_tiles; y.n_parents = L.n_parents; y.w_rows = L.w_rows;
         y.beam_in = P.beam_in; y.k = P.k; y.ns = k1q_bucket(ns);
         y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root;
@@ -311,29 +275,22 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
 __global__ void __launch_bounds__(256)
 densify_kernel(const uint64_t* __restrict__ col_ptr, const uint32_t* __restrict__ row_idx, const float* __restrict__ val,
                const uint32_t* __restrict__ src_col, const uint32_t* __restrict__ dst_off, uint32_t n_children,
-               uint64_t ld, uint32_t* __restrict__ wd, uint32_t* __restrict__ pres, uint32_t pres_ld, uint32_t gp_log2) {
+               uint64_t ld, uint32_t* __restrict__ wd) {
     // one wavefront per column: lanes stride over the column's entries
     const uint32_t c = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (c >= n_children) return;
     const uint32_t oc = src_col[c], off = dst_off[c];
-    const uint32_t tile = off >> gp_log2;
     const uint64_t e0 = col_ptr[oc], e1 = col_ptr[oc + 1];
-    for (uint64_t e = e0 + (threadIdx.x & 63u); e < e1; e += 64u) {
-        const uint32_t row = row_idx[e];
-        wd[(uint64_t)row * ld + off] = __float_as_uint(val[e]);
-        if (pres) atomicOr(&pres[(uint64_t)row * pres_ld + (tile >> 5)], 1u << (tile & 31u));
-    }
+    for (uint64_t e = e0 + (threadIdx.x & 63u); e < e1; e += 64u) wd[(uint64_t)row_idx[e] * ld + off] = __float_as_uint(val[e]);
 }
 
 void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,
-                    const uint32_t* dst_off, uint32_t n_children, uint32_t w_rows, uint64_t ld, uint32_t* wd,
-                    uint32_t* pres, uint32_t pres_ld, uint32_t gp_log2, hipStream_t s) {
-    // w_rows + 1 rows: the extra last row stays all-kMissing (K1Q sends out-of-range features there) and without presence bits
+                    const uint32_t* dst_off, uint32_t n_children, uint32_t w_rows, uint64_t ld, uint32_t* wd, hipStream_t s) {
+    // w_rows + 1 rows: the extra last row stays all-kMissing (K1Q sends out-of-range features there)
     XRL_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(wd), (int)kMissing, ((size_t)w_rows + 1) * ld, s));
-    if (pres) XRL_HIP(hipMemsetAsync(pres, 0, ((size_t)w_rows + 1) * pres_ld * 4, s));
     if (n_children) {
         hipLaunchKernelGGL(densify_kernel, dim3((n_children + 3u) / 4u), dim3(256), 0, s, col_ptr, row_idx, val, src_col, dst_off,
-                           n_children, ld, wd, pres, pres_ld, gp_log2);
+                           n_children, ld, wd);
         XRL_LAUNCH_CHECK();
     }
 }

@@ -469,7 +469,6 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     std::vector<uint32_t> d_ptile, d_tcol;
     uint32_t d_gp_log2 = 0, d_max_tiles = 0; uint64_t d_ld = 0;
     bool d_full = false;
-    uint32_t d_pres_ld = 0;
     {
         const char* de = std::getenv("XRL_DENSE");
         bool want = !(de && de[0] == '0') && c_nnz > 0 && W.rows > 0 && !structure_only;
@@ -508,29 +507,9 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
             DevBuf t_ptr, t_idx, t_val, t_src, t_dst;
             t_ptr.upload(W.col_ptr); t_idx.upload(W.row_idx); t_val.upload(W.val); t_src.upload(src_col); t_dst.upload(dst_off);
             L->d_wd.reserve(((size_t)W.rows + 1) * d_ld * 4);
-            // presence bits per (feature, dense tile): K1Q (sparse X) skips the segments that hold no weight.  Kept only when a
-            // lookup pays: several tiles per feature row and a fair share of empty segments (XRL_PRES=0 disables, =1 forces).
-            const uint64_t n_dt = d_tcol.size() - 2;
-            const char* pe = std::getenv("XRL_PRES");
-            const bool pres_off = pe && pe[0] == '0', pres_force = pe && pe[0] == '1';
-            uint32_t pres_ld = (uint32_t)((n_dt + 31) / 32);
-            if (pres_ld >= 16) pres_ld = (pres_ld + 15u) & ~15u;                 // whole 64-byte lines per feature row
-            const bool try_pres = !pres_off && (n_dt >= 4 || pres_force);
-            if (try_pres) L->d_pres.reserve(((size_t)W.rows + 1) * pres_ld * 4);
             launch_densify(t_ptr.as<uint64_t>(), t_idx.as<uint32_t>(), t_val.as<float>(), t_src.as<uint32_t>(), t_dst.as<uint32_t>(),
-                           (uint32_t)c_nnz, W.rows, d_ld, L->d_wd.as<uint32_t>(), try_pres ? L->d_pres.as<uint32_t>() : nullptr, pres_ld,
-                           d_gp_log2, nullptr);
+                           (uint32_t)c_nnz, W.rows, d_ld, L->d_wd.as<uint32_t>(), nullptr);
             XRL_HIP(hipStreamSynchronize(nullptr));
-            if (try_pres) {
-                std::vector<uint32_t> hp((size_t)W.rows * pres_ld);
-                XRL_HIP(hipMemcpy(hp.data(), L->d_pres.p, hp.size() * 4, hipMemcpyDeviceToHost));
-                const uint32_t feat_rows = has_bias ? W.rows - 1 : W.rows;       // the bias row is never looked up by a sparse query
-                uint64_t set = 0;
-                for (size_t i = 0; i < (size_t)feat_rows * pres_ld; ++i) set += (uint64_t)__builtin_popcount(hp[i]);
-                L->pres_fill = (feat_rows && n_dt) ? (double)set / ((double)feat_rows * (double)n_dt) : 1.0;
-                if (L->pres_fill > 0.9 && !pres_force) L->d_pres.release();
-                else d_pres_ld = pres_ld;
-            }
             L->d_dptile.upload(d_ptile); L->d_dtcol.upload(d_tcol);
             L->dense_bytes = L->d_wd.cap;
             // does every kept child hold a weight for every feature row (dense-input models do)?
@@ -573,7 +552,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
                       L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap +
-                      L->d_img.cap + L->d_img_off.cap + L->d_bucket.cap + L->d_bitmap64.cap + L->d_wd.cap + L->d_dptile.cap + L->d_dtcol.cap + L->d_pres.cap;
+                      L->d_img.cap + L->d_img_off.cap + L->d_bucket.cap + L->d_bitmap64.cap + L->d_wd.cap + L->d_dptile.cap + L->d_dtcol.cap;
 
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
@@ -598,7 +577,6 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
         d.d_sparse_ok = (wp <= 32 || per_segment >= 1.0) ? 1 : 0;
     }
     d.d_full = d_full ? 1 : 0; d.tile_parent = L->dense_bytes ? L->d_tile_parent.as<uint32_t>() : nullptr;
-    d.pres = d_pres_ld ? L->d_pres.as<uint32_t>() : nullptr; d.pres_ld = d_pres_ld;
     return L;
 }
 

@@ -90,8 +90,6 @@ struct LayerDev {
                                  // tile format's row lookup moves fewer lines (Wiki10-31K's leaf: 0.18 weights per 64-column segment)
     int d_full;                  // every (feature, kept child) cell of the dense matrix holds a weight (no kMissing): K1G's 2-op inner loop
     const uint32_t* tile_parent; // [n_tiles] parent of every tile-format tile (K1G walks tile-sorted items)
-    const uint32_t* pres;        // presence bits of the dense format: bit (dense tile t) of row f <=> wd holds a weight in segment (f, t);
-    uint32_t pres_ld;            //   [(w_rows+1) x pres_ld] words.  nullptr when nearly every segment holds one (not worth a lookup)
 };
 
 struct Layer {
@@ -116,8 +114,7 @@ struct Layer {
     // device storage
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
     DevBuf d_img, d_img_off, d_bucket, d_bitmap64;
-    DevBuf d_wd, d_dptile, d_dtcol, d_tile_parent, d_pres;   // dense row format (see LayerDev::wd)
-    double pres_fill = 1.0;                 // fraction of (feature, dense tile) segments holding a weight
+    DevBuf d_wd, d_dptile, d_dtcol, d_tile_parent;   // dense row format (see LayerDev::wd)
     uint64_t dense_bytes = 0;
     uint32_t bk_shift = 0, bk_n = 0, bk_levels = 0;
     LayerDev dev{};
@@ -165,7 +162,6 @@ struct Model {
     // options
     int k1_group = 0;                       // 0 = auto
     int k1_wpb = 1, k1_lds_pad = 0, k1_ablate = 0;   // K1 tuning / debug knobs (xrl_set_option), per handle
-    int k1q_pres = 1;                               // K1Q (sparse X) consults the presence bits of the dense format (0: loads every segment)
     int k1g_variant = 0;                            // 1: K1G's alternative register-tile / panel shapes (A/B, tests)
     int64_t max_batch_rows = 0;             // 0 = auto
     int overlap_min_rows = 0;               // split a predict of at least this many rows into two half batches on two streams so that one half's
@@ -205,10 +201,8 @@ void finalize_model(Model& m);
 std::unique_ptr<Model> load_mmap_model_from_disk(const std::string& path);        // xrl_mmap.cpp
 void compile_mmap_model(const std::string& npz_path, const std::string& mmap_path);   // xrl_mmap.cpp
 void ensure_device_csc(Layer& L);
-// xrl_k1q.hip: memset wd to kMissing and scatter the CSC columns src_col[c] to padded column dst_off[c]; with pres != nullptr
-// also set bit (dst_off >> gp_log2) of presence row `row` ([(w_rows+1) x pres_ld] words, cleared first)
+// xrl_k1q.hip: memset wd to kMissing and scatter the CSC columns src_col[c] to padded column dst_off[c]
 void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,
-                    const uint32_t* dst_off, uint32_t n_children, uint32_t w_rows, uint64_t ld, uint32_t* wd,
-                    uint32_t* pres, uint32_t pres_ld, uint32_t gp_log2, hipStream_t s);   // upload W as CSC (original column ids) if not there yet
+                    const uint32_t* dst_off, uint32_t n_children, uint32_t w_rows, uint64_t ld, uint32_t* wd, hipStream_t s);   // upload W as CSC (original column ids) if not there yet
 
 }  // namespace xrl

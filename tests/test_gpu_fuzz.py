@@ -79,16 +79,10 @@ def test_fuzz(seed, tmp_path, oracle_mod):
     # that layers too large for bitmaps fall back to, 64-feature words that carry the first row's extent (sparse tiles)
     mode = ("bucket", "bitmap", "bitmap64")[seed % 3]
     os.environ["XRL_LOOKUP"] = mode
-    # presence bits of the dense row format (K1Q skips weight segments without an entry): forced for every layer / by the model
-    # compiler's own rule (several tiles and >= 10 % empty segments) / never
-    pres_env = (None, "1", "1", "0")[(seed // 3) % 4]
-    if pres_env is not None:
-        os.environ["XRL_PRES"] = pres_env
     try:
         m = XLinearModel.load(folder)
     finally:
         os.environ.pop("XRL_LOOKUP", None)
-        os.environ.pop("XRL_PRES", None)
     assert clib.xlinear_get_int_attr(m.model.model_chain, "nr_bucket_layers") == (depth if mode == "bucket" else 0)
     assert clib.xlinear_get_int_attr(m.model.model_chain, "nr_bitmap64_layers") == (depth if mode == "bitmap64" else 0)
     om = oracle_mod.OracleModel.load(folder)
@@ -103,7 +97,6 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         # layers that carry the dense row format: fused kernel K1Q (when the beam's candidates fit its registers) / tile-format kernels
         clib.set_option(m.model.model_chain, "dense_layers", (2, 0, 1, 0)[trial])
         clib.set_option(m.model.model_chain, "k2_legacy", 1 if trial == 3 else 0)
-        clib.set_option(m.model.model_chain, "k1q_pres", 0 if (trial == 2 and seed % 2) else 1)
         clib.set_option(m.model.model_chain, "k1g_min_items", 1 if trial == 0 else 16)   # dense X: tiled SGEMM forced / by batch size
         clib.set_option(m.model.model_chain, "k1g_variant", int(rng.integers(0, 2)))      # its alternative tile shapes
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
@@ -122,7 +115,6 @@ def test_fuzz(seed, tmp_path, oracle_mod):
     clib.set_option(m.model.model_chain, "k2_legacy", 0)
     clib.set_option(m.model.model_chain, "k1g_min_items", 16)
     clib.set_option(m.model.model_chain, "k1g_variant", 0)
-    clib.set_option(m.model.model_chain, "k1q_pres", 1)
     clib.set_option(m.model.model_chain, "dense_layers", 1)
     clib.set_option(m.model.model_chain, "k1t_min_items", 1)
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)

@@ -529,16 +529,6 @@ def test_full_size_vs_reference(name, XLM, clib, oracle_mod, tmp_path):
     for dl in (1, 2, 0):
         clib.set_option(m.model.model_chain, "dense_layers", dl)
         assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{name} full size, dense_layers={dl}")
-    # the same with the dense format's presence bits forced on every layer (K1Q skips empty weight segments), and ignored
-    os.environ["XRL_PRES"] = "1"
-    try:
-        mp = XLM.load(folder)
-    finally:
-        os.environ.pop("XRL_PRES", None)
-    for dl, pres in ((2, 1), (2, 0), (1, 1)):
-        clib.set_option(mp.model.model_chain, "dense_layers", dl)
-        clib.set_option(mp.model.model_chain, "k1q_pres", pres)
-        assert_same_topk(mp.predict(X, **kw), want, exact_scores=True, what=f"{name} full size, presence bits forced, dense_layers={dl} k1q_pres={pres}")
 
 
 def test_dense_input_config_vs_reference(XLM, clib, oracle_mod, tmp_path):
