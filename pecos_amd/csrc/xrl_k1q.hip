@@ -51,9 +51,15 @@ struct K1QArgs {
     uint32_t row0, nrows;
 };
 
+#ifndef XRL_K1Q_U1
+#define XRL_K1Q_U1 16
+#endif
+#ifndef XRL_K1Q_U3
+#define XRL_K1Q_U3 8
+#endif
 template <int NS> struct K1QCfg {
     // weight rows (features) whose loads are in flight together: U * NS loads per lane
-    static constexpr int U = NS <= 1 ? 16 : NS <= 3 ? 8 : NS <= 12 ? 4 : 2;
+    static constexpr int U = NS <= 1 ? XRL_K1Q_U1 : NS <= 3 ? XRL_K1Q_U3 : NS <= 12 ? 4 : 2;
 };
 
 // One layer for one query (one wavefront): beam in s_bidx / s_bval[0..cnt) -> beam out in the same arrays; returns the new count.
