@@ -180,13 +180,11 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
 
 // MULTI = false: exactly one layer (layer[0]); the layer loop and its run-time descriptor indexing cost ~20 VGPRs, which the
 // single-layer launches (wide layers, k1q_fuse = 0) do not pay.
-#ifdef XRL_K1Q_WPE
-#define XRL_K1Q_OCC __attribute__((amdgpu_waves_per_eu(XRL_K1Q_WPE, 8)))
-#else
-#define XRL_K1Q_OCC
-#endif
+// The fused kernel of narrow layers is compiled for 7 wavefronts per SIMD (72 VGPRs instead of the 74 the compiler settles on,
+// no spills; the exp-family post-processors would spill and keep the default): measured 6.57 vs 6.73 ms on Amazon-670K's levels 0-3; 8 (64 VGPRs, 8 spilled) loses, and so does any target
+// on the wide single-layer kernels.
 template <int NSMAX, int PPC, bool DENSEX, bool MULTI>
-__global__ void __launch_bounds__(256) XRL_K1Q_OCC k1q_kernel(K1QArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI && NSMAX <= 3 && PPC == 0) ? 7 : 1, 8))) k1q_kernel(K1QArgs a) {
     __shared__ uint2 sc_all[4 * 64];
     __shared__ uint32_t bidx_all[4 * 64];
     __shared__ float bval_all[4 * 64];
