@@ -1,7 +1,8 @@
 #!/bin/bash
 # Run a pytest selection with the HOST code of libxrl_amd under AddressSanitizer + UBSan (make -C pecos_amd/csrc asan).
-#   scripts/asan_tests.sh -m "not gpu"            (here, no GPU)
-#   scripts/asan_tests.sh -m gpu tests/test_gpu_parity.py      (on a GPU box)
+#   scripts/asan_tests.sh -m "not gpu" tests
+# CPU suite only: ROCm's ASan runtime intercepts hsa_amd_memory_pool_allocate and aborts in a process that also runs HIP on a
+# stock (non-xnack, non-ASan) ROCm stack -- tried on the GPU box, the first HIP allocation fails.
 R=$(cd "$(dirname "$0")/.." && pwd)
 make -C $R/pecos_amd/csrc asan >/dev/null || exit 1
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
