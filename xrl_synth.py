@@ -157,17 +157,32 @@ def make_queries(N, D, x_nnz, seed=1, relabel_seed=0):
         return X
     relabel = np.random.default_rng(relabel_seed).permutation(D)
     cdf = _zipf_cdf(D)
-    # per-row nnz ~ lognormal around x_nnz (real TF-IDF rows are ragged), at least 1
+    # per-row nnz ~ lognormal with MEAN x_nnz (real TF-IDF rows are ragged), at least 1.  Zipf draws repeat the popular features,
+    # so rows are topped up with further draws until every row holds its target number of DISTINCT features (SURVEY.md 8d:
+    # 76 / 240 / 670 per row; round 1 stopped after one pass and came out 12-38 % lighter).
     tgt = np.clip(rng.lognormal(np.log(x_nnz) - 0.125, 0.5, N).astype(np.int64), 1, min(D, 8 * x_nnz))
-    total = int(tgt.sum() * 1.3) + N
-    row = np.repeat(np.arange(N, dtype=np.int64), np.ceil(tgt * 1.3).astype(np.int64) + 1)[:total]
-    ids = relabel[np.searchsorted(cdf, rng.random(len(row))).clip(0, D - 1)]
-    key = np.unique(row * D + ids)
+    work = np.zeros(0, np.int64)                   # keys (row * D + feature) of the rows still short of their target
+    done = []                                      # keys of finished rows
+    need = tgt.copy()
+    for it in range(64):
+        rows_short = np.nonzero(need > 0)[0]
+        if len(rows_short) == 0:
+            break
+        draws = np.ceil(need[rows_short] * (1.3 + 0.5 * it)).astype(np.int64) + 1
+        row = np.repeat(rows_short, draws)
+        ids = relabel[np.searchsorted(cdf, rng.random(len(row))).clip(0, D - 1)]
+        work = np.unique(np.concatenate([work, row * D + ids]))
+        # keep at most tgt ids per row; which ones does not matter for the arithmetic contract, the count does
+        row = work // D
+        cnt = np.bincount(row, minlength=N)
+        start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        work = work[(np.arange(len(work)) - np.repeat(start, cnt)) < np.repeat(tgt, cnt)]
+        row = work // D
+        need = np.where(need > 0, tgt - np.bincount(row, minlength=N), 0)
+        fin = need[row] <= 0
+        done.append(work[fin]); work = work[~fin]
+    key = np.sort(np.concatenate(done + [work]))
     row = key // D
-    cnt = np.bincount(row, minlength=N)
-    start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
-    keep = (np.arange(len(key)) - np.repeat(start, cnt)) < np.repeat(tgt, cnt)
-    key = key[keep]; row = row[keep]
     cnt = np.bincount(row, minlength=N)
     indptr = np.zeros(N + 1, np.int64); np.cumsum(cnt, out=indptr[1:])
     val = np.abs(rng.standard_normal(len(key))).astype(np.float32) + 0.05
