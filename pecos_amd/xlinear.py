@@ -313,6 +313,54 @@ class XLinearModel:
         shutil.copy(path.join(npz_folder, "param.json"), path.join(mmap_folder, "param.json"))
         clib.xlinear_compile_mmap_model(path.join(npz_folder, "ranker"), path.join(mmap_folder, "ranker"))
 
+    # ---- query / label matrix files as the reference's predict CLI reads and writes them (pecos/xmc/xlinear/model.py:424-467,
+    #      pecos/utils/smat_util.py:60-150): .npy = dense, scipy .npz = sparse
+    @staticmethod
+    def _load_matrix(src):
+        if not isinstance(src, str):
+            raise ValueError("src for load_matrix must be a str")
+        mat = np.load(src)
+        if isinstance(mat, np.ndarray):
+            return mat
+        fmt = mat["format"].item()
+        fmt = fmt if isinstance(fmt, str) else fmt.decode("ascii")
+        if fmt in ("csc", "csr", "bsr"):
+            out = getattr(smat, fmt + "_matrix")((mat["data"], mat["indices"], mat["indptr"]), shape=mat["shape"])
+            out.sort_indices()
+            return out
+        if fmt == "coo":
+            return smat.coo_matrix((mat["data"], (mat["row"], mat["col"])), shape=mat["shape"])
+        if fmt == "dia":
+            return smat.dia_matrix((mat["data"], mat["offsets"]), shape=mat["shape"])
+        raise ValueError("Unknown matrix format {}".format(fmt))
+
+    @staticmethod
+    def save_feature_matrix(tgt, feat_mat):
+        """dense -> .npy stream, sparse -> scipy .npz (uncompressed, like the reference's save_matrix)."""
+        if isinstance(feat_mat, np.ndarray):
+            np.save(tgt, feat_mat, allow_pickle=False)
+        elif smat.issparse(feat_mat):
+            smat.save_npz(tgt, feat_mat, compressed=False)
+        else:
+            raise NotImplementedError("Save not implemented for matrix type {}".format(type(feat_mat)))
+
+    @staticmethod
+    def load_feature_matrix(src):
+        """csr_matrix with sorted indices, or a C-contiguous ndarray (what predict() accepts)."""
+        feat_mat = XLinearModel._load_matrix(src)
+        if isinstance(feat_mat, np.ndarray):
+            return np.ascontiguousarray(feat_mat)
+        feat_mat = feat_mat.tocsr()
+        feat_mat.sort_indices()
+        return feat_mat
+
+    @staticmethod
+    def load_label_matrix(src, for_training=False):
+        assert isinstance(src, str), "src for load_label_matrix must be a str"
+        lab = XLinearModel._load_matrix(src)
+        lab = smat.csc_matrix(lab) if for_training else smat.csr_matrix(lab)
+        return lab.astype(np.float32)
+
     def get_pred_params(self):
         return self.PredParams(hlm_args=self.model.get_pred_params())
 

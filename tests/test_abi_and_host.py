@@ -203,3 +203,29 @@ def test_native_reader_survives_corrupt_files(tmp_path):
         shutil.rmtree(dst, ignore_errors=True); shutil.copytree(src, dst); shutil.copy(p, os.path.join(dst, wpath))
         with pytest.raises(RuntimeError):
             clib.inspect_model(os.path.join(dst, "ranker"))
+
+
+def test_feature_and_label_matrix_files_round_trip(tmp_path):
+    # XLinearModel.{save,load}_feature_matrix / load_label_matrix: the file forms the reference's predict CLI exchanges
+    # (pecos/xmc/xlinear/model.py:424-467): .npy dense, scipy .npz sparse; loaded CSR has sorted indices, dense is C-contiguous
+    import scipy.sparse as smat
+    from pecos_amd import XLinearModel
+    rng = np.random.default_rng(0)
+    Xs = smat.random(9, 17, density=0.3, format="csr", dtype=np.float32, random_state=1)
+    Xs.indices[Xs.indptr[2]:Xs.indptr[3]] = Xs.indices[Xs.indptr[2]:Xs.indptr[3]][::-1].copy()      # unsorted on disk
+    Xs.data[Xs.indptr[2]:Xs.indptr[3]] = Xs.data[Xs.indptr[2]:Xs.indptr[3]][::-1].copy()
+    p = str(tmp_path / "X.npz")
+    XLinearModel.save_feature_matrix(p, Xs)
+    got = XLinearModel.load_feature_matrix(p)
+    assert smat.isspmatrix_csr(got) and got.has_sorted_indices and (got != Xs).nnz == 0
+    Xd = np.asfortranarray(rng.standard_normal((5, 7)).astype(np.float32))
+    pd_ = str(tmp_path / "X.npy")
+    XLinearModel.save_feature_matrix(pd_, Xd)
+    gd = XLinearModel.load_feature_matrix(pd_)
+    assert gd.flags["C_CONTIGUOUS"] and np.array_equal(gd, Xd)
+    Y = smat.random(9, 30, density=0.1, format="coo", dtype=np.float64, random_state=2)
+    py = str(tmp_path / "Y.npz")
+    smat.save_npz(py, Y)
+    Yr = XLinearModel.load_label_matrix(py)
+    Yc = XLinearModel.load_label_matrix(py, for_training=True)
+    assert smat.isspmatrix_csr(Yr) and smat.isspmatrix_csc(Yc) and Yr.dtype == np.float32 and abs(Yr - Y.tocsr()).max() < 1e-6
