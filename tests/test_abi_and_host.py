@@ -229,3 +229,20 @@ def test_feature_and_label_matrix_files_round_trip(tmp_path):
     Yr = XLinearModel.load_label_matrix(py)
     Yc = XLinearModel.load_label_matrix(py, for_training=True)
     assert smat.isspmatrix_csr(Yr) and smat.isspmatrix_csc(Yc) and Yr.dtype == np.float32 and abs(Yr - Y.tocsr()).max() < 1e-6
+
+
+def test_synthetic_queries_carry_the_specified_number_of_features():
+    # the bench workloads are quoted on 76 / 240 / 670 distinct features per query; Zipf draws repeat the popular
+    # features, so the generator has to top rows up (round 1's single pass came out 12-38 % lighter)
+    import xrl_synth
+    for name, n_rows in (("amazon-670k", 20000), ("eurlex-4k", 3000), ("wiki10-31k", 1500)):
+        cfg = xrl_synth.CONFIGS[name]
+        X = xrl_synth.make_queries(n_rows, cfg["D"], cfg["x_nnz"], seed=1, relabel_seed=0)
+        per_row = np.diff(X.indptr)
+        assert abs(per_row.mean() / cfg["x_nnz"] - 1.0) < 0.03, (name, per_row.mean())
+        assert per_row.min() >= 1 and X.has_sorted_indices
+        for r in range(0, n_rows, max(1, n_rows // 50)):
+            ids = X.indices[X.indptr[r]:X.indptr[r + 1]]
+            assert (np.diff(ids) > 0).all()                      # sorted, distinct
+        nrm = np.sqrt(np.asarray(X.multiply(X).sum(axis=1)).ravel())
+        assert np.allclose(nrm, 1.0, atol=1e-4)                  # L2-normalised rows (xrl_predict.py:143)
