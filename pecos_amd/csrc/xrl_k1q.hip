@@ -41,7 +41,6 @@ struct K1QLayer {
     int has_bias, pp_kind, pp_p, first_layer, implicit_root;
 };
 constexpr int kK1QMaxLayers = 8;
-constexpr int kK1QStashRegs = 3;      // layers of up to this many candidate registers stash their epilogue state in LDS
 
 struct K1QArgs {
     K1QLayer layer[kK1QMaxLayers];
@@ -66,10 +65,7 @@ template <int NS> struct K1QCfg {
 // One layer for one query (one wavefront): beam in s_bidx / s_bval[0..cnt) -> beam out in the same arrays; returns the new count.
 template <int NS, int PPC, bool DENSEX>
 __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesDev& X, uint64_t xrow, uint32_t cnt_in,
-                                               uint32_t* s_bidx, float* s_bval, uint2* sc, uint2* stash, int lane) {
-    // narrow layers park what only the epilogue needs (child id, parent score) in LDS during the feature loop: 2 NS registers
-    // fewer is what lets the fused kernel run 8 wavefronts per SIMD
-    constexpr bool STASH = NS <= kK1QStashRegs;
+                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane) {
     constexpr int U = K1QCfg<NS>::U;
     // ---- prolongate: which (parent, dense tile, column) does each of this lane's candidates stand for
     const uint32_t gl = Ly.d_gp_log2, gmask = (1u << gl) - 1u, TT = Ly.d_max_tiles;
@@ -96,7 +92,6 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         ps[r] = pscore; valid[r] = v;
         // dense queries: bias FIRST (inference.hpp:824-830); bias_prod holds fl32(bias * w) or +0.0
         acc[r] = (DENSEX && Ly.has_bias) ? Ly.bias_prod[child[r]] : 0.0f;
-        if (STASH) stash[r * 64 + lane] = make_uint2(child[r], __float_as_uint(pscore));
     }
     wave_sync_lds();                                                   // the beam has been read: the arrays may be overwritten below
 
@@ -165,7 +160,6 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     uint32_t key[NS], sbits[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
-        if (STASH) { const uint2 st = stash[r * 64 + lane]; child[r] = st.x; ps[r] = __uint_as_float(st.y); }
         float s = acc[r];
         if (!DENSEX && Ly.has_bias) s = __fadd_rn(s, Ly.bias_prod[child[r]]);
         float v = pp_transform<PPC>(Ly.pp_kind, Ly.pp_p, s);
@@ -190,14 +184,12 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
 // no spills; the exp-family post-processors would spill and keep the default): measured 6.57 vs 6.73 ms on Amazon-670K's levels 0-3; 8 (64 VGPRs, 8 spilled) loses, and so does any target
 // on the wide single-layer kernels.
 template <int NSMAX, int PPC, bool DENSEX, bool MULTI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI && NSMAX <= 3 && PPC == 0) ? 8 : 1, 8))) k1q_kernel(K1QArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI && NSMAX <= 3 && PPC == 0) ? 7 : 1, 8))) k1q_kernel(K1QArgs a) {
     __shared__ uint2 sc_all[4 * 64];
     __shared__ uint32_t bidx_all[4 * 64];
     __shared__ float bval_all[4 * 64];
-    __shared__ uint2 stash_all[4 * 64 * kK1QStashRegs];
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar control flow below
-    uint2* stash = stash_all + wave * (64u * kK1QStashRegs);
     const uint32_t q = blockIdx.x * 4u + wave;
     if (q >= a.nrows) return;
     uint2* sc = sc_all + wave * 64u;
@@ -215,14 +207,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
-        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, stash, lane);
-        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, stash, lane);
-        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, stash, lane);
-        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, stash, lane);
-        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, stash, lane);
-        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, stash, lane);
-        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, stash, lane);
-        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, stash, lane);
+        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
     }
     if ((uint32_t)lane < cnt) {
         const size_t o = (size_t)q * a.out_stride + (uint32_t)lane;
