@@ -59,3 +59,33 @@ def test_sharded_predict_world2_gloo(tmp_path, oracle_mod):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")
+
+
+def test_packed_topk_uneven_and_empty_shards_two_parts():
+    # PackedTopk's cut / padding algebra without a process group: three ranks with uneven shards (one of them EMPTY), two parts
+    # per shard; every rank's send buffers are placed into rank 0's receive buffers by hand, unpack must return the rows in
+    # global order with labels, scores (bit patterns) and row lengths intact
+    import torch
+    from pecos_amd.distributed import PackedTopk
+    rng = np.random.default_rng(5)
+    k = 7
+    for sizes in ([5, 0, 9], [1, 1, 1], [0, 0, 4], [8, 3, 2]):
+        bounds = np.concatenate([[0], np.cumsum(sizes)])
+        n = int(bounds[-1])
+        idx = torch.from_numpy(rng.integers(0, 1 << 20, (n, k)).astype(np.int32))
+        val = torch.from_numpy(rng.standard_normal((n, k)).astype(np.float32))
+        val[0, 0] = float("-0.0")
+        cnt = torch.from_numpy(rng.integers(0, k + 1, n).astype(np.int32))
+        for parts in (1, 2):
+            pks = [PackedTopk(bounds, r, k, torch.device("cpu"), parts=parts) for r in range(3)]
+            for r, pk in enumerate(pks):
+                lo, hi = int(bounds[r]), int(bounds[r + 1])
+                assert [pk.rows(p) for p in range(parts)][0][0] == 0 and pk.rows(parts - 1)[1] == hi - lo
+                pk.store(idx[lo:hi], val[lo:hi], cnt[lo:hi])
+                for p in range(parts):
+                    pk.gather(p)                                   # no process group: folds cnt into the packed rows
+            for p in range(parts):
+                for r in range(3):
+                    pks[0].gathered[p][r].copy_(pks[r].buf[p])      # what the all-gather would deliver
+            gi, gv, gc = pks[0].unpack()
+            assert torch.equal(gi, idx) and torch.equal(gv.view(torch.int32), val.view(torch.int32)) and torch.equal(gc, cnt), (sizes, parts)
