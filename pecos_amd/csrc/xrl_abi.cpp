@@ -565,7 +565,7 @@ uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
         else if (!std::strcmp(attr, "nr_dense_layers")) {    // additive: layers that also carry the dense row format (K1Q)
             for (auto& l : m.layers) v += l->dev.wd ? 1u : 0u;
         }
-        else if (!std::strcmp(attr, "nr_k1t_layers")) {      // additive: layers that carry K1T tile images
+        else if (!std::strcmp(attr, "nr_k1r_layers")) {      // additive: layers that carry K1R tile images
             for (auto& l : m.layers) v += l->dev.img ? 1u : 0u;
         }
         else fail(std::string(attr) + " is not implemented in get_int_attr.");
@@ -882,6 +882,23 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
     return v;
 }
 
+uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, const uint32_t* rows, const uint32_t* rptr,
+                             const uint32_t* ent_col, const float* ent_val, uint64_t cap_bytes, uint32_t* image, uint64_t image_cap_words) {
+    uint64_t words = 0;
+    guarded([&] {
+        if (!rows || !rptr || !ent_col || !ent_val) fail("null argument");
+        uint32_t thr = 0;
+        words = k1r_image_words(rptr, nrows, ncols, w_rows, cap_bytes, &thr);
+        if (words == 0 || !image) return;
+        if (words > image_cap_words) fail("image buffer too small");
+        std::vector<Entry> ent(rptr[nrows]);
+        for (uint32_t e = 0; e < rptr[nrows]; ++e) ent[e] = Entry{ent_col[e], ent_val[e]};
+        std::memset(image, 0, words * 4);
+        if (!k1r_build_image(rows, rptr, ent.data(), nrows, ncols, w_rows, thr, words, image)) words = 0;
+    });
+    return words;
+}
+
 int xrl_set_option(void* model, const char* key, int64_t value) {
     int rc = -1;
     guarded([&] {
@@ -896,8 +913,8 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         else if (!std::strcmp(key, "dense_layers")) m.dense_layers = (int)value;   // 0: never run the fused dense-format kernel K1Q
         else if (!std::strcmp(key, "k2_legacy")) m.k2_legacy = (int)value;        // debug / A-B: round-1 insertion top-k
         else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
-        else if (!std::strcmp(key, "k1t_min_items")) m.k1t_min_items = (int)value;
-        else if (!std::strcmp(key, "k1t_items_per_block")) m.k1t_items_per_block = (int)value;
+        else if (!std::strcmp(key, "k1r_min_items")) m.k1r_min_items = (int)value;
+        else if (!std::strcmp(key, "k1r_split_items")) m.k1r_split_items = (int)value;
         else if (!std::strcmp(key, "k1g_variant")) m.k1g_variant = (int)value;   // K1G tile-shape alternative (tuning; results identical)
         else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
         else if (!std::strcmp(key, "k1_lds_pad")) m.k1_lds_pad = (int)value;   // debug: occupancy experiments

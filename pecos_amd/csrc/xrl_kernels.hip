@@ -5,7 +5,7 @@
 //   K1 k1_kernel       compute_sparse_predictions + chunk_ops + transform + combine
 //                                                           inference.hpp:925-1007, 769-839, 506-518,
 //                                                           1360-1384, PostProcessor :192-240
-//   K1T k1t_kernel     the same, tile-stationary: tile image held in LDS (optional, see below)
+//   K1R k1r_kernel     the same, tile-RESIDENT: tile image held in LDS, accumulators in registers (xrl_k1r.hip)
 //   K2 k2_topk_*       sorted_csr + reorder_prediction      inference.hpp:1223-1298, 1919-1923
 //   K3 k3_kernel       sparse_inner_products                matrix.hpp:1049-1060, 836-877
 //   K4 k4_selected     predict_on_selected_outputs (CSC)    inference.hpp:1018-1078, 1302-1358
@@ -34,6 +34,7 @@
 
 #include "xrl_device.h"
 #include "xrl_kernels.h"
+#include "xrl_items.h"
 
 namespace xrl {
 
@@ -44,15 +45,6 @@ namespace xrl {
 // ITEM DESCRIPTOR per (query, beam slot, tile-in-parent) so that K1 starts from a single coalesced
 // load instead of a chain of dependent lookups (beam -> parent -> tile range -> offsets).
 // ---------------------------------------------------------------------------------------------
-struct alignas(16) ItemDesc {   // 32 bytes; tile == kNoTile: inactive slot
-    uint32_t q, tile, out_off; float pscore;
-    uint64_t x_begin; uint32_t x_len, pad;   // CSR queries: the query row's range in col_idx / val (saves K1 a dependent lookup)
-};
-__host__ __device__ inline ItemDesc make_item(uint32_t q, uint32_t tile, uint32_t out_off, float ps, uint64_t xb, uint32_t xl) {
-    ItemDesc d; d.q = q; d.tile = tile; d.out_off = out_off; d.pscore = ps; d.x_begin = xb; d.x_len = xl; d.pad = 0u; return d;
-}
-constexpr uint32_t kNoTile = 0xFFFFFFFFu;
-
 __global__ void __launch_bounds__(256)
 k0_prolongate(const uint32_t* __restrict__ chunk_col, const uint32_t* __restrict__ ptile,
               const TileDesc* __restrict__ tiles, uint32_t nrows, uint32_t beam_in, uint32_t TT, uint32_t cand_stride,
@@ -618,316 +610,6 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     }
 #undef XRL_K1
 #undef XRL_K1_PP
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1T: tile-stationary K1 for sparse queries.  The items of a layer are tile-sorted (counting sort
-// above); a 16-wavefront workgroup takes a run of `ch` consecutive items, copies the run's tile
-// image (xrl_model.cpp: entries, row_ptr, row ids, bucket table, bias products) into LDS ONCE and
-// streams the run's items through it.  Everything K1 fetches per item from L2/HBM -- one bitmap
-// word per query feature, one row extent per hit, ~3 cache lines per row -- becomes LDS traffic;
-// per item only the descriptor, the query row and the output block touch global memory, and those
-// are prefetched one and two iterations ahead.
-//   lookup  feature id -> bucket (LDS) -> a few branch-free binary-search steps over the bucket's
-//           row ids (the reference's own lookup is a binary search, inference.hpp:786-803)
-//   rows    as in K1: the G lanes of an item take a row's entries G at a time (distinct columns),
-//           accumulators in LDS; lanes past the row's end are masked off
-// K1 and K1T are VALU-issue bound (SQ_ACTIVE_INST_VALU ~ 100 % of SIMD cycles), so this kernel is
-// written for instruction count: 32-bit relative indices, pre-scaled column offsets, queue entries
-// that carry the row extent, empty tail hits instead of bounds checks.
-// Arithmetic and its order are K1's: per column, fl32(acc + fl32(x*w)) over hits in feature order.
-// Used when a tile image fits in LDS and a tile serves enough items to pay for the copy.
-// ---------------------------------------------------------------------------------------------
-struct K1TArgs {
-    LayerDev L;
-    QueriesDev X;
-    const ItemDesc* items;       // tile-sorted, all active
-    const uint32_t* start;       // [n_tiles+1] first sorted item of every tile; start[n_tiles] = #items
-    float* cand;
-    uint32_t row0, ch, acc_stride;
-    uint32_t tile_cap;           // bytes of LDS reserved for the tile image
-    uint32_t scratch_per_wave;   // bytes of LDS per wavefront (hit queue + accumulators)
-    int pp_kind, pp_p, first_layer;
-    unsigned long long* phase;   // debug (k1_ablate bit 6): per-phase cycle totals
-};
-
-template <int G> struct K1TCfg {
-    static constexpr int W = 64 / G;                              // items per wavefront
-    static constexpr int U = (G >= 32) ? 3 : (G == 16 ? 4 : 8);   // query features per lane per step
-    static constexpr int H = 64;                                  // hit queue depth per item (>= G)
-    static constexpr int P = 4;                                   // hits per drain batch
-    static constexpr size_t scratch(uint32_t acc_stride) { return ((size_t)W * (H + P) * 8 + (size_t)W * acc_stride * 4 + 15) & ~(size_t)15; }
-};
-
-template <int G, int NS, int PPC>
-__global__ void __launch_bounds__(1024) k1t_kernel(K1TArgs a) {
-    constexpr int W = K1TCfg<G>::W, U = K1TCfg<G>::U, H = K1TCfg<G>::H, P = K1TCfg<G>::P;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
-    const uint32_t n = a.start[a.L.n_tiles];
-    const uint32_t b0 = blockIdx.x * a.ch;
-    if (b0 >= n) return;
-    const uint32_t b1 = min(n, b0 + a.ch);
-    const uint32_t nthreads = blockDim.x, nw = blockDim.x >> 6;
-    const uint32_t wave = threadIdx.x >> 6;
-    const int lane = threadIdx.x & 63, grp = lane / G, lig = lane % G;
-    unsigned char* sw = smem_all + a.tile_cap + (size_t)wave * a.scratch_per_wave;
-    uint2* __restrict__ my_hq = reinterpret_cast<uint2*>(sw) + (size_t)grp * (H + P);
-    unsigned char* __restrict__ my_acc = sw + (size_t)W * (H + P) * 8 + (size_t)grp * a.acc_stride * 4;   // byte-addressed floats
-    const unsigned long long below = (1ull << lig) - 1ull;
-    const uint32_t* __restrict__ xi = a.X.col_idx;
-    const float* __restrict__ xv = a.X.val;
-    const uint32_t stride = nw * W;                                    // items between a wavefront's iterations
-    const uint32_t NBK = a.L.img_nbk, shift = a.L.img_shift, bkw = a.L.img_mw, w_rows = a.L.w_rows;
-#ifdef XRL_K1_PHASE_PROF   // debug build only: cycles per phase [tile copy, prefetch, fill, drain, epilogue, wave-iterations]
-    const bool prof = a.phase != nullptr;
-    unsigned long long t_last = prof ? __builtin_readcyclecounter() : 0ull, t_ph[5] = {0, 0, 0, 0, 0}, n_it = 0;
-    auto tick = [&](int ph) { if (prof) { const unsigned long long t = __builtin_readcyclecounter(); t_ph[ph] += t - t_last; t_last = t; } };
-#else
-    auto tick = [](int) {};
-#endif
-
-    // one step's query features of one item group (U slices of G features), kept in registers
-    struct XStep { uint32_t f[U]; float v[U]; };
-    auto load_desc = [&](uint32_t i, uint32_t seg_end) {
-        ItemDesc d = make_item(0u, kNoTile, 0u, 0.f, 0, 0u);
-        if (i + grp < seg_end) d = a.items[i + grp];
-        return d;
-    };
-    auto load_x = [&](const ItemDesc& d, uint32_t rel0, XStep& xs) {   // unconditional, clamped loads; rel0 = features already consumed
-        const uint32_t last = d.x_len ? d.x_len - 1u : 0u;
-        const uint32_t* __restrict__ pi = xi + d.x_begin;
-        const float* __restrict__ pv = xv + d.x_begin;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t rel = rel0 + (uint32_t)(u * G + lig);
-            const uint32_t idx = min(rel, last);
-            const uint32_t fi = pi[idx];
-            xs.v[u] = pv[idx];
-            xs.f[u] = (rel < d.x_len && fi < w_rows) ? fi : 0xFFFFFFFFu;
-        }
-    };
-
-    uint32_t pos = b0;
-    while (pos < b1) {
-        // ---- the run's next tile image -> LDS
-        const uint32_t t = __builtin_amdgcn_readfirstlane(a.items[pos].tile);
-        const uint32_t seg_end = __builtin_amdgcn_readfirstlane(min(b1, a.start[t + 1]));
-        const uint32_t* __restrict__ g_img = a.L.img + a.L.img_off[t];
-        const uint32_t n_words = (uint32_t)(a.L.img_off[t + 1] - a.L.img_off[t]);
-        const uint32_t E = __builtin_amdgcn_readfirstlane(g_img[0]), R = __builtin_amdgcn_readfirstlane(g_img[1]);
-        const uint32_t ncols = __builtin_amdgcn_readfirstlane(g_img[2]), levels = __builtin_amdgcn_readfirstlane(g_img[3]);
-        const uint32_t* __restrict__ t_img = reinterpret_cast<const uint32_t*>(smem_all);
-        const uint2* __restrict__ t_ent = reinterpret_cast<const uint2*>(t_img + 4);       // {column * 4, value bits}
-        const uint32_t* __restrict__ t_rp = t_img + 4 + 2 * (size_t)E;
-        const uint32_t* __restrict__ t_ridx = t_rp + (R + 1);
-        const uint16_t* __restrict__ t_bk = reinterpret_cast<const uint16_t*>(t_ridx + R);
-        const float* __restrict__ t_bias = reinterpret_cast<const float*>(t_ridx + R + bkw);
-        // software pipeline, stage 1 of the first two iterations: descriptors (in flight during the tile copy)
-        uint32_t i0 = pos + wave * W;
-        ItemDesc it = load_desc(i0, seg_end);
-        ItemDesc it_n = load_desc(i0 + stride, seg_end);
-        __syncthreads();                                               // the previous tile's readers are done
-        {
-            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(g_img);   // images are 16-byte aligned and padded
-            uint4* dst = reinterpret_cast<uint4*>(smem_all);
-            const uint32_t nq = n_words >> 2;
-            uint32_t i = threadIdx.x;
-            for (; i + 3 * nthreads < nq; i += 4 * nthreads) {         // four loads in flight per thread
-                const uint4 q0 = src[i], q1 = src[i + nthreads], q2 = src[i + 2 * nthreads], q3 = src[i + 3 * nthreads];
-                dst[i] = q0; dst[i + nthreads] = q1; dst[i + 2 * nthreads] = q2; dst[i + 3 * nthreads] = q3;
-            }
-            for (; i < nq; i += nthreads) dst[i] = src[i];
-        }
-        XStep xs;
-        load_x(it, 0u, xs);                                            // stage 2 of the first iteration
-        __syncthreads();
-        tick(0);
-
-        for (; i0 < seg_end; i0 += stride) {
-            // ---- prefetch: query features of the next iteration, descriptors of the one after
-            XStep xs_n;
-            load_x(it_n, 0u, xs_n);
-            const ItemDesc it_nn = load_desc(i0 + 2 * stride, seg_end);
-
-            const bool active = it.tile != kNoTile;
-            const uint32_t x_len = it.x_len;
-            uint32_t cur = 0;                                          // query features consumed
-            for (uint32_t c = lig; c < ncols; c += G) reinterpret_cast<float*>(my_acc)[c] = 0.0f;   // std::fill(..., 0.0), inference.hpp:964
-            uint32_t nh = 0;
-            wave_sync_lds();
-            tick(1);
-
-            // ---- drain: hits {x value, row start | row length << 16} in feature order, P per batch (descriptors and
-            //      first-unit entries of the batch are read together).  The queue is closed with empty hits up to the
-            //      longest queue of the wavefront, so the loop carries no bounds checks; lanes past a row's end are
-            //      masked off.
-            auto drain = [&]() {
-                uint32_t nh_max = nh;
-#pragma unroll
-                for (int d = G; d < 64; d <<= 1) nh_max = max(nh_max, (uint32_t)__shfl_xor((int)nh_max, d, 64));
-                nh_max = __builtin_amdgcn_readfirstlane(nh_max);
-                for (uint32_t j = nh + lig; j < nh_max + (uint32_t)P; j += G) my_hq[j] = make_uint2(0u, 0u);
-                wave_sync_lds();
-                tick(2);
-                const uint2* __restrict__ hq = my_hq;
-                for (uint32_t h0 = 0; h0 < nh_max; h0 += P, hq += P) {
-                    uint2 hv[P], e[P];
-#pragma unroll
-                    for (int p = 0; p < P; ++p) hv[p] = hq[p];
-#pragma unroll
-                    for (int p = 0; p < P; ++p) e[p] = t_ent[(hv[p].y & 0xFFFFu) + (uint32_t)lig];
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        const float v = __uint_as_float(hv[p].x);
-                        const uint32_t len = hv[p].y >> 16;
-                        if ((uint32_t)lig < len) {
-                            float* q = reinterpret_cast<float*>(my_acc + e[p].x);
-                            *q = __fadd_rn(*q, __fmul_rn(v, __uint_as_float(e[p].y)));   // scalar * val, then add: no fma (inference.hpp:512-517)
-                        }
-#pragma unroll
-                        for (int k = 1; k < NS; ++k) {
-                            if (__any(len > (uint32_t)(k * G))) {
-                                const uint2 e2 = t_ent[(hv[p].y & 0xFFFFu) + (uint32_t)(k * G + lig)];
-                                if ((uint32_t)(k * G + lig) < len) {
-                                    float* q = reinterpret_cast<float*>(my_acc + e2.x);
-                                    *q = __fadd_rn(*q, __fmul_rn(v, __uint_as_float(e2.y)));
-                                }
-                            }
-                        }
-                        wave_sync_lds();
-                    }
-                }
-                nh = 0;
-                tick(3);
-            };
-
-            uint32_t skip = 0;                 // u-slices of the current step already queued (after an overflow)
-            bool first = true;
-            while (__any(cur < x_len)) {
-                bool overflow = false;
-                {
-                    XStep st = xs;
-                    if (!first) load_x(it, cur, st);
-                    // bucket, then `levels` branch-free binary-search steps: pr = last row of the bucket with id <= f
-                    uint32_t pr[U], hi[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const uint32_t bq = min(st.f[u] >> shift, NBK - 1u);
-                        pr[u] = t_bk[bq]; hi[u] = t_bk[bq + 1];
-                    }
-                    for (uint32_t lv = levels; lv > 0; --lv) {
-                        const uint32_t stp = 1u << (lv - 1);
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const uint32_t np = pr[u] + stp;
-                            const bool in = np < hi[u];
-                            const uint32_t r = t_ridx[in ? np : pr[u]];
-                            pr[u] = (in && r <= st.f[u]) ? np : pr[u];
-                        }
-                    }
-                    bool hit[U]; uint32_t ext[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        hit[u] = pr[u] < hi[u] && t_ridx[pr[u]] == st.f[u];
-                        const uint32_t rs = t_rp[pr[u]], re = t_rp[pr[u] + 1];   // pr <= R: inside the image
-                        ext[u] = rs | ((re - rs) << 16);               // row start < 2^16 (the image fits in LDS), length <= 128
-                    }
-                    uint32_t done = skip;
-                    bool stopped = false;
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const unsigned long long mm = __ballot(hit[u]);
-                        const unsigned long long gm = (G == 64) ? mm : ((mm >> (grp * G)) & ((1ull << G) - 1ull));
-                        const uint32_t cnt = (uint32_t)__popcll(gm);
-                        if ((uint32_t)u >= done && !stopped) {
-                            if (nh + cnt <= (uint32_t)H) {
-                                if (hit[u]) my_hq[nh + (uint32_t)__popcll(gm & below)] = make_uint2(__float_as_uint(st.v[u]), ext[u]);
-                                nh += cnt; done = u + 1;
-                            } else {
-                                stopped = true;
-                            }
-                        }
-                    }
-                    if (done == (uint32_t)U) { if (cur < x_len) cur += (uint32_t)(U * G); skip = 0; first = false; }
-                    else { skip = done; overflow = true; }
-                }
-                if (__any(overflow)) drain();
-            }
-            drain();
-            // bias LAST (inference.hpp:806-811), transform, combine, write the child block
-            if (active) {
-                float* __restrict__ out = a.cand + it.out_off;
-                for (uint32_t c = lig; c < ncols; c += G) {
-                    float s = reinterpret_cast<const float*>(my_acc)[c];
-                    if (a.L.has_bias) s = __fadd_rn(s, t_bias[c]);
-                    float vv = pp_transform<PPC>(a.pp_kind, a.pp_p, s);
-                    if (!a.first_layer) vv = pp_combine(a.pp_kind, vv, it.pscore);
-                    out[c] = vv;
-                }
-            }
-            wave_sync_lds();
-            it = it_n; it_n = it_nn; xs = xs_n;
-            tick(4);
-#ifdef XRL_K1_PHASE_PROF
-            ++n_it;
-#endif
-        }
-        pos = seg_end;
-    }
-#ifdef XRL_K1_PHASE_PROF
-    if (prof && lane == 0) { for (int i = 0; i < 5; ++i) atomicAdd(&a.phase[i], t_ph[i]); atomicAdd(&a.phase[5], n_it); }
-#endif
-}
-
-static size_t k1t_tile_cap(const LayerDev& L) { return ((size_t)L.max_tile_img + 15) & ~(size_t)15; }
-
-int k1t_group(const LayerDev& L) { return L.max_tile_cols <= 8 ? 8 : (L.max_tile_cols <= 16 ? 16 : 32); }
-
-static size_t k1t_scratch(const LayerDev& L) {
-    const int g = k1t_group(L);
-    const uint32_t as = L.max_tile_cols | 1u;
-    return g == 8 ? K1TCfg<8>::scratch(as) : g == 16 ? K1TCfg<16>::scratch(as) : K1TCfg<32>::scratch(as);
-}
-
-// waves per workgroup K1T would run with on this layer, or 0 if the layer has no tile images
-int k1t_waves(const LayerDev& L) {
-    if (!L.img || L.max_tile_cols > 128) return 0;
-    for (int nw = 16; nw >= 8; nw -= 4)
-        if (k1t_tile_cap(L) + (size_t)nw * k1t_scratch(L) <= 160 * 1024) return nw;
-    return 0;
-}
-
-void launch_k1t(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
-                float* cand, uint32_t items_per_block, hipStream_t s) {
-    if (P.nrows == 0) return;
-    const int nw = k1t_waves(L);
-    if (nw == 0 || X.dense) fail("k1t: layer not eligible");
-    K1TArgs a;
-    a.L = L; a.X = X; a.items = static_cast<const ItemDesc*>(items_sorted); a.start = start; a.cand = cand;
-    a.row0 = P.row0; a.ch = items_per_block; a.acc_stride = L.max_tile_cols | 1u;
-    a.tile_cap = (uint32_t)k1t_tile_cap(L);
-    a.scratch_per_wave = (uint32_t)k1t_scratch(L);
-    a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
-    a.phase = ((P.tune.ablate & 64) && ((P.tune.ablate >> 8) == 0 || (P.tune.ablate >> 8) == P.layer + 1)) ? k1_phase_buffer() : nullptr;
-    const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
-    const uint64_t blocks = (n_slots + items_per_block - 1) / items_per_block;
-    if (blocks > 0x7FFFFFFFull) fail("k1t: grid too large; lower max_batch_rows");
-    const int ppc = pp_class(P.pp);
-    const size_t lds = (size_t)a.tile_cap + (size_t)nw * a.scratch_per_wave;
-#define XRL_K1T(GG, NN) do { \
-        auto kern = ppc ? &k1t_kernel<GG, NN, 1> : &k1t_kernel<GG, NN, 0>; \
-        XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(64 * nw), lds, s, a); } while (0)
-    const int g = k1t_group(L);
-    const uint32_t ns = (L.max_tile_cols + (uint32_t)g - 1) / (uint32_t)g;
-    if (g == 8) XRL_K1T(8, 1);
-    else if (g == 16) XRL_K1T(16, 1);
-    else if (ns <= 1) XRL_K1T(32, 1);
-    else if (ns == 2) XRL_K1T(32, 2);
-    else if (ns == 3) XRL_K1T(32, 3);
-    else XRL_K1T(32, 4);
-#undef XRL_K1T
-    XRL_LAUNCH_CHECK();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -132,9 +132,78 @@ uint64_t layout_tile_rows(const uint32_t* rptr, uint32_t nrows, bool align, uint
     return (cur + 15) & ~15ull;
 }
 
-static bool k1t_images_enabled() {
-    const char* e = std::getenv("XRL_K1T");
-    return e && e[0] && e[0] != '0';
+// ---- tile images of the tile-RESIDENT kernel K1R (xrl_k1r.hip): one self-contained blob per tile, copied verbatim into LDS
+//      by the workgroup that owns the tile.  Row lookup = a rank-bitmap over the feature ids (one LDS read per probe); rows
+//      longer than a per-tile threshold T are held DENSE (ncols + 1 words: the weight bits, kMissing where the row has no
+//      entry -- lane == column, accumulators in registers), shorter ones as {column, value} pairs.  T is the smallest value
+//      in [2, kK1RMaxShort] for which the image fits `cap_bytes`.  Layout (u32 words):
+//        [0] words  [1] R  [2] ncols  [3] off_rank  [4] off_rowdesc  [5] off_bias  [6] nw64  [7] T
+//        bits u64[nw64] | rank u16[nw64] | rowdesc u32[R] | bias f32[ncols] | pairs (8-byte aligned) | dense rows
+//        rowdesc: dense  0x80000000 | word offset of the row's ncols + 1 words
+//                 short  word offset of the row's first pair | (len - 1) << 24
+// k1r_image_words: size of the image in words (a multiple of 4) and T, or 0 when no T fits.
+uint64_t k1r_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t cap_bytes, uint32_t* thr_out) {
+    if (R >= 65536 || ncols > kMaxTileCols) return 0;
+    const uint64_t nw64 = ((uint64_t)w_rows + 63) / 64;
+    uint64_t n_len[kMaxTileCols + 2] = {0};                               // rows by length
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t len = rptr[r + 1] - rptr[r];
+        if (len == 0 || len > kMaxTileCols) return 0;
+        n_len[len] += 1;
+    }
+    const uint64_t fixed = 8 + 2 * nw64 + (nw64 + 1) / 2 + R + ncols + 1;   // + alignment of the pairs
+    for (uint32_t thr = 2; thr <= kK1RMaxShort; ++thr) {
+        uint64_t dense_rows = 0, short_ent = 0;
+        for (uint32_t len = 1; len <= kMaxTileCols; ++len) { if (len <= thr) short_ent += n_len[len] * len; else dense_rows += n_len[len]; }
+        const uint64_t w = (fixed + dense_rows * (ncols + 1ull) + 2 * short_ent + 3) & ~3ull;
+        if (w * 4 <= cap_bytes && w < (1ull << 24)) { if (thr_out) *thr_out = thr; return w; }
+    }
+    return 0;
+}
+
+// writes the image (words[0..words) zero-initialised by the caller; the bias words are filled in later); false when a
+// (feature, column) pair is stored twice in a row held dense (one cell cannot hold both: the layer then stays on K1)
+bool k1r_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* ent, uint32_t R, uint32_t ncols, uint32_t w_rows,
+                     uint32_t thr, uint64_t words, uint32_t* b) {
+    const uint32_t nw64 = (uint32_t)(((uint64_t)w_rows + 63) / 64);
+    const uint32_t off_bits = 8, off_rank = off_bits + 2 * nw64, off_desc = off_rank + (nw64 + 1) / 2, off_bias = off_desc + R;
+    uint32_t cur = (off_bias + ncols + 1u) & ~1u;                          // {column, value} pairs are read as 8-byte words
+    b[0] = (uint32_t)words; b[1] = R; b[2] = ncols; b[3] = off_rank; b[4] = off_desc; b[5] = off_bias; b[6] = nw64; b[7] = thr;
+    uint16_t* rank = reinterpret_cast<uint16_t*>(b + off_rank);
+    bool ok = true;
+    for (uint32_t r = 0; r < R; ++r) {                                     // rows kept in entry form first, dense rows after them
+        const uint32_t f = rows[r];
+        if (f >= w_rows) fail("layer: W row index out of range");
+        b[off_bits + 2 * (f >> 6) + ((f >> 5) & 1u)] |= 1u << (f & 31u);
+        const uint32_t len = rptr[r + 1] - rptr[r];
+        if (len > thr) continue;
+        b[off_desc + r] = cur | ((len - 1u) << 24);
+        for (uint32_t e = rptr[r]; e < rptr[r + 1]; ++e) { b[cur] = ent[e].col; std::memcpy(&b[cur + 1], &ent[e].val, 4); cur += 2; }
+    }
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t len = rptr[r + 1] - rptr[r];
+        if (len <= thr) continue;
+        b[off_desc + r] = 0x80000000u | cur;
+        for (uint32_t c = 0; c <= ncols; ++c) b[cur + c] = kMissing;
+        for (uint32_t e = rptr[r]; e < rptr[r + 1]; ++e) {
+            if (ent[e].col >= ncols) fail("layer: internal error, K1R column out of range");
+            if (b[cur + ent[e].col] != kMissing) ok = false;
+            std::memcpy(&b[cur + ent[e].col], &ent[e].val, 4);
+        }
+        cur += ncols + 1;
+    }
+    uint32_t run = 0;
+    for (uint32_t w = 0; w < nw64; ++w) {
+        rank[w] = (uint16_t)run;
+        run += (uint32_t)__builtin_popcount(b[off_bits + 2 * w]) + (uint32_t)__builtin_popcount(b[off_bits + 2 * w + 1]);
+    }
+    if (cur > words) fail("layer: internal error, K1R tile image overflow");
+    return ok;
+}
+
+static bool k1r_images_enabled() {   // XRL_K1R=0: do not build the tile images of the tile-resident kernel (saves about the entries' size in HBM)
+    const char* e = std::getenv("XRL_K1R");
+    return !(e && e[0] == '0');
 }
 
 std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, float bias, uint32_t only_topk,
@@ -329,49 +398,33 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
         L->bk_shift = shift; L->bk_n = NBK; L->bk_levels = levels;
     }
 
-    // ---- tile images for the tile-stationary kernel K1T: one self-contained blob per tile, copied verbatim into
-    //      LDS.  The row lookup is a bucket table over feature-id ranges followed by a few binary-search steps.
-    //      words: [E, R, ncols, levels] entries[E]{col*4, val} rp[R+1] ridx[R] bucket[NBK+1] (u16) bias[ncols] pad-to-4
+    // ---- tile images for the tile-RESIDENT kernel K1R (k1r_image_words / k1r_build_image above): built when EVERY tile fits
     std::vector<uint32_t> img; std::vector<uint64_t> img_off;
-    {
-        uint32_t shift = 0;
-        while ((((uint64_t)W.rows - 1) >> shift) + 1 > 4096) ++shift;
-        const uint32_t NBK = W.rows ? (uint32_t)((((uint64_t)W.rows - 1) >> shift) + 1) : 1;
-        const uint64_t bkw = (NBK + 1 + 1) / 2;   // u16 bucket table, in words
-        auto words_of = [&](uint64_t E, uint64_t R, uint64_t nc) { return (4 + 2 * E + (R + 1) + R + bkw + nc + 3) & ~3ull; };
-        uint64_t max_words = 0, total = 0; uint32_t max_rows = 0;
-        for (uint32_t t = 0; t < T; ++t) {
-            const uint64_t w = words_of(tile_nnz[t], tiles[t].nrows, tiles[t].ncols);
-            max_words = std::max(max_words, w); total += w; max_rows = std::max(max_rows, tiles[t].nrows);
+    if (k1r_images_enabled() && T > 0 && !structure_only && L->max_tile_cols <= kMaxTileCols) {
+        std::vector<uint32_t> t_thr(T, 0);
+        std::vector<uint64_t> t_words(T, 0);
+        std::atomic<bool> all_fit{true};
+        parallel_for(T, [&](size_t t) {
+            t_words[t] = k1r_image_words(t_rptr[t].data(), tiles[t].nrows, tiles[t].ncols, W.rows, kMaxTileImageBytes, &t_thr[t]);
+            if (t_words[t] == 0) all_fit = false;
+        });
+        if (all_fit) {   // the images cost about as much HBM as the entries themselves: never more than a quarter of what is free
+            uint64_t tot = 0; for (uint32_t t = 0; t < T; ++t) tot += t_words[t];
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && tot * 4 > free_b / 4) all_fit = false;
         }
-        L->max_tile_img = max_words * 4;
-        // the images cost about as much HBM as the entries themselves: built only when K1T is asked for (XRL_K1T=1)
-        if (k1t_images_enabled() && T > 0 && max_words * 4 <= kMaxTileImageBytes && max_rows < 65536) {
-            img.assign(total, 0u); img_off.assign((size_t)T + 1, 0);
-            for (uint32_t t = 0; t < T; ++t) img_off[t + 1] = img_off[t] + words_of(tile_nnz[t], tiles[t].nrows, tiles[t].ncols);
+        if (all_fit) {
+            img_off.assign((size_t)T + 1, 0);
+            uint64_t max_words = 0; uint32_t max_thr = 0;
+            for (uint32_t t = 0; t < T; ++t) { img_off[t + 1] = img_off[t] + t_words[t]; max_words = std::max(max_words, t_words[t]); max_thr = std::max(max_thr, t_thr[t]); }
+            img.assign(img_off[T] + 4, 0u);
             parallel_for(T, [&](size_t t) {
-                const TileDesc& td = tiles[t];
-                const uint32_t E = (uint32_t)tile_nnz[t], R = td.nrows;
-                uint32_t* b = img.data() + img_off[t];
-                uint32_t* ents = b + 4; uint32_t* rp = ents + 2 * (size_t)E;
-                uint32_t* ridx = rp + (R + 1); uint16_t* bk = reinterpret_cast<uint16_t*>(ridx + R);
-                const Entry* ent = entries.data() + td.ent_base;
-                for (uint32_t e = 0; e < E; ++e) { ents[2 * e] = ent[e].col * 4u; std::memcpy(&ents[2 * e + 1], &ent[e].val, 4); }
-                std::memcpy(rp, t_rptr[t].data(), ((size_t)R + 1) * 4);
-                if (R) std::memcpy(ridx, t_rows[t].data(), (size_t)R * 4);
-                uint32_t maxlen = 0, r0 = 0;
-                for (uint32_t k = 0; k < NBK; ++k) {
-                    while (r0 < R && (ridx[r0] >> shift) < k) ++r0;
-                    bk[k] = (uint16_t)r0;
-                    if (k > 0) maxlen = std::max<uint32_t>(maxlen, bk[k] - bk[k - 1]);
-                }
-                bk[NBK] = (uint16_t)R;
-                maxlen = std::max<uint32_t>(maxlen, R - bk[NBK - 1]);
-                uint32_t levels = 0;
-                while ((1u << levels) < maxlen) ++levels;      // search steps of 2^(levels-1) .. 1 cover maxlen rows
-                b[0] = E; b[1] = R; b[2] = td.ncols; b[3] = levels;
+                if (!k1r_build_image(t_rows[t].data(), t_rptr[t].data(), entries.data() + tiles[t].ent_base, tiles[t].nrows, tiles[t].ncols, W.rows,
+                                     t_thr[t], t_words[t], img.data() + img_off[t])) all_fit = false;
             });
-            L->img_mw = (uint32_t)bkw; L->img_shift = shift; L->img_nbk = NBK;
+            L->max_tile_img = max_words * 4;
+            L->img_max_short = max_thr;
+            if (!all_fit) { img.clear(); img_off.clear(); L->max_tile_img = 0; L->img_max_short = 0; }
         }
     }
 
@@ -405,9 +458,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     }
     if (!img.empty()) {
         for (uint32_t t = 0; t < T; ++t) {
-            const uint32_t E = (uint32_t)tile_nnz[t], R = tiles[t].nrows;
-            uint32_t* bias_w = img.data() + img_off[t] + 4 + 2 * (size_t)E + (R + 1) + R + L->img_mw;
-            std::memcpy(bias_w, bias_prod.data() + tiles[t].col_begin, (size_t)tiles[t].ncols * 4);
+            uint32_t* b = img.data() + img_off[t];
+            std::memcpy(b + b[5], bias_prod.data() + tiles[t].col_begin, (size_t)tiles[t].ncols * 4);
         }
         L->d_img.upload(img); L->d_img_off.upload(img_off);
     }
@@ -567,7 +619,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     d.max_tiles_per_parent = L->max_tiles_per_parent; d.max_tile_cols = L->max_tile_cols;
     d.max_tile_img = (uint32_t)std::min<uint64_t>(L->max_tile_img, 0xFFFFFFFFull);
     d.img = img.empty() ? nullptr : L->d_img.as<uint32_t>(); d.img_off = img.empty() ? nullptr : L->d_img_off.as<uint64_t>();
-    d.img_mw = L->img_mw; d.img_shift = L->img_shift; d.img_nbk = L->img_nbk;
+    d.img_max_short = L->img_max_short;
     d.bias = bias; d.has_bias = has_bias ? 1 : 0;
     d.wd = L->dense_bytes ? L->d_wd.as<uint32_t>() : nullptr; d.d_ld = d_ld; d.d_gp_log2 = d_gp_log2; d.d_max_tiles = d_max_tiles;
     d.d_ptile = L->dense_bytes ? L->d_dptile.as<uint32_t>() : nullptr; d.d_tcol = L->dense_bytes ? L->d_dtcol.as<uint32_t>() : nullptr;

@@ -30,7 +30,8 @@ namespace xrl {
 constexpr uint32_t kMaxTileCols = 128;       // accumulators per (query, tile) item held in LDS
 constexpr uint32_t kNoBias = 0xFFFFFFFFu;
 constexpr uint32_t kMissing = 0x7FA5A5A5u;   // dense row format: "W has no entry here" (a signalling-NaN pattern no weight file holds)
-constexpr uint64_t kMaxTileImageBytes = 136 * 1024;   // K1T: largest tile image kept in LDS (160 KiB minus wavefront scratch)
+constexpr uint64_t kMaxTileImageBytes = 152 * 1024;   // K1R: largest tile image kept in LDS (160 KiB minus the kernel's static LDS and a margin)
+constexpr uint32_t kK1RMaxShort = 8;                  // K1R: rows of up to this many entries may stay in entry form (longer rows are held dense)
 
 enum PPKind : int { PP_NOOP = 0, PP_SIGMOID = 1, PP_LOG_SIGMOID = 2, PP_LP_HINGE = 3, PP_LOG_LP_HINGE = 4 };
 struct PostProc { int kind = PP_NOOP; int p = 0; };
@@ -69,10 +70,10 @@ struct LayerDev {
     const float* bias_prod;      // [n_children] fl32(bias * W[bias_row, child]) or +0.0 (no explicit entry / no bias)
     uint32_t n_parents, n_children, n_tiles, nwords, w_rows;
     uint32_t max_tiles_per_parent, max_tile_cols;
-    uint32_t max_tile_img;       // bytes of the largest K1T tile image
-    const uint32_t* img;         // K1T tile images (nullptr: a tile does not fit in LDS), image t at img + img_off[t] (u32 words)
+    uint32_t max_tile_img;       // bytes of the largest K1R tile image
+    const uint32_t* img;         // K1R tile images (nullptr: some tile does not fit in LDS), image t at img + img_off[t] (u32 words); layout: xrl_k1r.h
     const uint64_t* img_off;
-    uint32_t img_mw, img_shift, img_nbk;   // words of the (u16) bucket table, feature-id shift, number of buckets
+    uint32_t img_max_short;      // longest row kept in entry form by any tile of the layer (<= kK1RMaxShort)
     float bias;
     int has_bias;
     // DENSE row format (K1Q, xrl_k1q.hip), nullptr when the layer is held in the tile format only:
@@ -103,7 +104,7 @@ struct Layer {
     uint32_t n_children = 0;               // nnz(C)
     uint32_t n_tiles = 0, nwords = 0, max_tiles_per_parent = 0, max_tile_cols = 0, max_chunk_cols = 0;
     uint64_t max_tile_img = 0;
-    uint32_t img_mw = 0, img_shift = 0, img_nbk = 0;
+    uint32_t img_max_short = 0;
     uint64_t nnz = 0, total_rows = 0;
     std::vector<uint32_t> chunk_sizes_desc;  // chunk sizes sorted descending (cand stride bound)
     // predict_on_selected_outputs (inference.hpp:2507-2571): host copy of C's pattern, child -> parent,
@@ -166,8 +167,9 @@ struct Model {
     int64_t max_batch_rows = 0;             // 0 = auto
     int overlap_min_rows = 0;               // split a predict of at least this many rows into two half batches on two streams so that one half's
                                             // K0/K2 run under the other half's K1; 0 = never (measured on Amazon-670K: 25.9 vs 25.5 ms, no gain)
-    int k1t_min_items = 0;                  // run a layer tile-stationary (K1T) once a tile serves at least this many items on average (0 = never)
-    int k1t_items_per_block = 1024;
+    int k1r_min_items = 128;                // sparse X: run a tile-format layer tile-RESIDENT (K1R: tile-sorted items, the tile's image in LDS) once a tile serves
+                                            // at least this many items on average (0 = never)
+    int k1r_split_items = 4096;             // K1R: a tile's items are shared by ceil(average items per tile / this) workgroups
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
     int k1q_fuse = 3;                       // consecutive dense-format layers of <= this many candidate registers (1..3) share one K1Q launch (the beam stays in LDS); 0: one launch per layer
@@ -185,6 +187,9 @@ struct Model {
 // host-only pieces of the model compiler (also exported for tests: xrl_debug_split_chunk / xrl_debug_layout_rows)
 uint32_t split_chunk(const uint64_t* cum, uint32_t n, uint64_t limit);
 uint64_t layout_tile_rows(const uint32_t* rptr, uint32_t nrows, bool align, uint32_t* ext);
+uint64_t k1r_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t cap_bytes, uint32_t* thr_out);
+bool k1r_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* ent, uint32_t R, uint32_t ncols, uint32_t w_rows,
+                     uint32_t thr, uint64_t words, uint32_t* image);
 
 // Build one layer from host CSC W / C (LayerData<chunked>::init, inference.hpp:1849-1883).
 // perm_inv_override / orig_rows: W and C are already in the rearranged (contiguous) child order and the

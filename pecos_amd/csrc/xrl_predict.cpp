@@ -90,8 +90,8 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     uint64_t slots_max = 1;
     for (size_t l = 0; l < T; ++l) slots_max = std::max<uint64_t>(slots_max, nb * beam_in[l] * m.layers[l]->max_tiles_per_parent);
     for (int ln = 0; ln < lanes; ++ln) ws.lane[ln].items.reserve(slots_max * k0_item_bytes());
-    // per layer: 0 = K1 on the items in natural order, 1 = K1 on tile-sorted items, 2 = K1T (tile-stationary:
-    // tile-sorted items, tile image in LDS) -- chosen when a tile image fits and a tile serves enough items
+    // per layer: 0 = K1 on the items in natural order, 1 = K1 on tile-sorted items, 2 = K1R (tile-resident:
+    // tile-sorted items, tile image in LDS) -- chosen when every tile image fits and a tile serves enough items
     auto layer_mode = [&](size_t l, uint64_t rows) -> int {
         const Layer& L = *m.layers[l];
         if (L.n_tiles > sort_max_tiles()) return 0;
@@ -99,7 +99,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         // 3 = K1G: dense queries against a dense-format layer as a tiled SGEMM over tile-sorted items
         if (X.dense && m.dense_layers && m.k1g_min_items > 0 && !csc && k1g_cols(L.dev) != 0 && k[l] <= k2_max_k() &&
             slots / std::max<uint32_t>(1, L.n_tiles) >= (uint64_t)m.k1g_min_items) return 3;
-        if (!X.dense && m.k1t_min_items > 0 && k1t_waves(L.dev) > 0 && slots / L.n_tiles >= (uint64_t)m.k1t_min_items) return 2;
+        if (!X.dense && X.nnz > 0 && m.k1r_min_items > 0 && k1r_eligible(L.dev) && slots / L.n_tiles >= (uint64_t)m.k1r_min_items) return 2;
         if (m.sort_min_tiles > 0 && L.n_tiles >= (uint32_t)m.sort_min_tiles) return 1;
         return 0;
     };
@@ -228,8 +228,12 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             const uint64_t n_slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
             if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
             if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));   // K1 launches take turns across the lanes
-            if (mode == 2)
-                timed("k1t_sparse", (uint32_t)l, [&] { launch_k1t(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.cand.as<float>(), (uint32_t)std::max(64, m.k1t_items_per_block), S); });
+            if (mode == 2) {
+                // a tile's items are shared by several workgroups once a tile serves many more items than one workgroup should walk
+                const uint64_t per_tile = n_slots / std::max<uint32_t>(1, L.n_tiles);
+                const uint32_t splits = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (per_tile + (uint64_t)std::max(1, m.k1r_split_items) - 1) / (uint64_t)std::max(1, m.k1r_split_items)));
+                timed("k1r_sparse", (uint32_t)l, [&] { launch_k1r(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.cand.as<float>(), splits, S); });
+            }
             else
                 timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] {
                     launch_k1(L.dev, P, X, mode == 1 ? lw.items_sorted.p : lw.items.p, mode == 1 ? lw.sort_start.as<uint32_t>() + L.n_tiles : nullptr,

@@ -9,8 +9,6 @@ import scipy.sparse as smat
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
-# build the tile images of the optional tile-stationary kernel (K1T) at model load, so the parity tests can force it
-os.environ.setdefault("XRL_K1T", "1")
 
 
 def pytest_configure(config):

@@ -246,3 +246,72 @@ def test_synthetic_queries_carry_the_specified_number_of_features():
             assert (np.diff(ids) > 0).all()                      # sorted, distinct
         nrm = np.sqrt(np.asarray(X.multiply(X).sum(axis=1)).ravel())
         assert np.allclose(nrm, 1.0, atol=1e-4)                  # L2-normalised rows (xrl_predict.py:143)
+
+
+def _k1r_walk(img, x_idx, x_val, w_rows):
+    """The traversal xrl_k1r.hip performs on a tile image, restated with numpy scalars: per query feature in ascending
+    order probe the rank-bitmap, then apply the row (dense: every column with a weight; short: its pairs in stored order)
+    with a separate fp32 multiply and add."""
+    kMissing = 0x7FA5A5A5
+    R, ncols, off_rank, off_desc, off_bias = (int(img[k]) for k in (1, 2, 3, 4, 5))
+    rank16 = img[off_rank:].view(np.uint16)
+    acc = np.zeros(ncols, dtype=np.float32)
+    for f, v in zip(x_idx, x_val):
+        if f >= w_rows:
+            continue
+        w = int(f) >> 6
+        bits = int(img[8 + 2 * w]) | (int(img[8 + 2 * w + 1]) << 32)
+        b = int(f) & 63
+        if not (bits >> b) & 1:
+            continue
+        slot = int(rank16[w]) + bin(bits & ((1 << b) - 1)).count("1")
+        assert slot < R
+        d = int(img[off_desc + slot])
+        if d & 0x80000000:
+            row = img[(d & 0xFFFFFF):(d & 0xFFFFFF) + ncols + 1]
+            assert row[ncols] == kMissing
+            for c in range(ncols):
+                if row[c] != kMissing:
+                    acc[c] = np.float32(acc[c] + np.float32(np.float32(v) * row[c:c + 1].view(np.float32)[0]))
+        else:
+            n = ((d >> 24) & 7) + 1
+            base = d & 0xFFFFFF
+            assert base % 2 == 0
+            for k in range(n):
+                c = int(img[base + 2 * k]); wv = img[base + 2 * k + 1:base + 2 * k + 2].view(np.float32)[0]
+                acc[c] = np.float32(acc[c] + np.float32(np.float32(v) * wv))
+    return acc
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_k1r_tile_image_walk(seed):
+    # the LDS image of the tile-resident kernel, built by the model compiler's host code, walked the way the kernel walks it
+    from pecos_amd import clib
+    rng = np.random.default_rng(seed)
+    w_rows = int(rng.choice([70, 700, 5000]))
+    ncols = int(rng.choice([1, 7, 64, 65, 82, 128]))
+    dens = float(rng.choice([0.02, 0.2, 0.7])) if w_rows * ncols < 50000 else 0.01   # (a tile must fit 152 KiB)
+    M = (rng.random((w_rows, ncols)) < dens * rng.random((w_rows, 1)) ** 2)
+    M[rng.integers(0, w_rows)] = True                                   # one full row
+    vals = rng.standard_normal((w_rows, ncols)).astype(np.float32)
+    vals[rng.random((w_rows, ncols)) < 0.05] = 0.0                      # explicit zeros are entries
+    rows = np.nonzero(M.any(axis=1))[0].astype(np.uint32)
+    rptr = np.concatenate([[0], np.cumsum(M[rows].sum(axis=1))]).astype(np.uint32)
+    ent_col = np.concatenate([np.nonzero(M[r])[0] for r in rows]).astype(np.uint32)
+    ent_val = np.concatenate([vals[r][M[r]] for r in rows]).astype(np.float32)
+    img = clib.debug_k1r_image(w_rows, ncols, rows, rptr, ent_col, ent_val)
+    assert img is not None and len(img) % 4 == 0 and img[0] == len(img) and img[1] == len(rows) and img[2] == ncols
+    assert 2 <= img[7] <= 8
+    # a tile that cannot fit is refused, not truncated
+    assert clib.debug_k1r_image(w_rows, ncols, rows, rptr, ent_col, ent_val, cap_bytes=64) is None
+    for _ in range(5):
+        nx = int(rng.integers(0, min(w_rows, 200)))
+        x_idx = np.sort(rng.choice(w_rows + 5, size=nx, replace=False))
+        x_val = rng.standard_normal(nx).astype(np.float32)
+        want = np.zeros(ncols, dtype=np.float32)
+        for f, v in zip(x_idx, x_val):
+            if f < w_rows:
+                for c in np.nonzero(M[f])[0]:
+                    want[c] = np.float32(want[c] + np.float32(np.float32(v) * vals[f, c]))
+        got = _k1r_walk(img, x_idx, x_val, w_rows)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -100,9 +100,9 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         clib.set_option(m.model.model_chain, "k1g_min_items", 1 if trial == 0 else 16)   # dense X: tiled SGEMM forced / by batch size
         clib.set_option(m.model.model_chain, "k1g_variant", int(rng.integers(0, 2)))      # its alternative tile shapes
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
-        # tile-stationary kernel: off / forced for every layer whose tiles fit in LDS, short and long item runs
-        clib.set_option(m.model.model_chain, "k1t_min_items", int(rng.choice([0, 1, 1])))
-        clib.set_option(m.model.model_chain, "k1t_items_per_block", int(rng.choice([64, 128, 1024])))
+        # tile-resident kernel (K1R): off / forced for every layer whose tile images fit in LDS, one or several workgroups per tile
+        clib.set_option(m.model.model_chain, "k1r_min_items", int(rng.choice([0, 1, 1])))
+        clib.set_option(m.model.model_chain, "k1r_split_items", int(rng.choice([1, 3, 4096])))
         # one or two row batches in flight (two streams), whole or ragged batches
         clib.set_option(m.model.model_chain, "overlap_min_rows", int(rng.choice([0, 2])))
         clib.set_option(m.model.model_chain, "max_batch_rows", int(rng.choice([0, 0, 7, 32])))
@@ -116,7 +116,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
     clib.set_option(m.model.model_chain, "k1g_min_items", 16)
     clib.set_option(m.model.model_chain, "k1g_variant", 0)
     clib.set_option(m.model.model_chain, "dense_layers", 1)
-    clib.set_option(m.model.model_chain, "k1t_min_items", 1)
+    clib.set_option(m.model.model_chain, "k1r_min_items", 1)
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)
     # model defaults (per-layer only_topk / post-processor from param.json)
     assert_same_topk(m.predict(X), om.predict(X), exact_scores=True, what=f"seed={seed} defaults")

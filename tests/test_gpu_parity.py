@@ -78,7 +78,7 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
         clib.set_option(m.model.model_chain, "dense_layers", 0)     # tile format: K0 -> K1 -> K2
         for g in (0, 1, 2, 8, 64):
             clib.set_option(m.model.model_chain, "k1_group", g)
-            clib.set_option(m.model.model_chain, "k1t_min_items", 0)
+            clib.set_option(m.model.model_chain, "k1r_min_items", 0)
             P = m.predict(X, **c["kwargs"])
             assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} G={g}")
         clib.set_option(m.model.model_chain, "k2_legacy", 1)        # round-1 insertion top-k kernels
@@ -86,13 +86,14 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
         assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} legacy K2")
         clib.set_option(m.model.model_chain, "k2_legacy", 0)
         clib.set_option(m.model.model_chain, "k1_group", 0)
-        # tile-stationary kernel forced on every layer whose tiles fit in LDS
-        for ipb in (64, 1024):
-            clib.set_option(m.model.model_chain, "k1t_min_items", 1)
-            clib.set_option(m.model.model_chain, "k1t_items_per_block", ipb)
+        # tile-resident kernel (K1R) forced on every layer whose tile images fit in LDS; one / several workgroups per tile
+        for spl in (4096, 1):
+            clib.set_option(m.model.model_chain, "k1r_min_items", 1)
+            clib.set_option(m.model.model_chain, "k1r_split_items", spl)
             P = m.predict(X, **c["kwargs"])
-            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1T ipb={ipb}")
-        clib.set_option(m.model.model_chain, "k1t_min_items", 0)
+            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1R split_items={spl}")
+        clib.set_option(m.model.model_chain, "k1r_min_items", 128)
+        clib.set_option(m.model.model_chain, "k1r_split_items", 4096)
         clib.set_option(m.model.model_chain, "dense_layers", 1)
 
 
@@ -131,19 +132,21 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
                          exact_scores=True, what=f"{name} two lanes, max_batch_rows={rows}")
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)
     clib.set_option(m.model.model_chain, "overlap_min_rows", 0)
-    for k1t in (0, 1):   # K1 everywhere / tile-stationary K1T wherever a tile image fits in LDS
-        clib.set_option(m.model.model_chain, "k1t_min_items", k1t)
-        assert_same_topk(m.predict(X, beam_size=cfg["beam"], only_topk=10), ref.predict(X, beam_size=cfg["beam"], only_topk=10),
-                         exact_scores=True, what=f"{name} k1t_min_items={k1t}")
-    # the forced run really went through the tile-stationary kernel
-    clib.set_option(m.model.model_chain, "k1t_min_items", 1)
+    for k1r in (0, 1):   # K1 everywhere / tile-resident K1R wherever the tile images fit in LDS
+        clib.set_option(m.model.model_chain, "k1r_min_items", k1r)
+        for pp in (None, "sigmoid"):
+            kw = dict(beam_size=cfg["beam"], only_topk=10, **({"post_processor": pp} if pp else {}))
+            assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} k1r_min_items={k1r} {pp}")
+    # the forced run really went through the tile-resident kernel
+    clib.set_option(m.model.model_chain, "k1r_min_items", 1)
     clib.profile_enable(m.model.model_chain, True); clib.profile_reset(m.model.model_chain)
     m.predict(X, beam_size=cfg["beam"], only_topk=10)
     names = {r["name"] for r in clib.profile_get(m.model.model_chain)}
     clib.profile_enable(m.model.model_chain, False)
-    if name != "wiki10-31k":   # its scaled-down leaf tiles (101938 features) do not fit in LDS: K1 serves every layer
-        assert "k1t_sparse" in names, names
-    clib.set_option(m.model.model_chain, "k1t_min_items", 0)
+    assert ("k1r_sparse" in names) == (clib.xlinear_get_int_attr(m.model.model_chain, "nr_k1r_layers") > 0), names
+    if name != "wiki10-31k":
+        assert "k1r_sparse" in names, names
+    clib.set_option(m.model.model_chain, "k1r_min_items", 128)
     clib.set_option(m.model.model_chain, "dense_layers", 1)
     assert_same_topk(m.predict(X, beam_size=5, only_topk=3, max_pred_chunk=37), ref.predict(X, beam_size=5, only_topk=3),
                      exact_scores=True, what="max_pred_chunk")
