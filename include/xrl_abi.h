@@ -259,9 +259,9 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *   "sort_min_tiles"      tile-sort the items of layers with at least this many tiles (0 = never)
  *   "k1r_min_items"       sparse X: run a tile-format layer with the tile-RESIDENT kernel K1R (tile-sorted items, the tile's
  *                         image in LDS, accumulators in registers) once a tile serves this many items on average
- *                         (default 128; 0 = never); needs the tile images (every tile of the layer fits in LDS; XRL_K1R=0
+ *                         (0 = never, the default: profiles/r03_k1r_experiments.txt); needs the tile images (every tile of the layer fits in LDS; XRL_K1R=0
  *                         in the environment at load skips building them)
- *   "k1r_split_items"     K1R: a tile's items are shared by ceil(average items per tile / this) workgroups (default 4096)
+ *   "k1r_items_per_block" K1R: consecutive tile-sorted items per workgroup (default 1024)
  *   "overlap_min_rows"    split predicts of at least this many rows into two batches on two streams (0 = never)
  *   "host_pipeline"       1 (default): c_xlinear_predict_* cut a large X into nnz-balanced row batches; batch b+1 is staged into
  *                         pinned memory and uploaded on a copy stream while batch b computes; 0: one synchronous upload

@@ -914,7 +914,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
         else if (!std::strcmp(key, "k2_legacy")) m.k2_legacy = (int)value;        // debug / A-B: round-1 insertion top-k
         else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
         else if (!std::strcmp(key, "k1r_min_items")) m.k1r_min_items = (int)value;
-        else if (!std::strcmp(key, "k1r_split_items")) m.k1r_split_items = (int)value;
+        else if (!std::strcmp(key, "k1r_items_per_block")) m.k1r_items_per_block = (int)value;
         else if (!std::strcmp(key, "k1g_variant")) m.k1g_variant = (int)value;   // K1G tile-shape alternative (tuning; results identical)
         else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
         else if (!std::strcmp(key, "k1_lds_pad")) m.k1_lds_pad = (int)value;   // debug: occupancy experiments

@@ -11,17 +11,22 @@
 // tile's lookup structure and weights are read from HBM once per workgroup; per item only the descriptor, the query row and
 // the output block touch global memory (~20 requests).
 //
-// Work decomposition.  Items are tile-sorted (launch_sort_items).  One workgroup = one tile (or 1/splits of its items);
-// one wavefront = one item at a time, LANE == COLUMN, accumulators in registers (NS = 1 or 2 per lane: tiles of <= 64 / <= 128
-// columns).  Per 64 query features: every lane probes one feature against the tile's rank-bitmap in LDS (one ds_read_b64 + the
-// rank), hit lanes fetch their row descriptor (and, for rows held in entry form, their <= TS entries) -- all hits of the step
-// in parallel -- then a SCALAR loop walks the hits in lane (= ascending feature) order:
-//   dense row (len > T): every lane reads its column's weight (kMissing where the row has no entry), v_mul, v_add, select;
-//   short row (len <= T): per entry, column and weight are broadcast from the hit lane (v_readlane), the one lane that owns
-//                         the column adds.
-// Each column therefore accumulates fl32(acc + fl32(x_f * w)) over its matched features in ascending feature order, which is
-// the reference's order; an absent entry performs no operation (so explicit zeros in W and non-finite x behave as in the
-// reference's row walk); bias last; transform in fp64; combine in fp32 -- bit-identical to K1.
+// Work decomposition.  Items are tile-sorted (launch_sort_items).  One workgroup = a run of `ch` consecutive sorted items
+// (usually of one tile; the image is re-loaded when the run crosses into the next tile); one wavefront = one item at a time,
+// LANE == COLUMN PAIR (lane l owns columns 2l and 2l+1), accumulators in registers.  Per 64 query features: every lane probes
+// one feature against the tile's rank-bitmap in LDS (one ds_read_b64 + the rank), hit lanes fetch their row descriptor (and,
+// for rows held in entry form, their <= TS entries) -- all hits of the step in parallel -- and work out the NEXT hit lane and the
+// LDS offset of their row; then a scalar loop walks the hits in lane (= ascending feature) order with three v_readlane per hit:
+//   every hit:  the lanes read their pair of the row's weights (a dense row, or the all-zero row for a short one), v_pk_mul, v_pk_add;
+//   short row:  additionally, per entry, column and weight are broadcast from the hit lane and the one lane that owns the column adds.
+// The loop is kept poor in SCALAR instructions on purpose: the CU's single scalar unit serves all 16 wavefronts (a first version
+// that derived the next hit and the row address with ~25 s_* instructions per hit ran at 17.5 ms, scalar-issue bound).
+//
+// Arithmetic: each column accumulates fl32(acc + fl32(x_f * w)) over its matched features in ascending feature order -- the
+// reference's order.  A dense row holds +0.0 where it has no entry: for FINITE x that step is acc + (+-0) == acc (an accumulator
+// that starts at +0.0 can never become -0.0), i.e. "no operation", exactly like the reference's skip; a 64-feature step that
+// contains a non-finite x takes the exact loop instead (select on the row's column mask), so inf / NaN inputs still behave like
+// the reference's row walk.  Bias last; transform in fp64; combine in fp32 -- bit-identical to K1.
 #include <hip/hip_runtime.h>
 
 #include "xrl_device.h"
@@ -38,46 +43,55 @@ struct K1RArgs {
     const uint32_t* start;                           // [n_tiles + 1] first sorted item of every tile
     const uint32_t* xi; const float* xv;             // CSR queries
     float* cand;
-    uint32_t w_rows, splits;
+    uint32_t w_rows, n_tiles, ch;                    // ch: sorted items per workgroup
     int pp_kind, pp_p, first_layer, has_bias;
 };
 
 struct XChunk { uint32_t f; uint32_t v; };           // one query feature per lane: id (0xFFFFFFFF past the row's end), value bits
 
-template <int NS, int TS, int PPC>
+template <int TS, int PPC>
 __global__ void __launch_bounds__(1024) k1r_kernel(K1RArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t t = blockIdx.x / a.splits, sp = blockIdx.x - t * a.splits;
-    const uint32_t s0 = a.start[t], n_t = a.start[t + 1] - s0;
-    const uint32_t b0 = s0 + (uint32_t)((uint64_t)n_t * sp / a.splits), b1 = s0 + (uint32_t)((uint64_t)n_t * (sp + 1u) / a.splits);
-    if (b0 >= b1) return;                                               // uniform: no barrier has been reached yet
+    // workgroup b walks the sorted items [b * ch, (b + 1) * ch): a run may cross tile boundaries (the image is re-loaded), and a
+    // tile that serves many items is shared by as many workgroups as it takes -- the work per workgroup is bounded either way
+    // (beams concentrate on few parents: on the Amazon-670K shape 10 of the 8192 leaf tiles receive 3/4 of the items)
+    const uint32_t n_items = a.start[a.n_tiles];
+    const uint32_t blk0 = blockIdx.x * a.ch;
+    if (blk0 >= n_items) return;
+    const uint32_t blk1 = min(n_items, blk0 + a.ch);
     const uint32_t nthreads = blockDim.x;
     const uint32_t nw = __builtin_amdgcn_readfirstlane(nthreads >> 6);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const uint32_t* __restrict__ xi = a.xi;
     const float* __restrict__ xv = a.xv;
-
+    const uint32_t w_rows = a.w_rows;
     const ItemDesc none = make_item(0u, kNoTile, 0u, 0.f, 0, 0u);
+    const unsigned long long lane_bit = 1ull << lane;
+
+  for (uint32_t pos = blk0; pos < blk1;) {
+    const uint32_t t = __builtin_amdgcn_readfirstlane(a.items[pos].tile);
+    const uint32_t b1 = __builtin_amdgcn_readfirstlane(min(blk1, a.start[t + 1]));   // end of this tile's run inside the block
     auto ld_item = [&](uint32_t i) -> ItemDesc { return i < b1 ? a.items[i] : none; };   // uniform index: scalar loads
-    // 64 query features of an item, one per lane; unconditional clamped loads (lanes past the row's end re-read element 0)
+    // 64 query features of an item, one per lane; unconditional clamped loads (lanes past the row's end re-read the row's first element)
     auto ld_chunk = [&](const ItemDesc& d, uint32_t c0) -> XChunk {
         const uint32_t idx = c0 + (uint32_t)lane;
         const bool ok = idx < d.x_len;
-        const uint64_t p = ok ? d.x_begin + idx : 0ull;
+        const uint64_t p = d.x_begin + (ok ? idx : 0u);
         XChunk r; r.f = xi[p]; r.v = __float_as_uint(xv[p]);
         if (!ok) r.f = 0xFFFFFFFFu;
         return r;
     };
 
     // the first items' descriptors and features are in flight during the image copy
-    uint32_t i = b0 + wave;
+    uint32_t i = pos + wave;
     ItemDesc it = ld_item(i), it_n = ld_item(i + nw);
     XChunk A = ld_chunk(it, 0u), B = ld_chunk(it, 64u);
+    __syncthreads();                                                    // the previous tile's readers are done
     {
         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.img + a.img_off[t]);   // images are 16-byte aligned, whole uint4s
         uint4* dst = reinterpret_cast<uint4*>(smem);
-        const uint32_t nq = src[0].x >> 2;
+        const uint32_t nq = (uint32_t)(a.img_off[t + 1] - a.img_off[t]) >> 2;
         uint32_t k = threadIdx.x;
         for (; k + 3u * nthreads < nq; k += 4u * nthreads) {            // four loads in flight per thread
             const uint4 q0 = src[k], q1 = src[k + nthreads], q2 = src[k + 2u * nthreads], q3 = src[k + 3u * nthreads];
@@ -87,24 +101,21 @@ __global__ void __launch_bounds__(1024) k1r_kernel(K1RArgs a) {
     }
     __syncthreads();
     const uint32_t ncols = __builtin_amdgcn_readfirstlane(smem[2]);
-    const uint2* __restrict__ bm_bits = reinterpret_cast<const uint2*>(smem + 8);
+    const uint2* __restrict__ bm_bits = reinterpret_cast<const uint2*>(smem + 12);
     const uint16_t* __restrict__ bm_rank = reinterpret_cast<const uint16_t*>(smem + __builtin_amdgcn_readfirstlane(smem[3]));
     const uint32_t* __restrict__ rowdesc = smem + __builtin_amdgcn_readfirstlane(smem[4]);
     const float* __restrict__ t_bias = reinterpret_cast<const float*>(smem + __builtin_amdgcn_readfirstlane(smem[5]));
+    const uint32_t zero_row = __builtin_amdgcn_readfirstlane(smem[8]) * 4u;          // byte offset of the all-zero row's first pair
     const unsigned char* __restrict__ sbytes = reinterpret_cast<const unsigned char*>(smem);
-    uint32_t coff[NS];                                                  // byte offset of this lane's columns inside a dense row (pad word past the tile's width)
-#pragma unroll
-    for (int r = 0; r < NS; ++r) coff[r] = min((uint32_t)(r * 64 + lane), ncols) * 4u;
-    const uint32_t w_rows = a.w_rows;
+    const uint32_t npairs = (ncols + 1u) >> 1;
+    const uint32_t poff = min((uint32_t)lane, npairs) * 8u;            // byte offset of this lane's pair inside a dense row (zero pair past the tile's width)
 
     for (; i < b1; i += nw) {
         // ---- prefetch: descriptor two items ahead, the first 128 features of the next item
         const ItemDesc it_nn = ld_item(i + 2u * nw);
         const XChunk An = ld_chunk(it_n, 0u), Bn = ld_chunk(it_n, 64u);
 
-        float acc[NS];
-#pragma unroll
-        for (int r = 0; r < NS; ++r) acc[r] = 0.0f;                     // std::fill(..., 0.0), inference.hpp:964
+        float2 acc = make_float2(0.0f, 0.0f);                           // std::fill(..., 0.0), inference.hpp:964
         const uint32_t x_len = it.x_len;
         for (uint32_t c0 = 0; c0 < x_len; c0 += 64u) {
             XChunk C; C.f = 0xFFFFFFFFu; C.v = 0u;
@@ -127,106 +138,106 @@ __global__ void __launch_bounds__(1024) k1r_kernel(K1RArgs a) {
             uint2 e[TS];
 #pragma unroll
             for (int k = 0; k < TS; ++k) e[k] = ep[min((uint32_t)k, len1)];
-            // ---- hits in ascending feature order.  The dense-row weights of the NEXT hit are requested (unconditionally: offset 0
-            //      when that hit is a short row or there is none) before the current hit is applied, so the LDS latency of a row
-            //      hides behind the previous row's arithmetic.
-            unsigned long long mask = __ballot(hit);
+            const unsigned long long mask = __ballot(hit);
+            // what the scalar loop reads per hit: the row's byte offset (zero row for a short one) with the "short" flag in bit 0,
+            // and the NEXT hit lane (the last hit points at itself) with the row's length - 1 above it
+            const uint32_t rowoff = is_short ? (zero_row | 1u) : (desc & 0x3FFFFFu) * 4u;
+            const unsigned long long later = mask & ~(lane_bit | (lane_bit - 1ull));
+            const uint32_t nxt = (later ? (uint32_t)__ffsll((long long)later) - 1u : (uint32_t)lane) | (len1 << 8);
+            const bool nonfinite = __ballot(inr && (A.v & 0x7F800000u) == 0x7F800000u) != 0ull;
             if (mask) {
-                uint32_t dn = (uint32_t)__builtin_amdgcn_readlane((int)desc, __ffsll((long long)mask) - 1);
-                uint32_t wbn[NS];
-                {
-                    const unsigned char* __restrict__ row = sbytes + ((dn & 0x80000000u) ? (dn & 0xFFFFFFu) * 4u : 0u);
-#pragma unroll
-                    for (int r = 0; r < NS; ++r) wbn[r] = *reinterpret_cast<const uint32_t*>(row + coff[r]);
-                }
-                while (mask) {
-                    const int h = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1ull;
-                    const uint32_t d = dn;
-                    uint32_t wb[NS];
-#pragma unroll
-                    for (int r = 0; r < NS; ++r) wb[r] = wbn[r];
-                    {
-                        const int hn = mask ? __ffsll((long long)mask) - 1 : h;
-                        dn = (uint32_t)__builtin_amdgcn_readlane((int)desc, hn);
-                        const unsigned char* __restrict__ row = sbytes + ((dn & 0x80000000u) ? (dn & 0xFFFFFFu) * 4u : 0u);
-#pragma unroll
-                        for (int r = 0; r < NS; ++r) wbn[r] = *reinterpret_cast<const uint32_t*>(row + coff[r]);
-                    }
+                int h = __ffsll((long long)mask) - 1;
+                uint32_t rn = (uint32_t)__builtin_amdgcn_readlane((int)rowoff, h);
+                uint2 wbn = *reinterpret_cast<const uint2*>(sbytes + (rn & ~3u) + poff);
+                for (;;) {
+                    // ---- this hit: x value, next hit, row weights (requested during the previous hit)
                     const float xs = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)A.v, h));
-                    if (d & 0x80000000u) {
-#pragma unroll
-                        for (int r = 0; r < NS; ++r) {
-                            // scalar * val, then add: no fma (inference.hpp:512-517); no entry -> no operation
-                            const float s = __fadd_rn(acc[r], __fmul_rn(xs, __uint_as_float(wb[r])));
-                            acc[r] = (wb[r] == kMissing) ? acc[r] : s;
-                        }
-                    } else {
-                        const uint32_t l1 = (d >> 24) & 7u;
+                    const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)nxt, h);
+                    const int hn = (int)(nx & 0xFFu);
+                    const uint32_t r = rn;
+                    const uint2 wb = wbn;
+                    rn = (uint32_t)__builtin_amdgcn_readlane((int)rowoff, hn);
+                    wbn = *reinterpret_cast<const uint2*>(sbytes + (rn & ~3u) + poff);   // the next hit's weights: in flight while this one is applied
+                    // scalar * val, then add: no fma (inference.hpp:512-517)
+                    const float s0 = __fadd_rn(acc.x, __fmul_rn(xs, __uint_as_float(wb.x)));
+                    const float s1 = __fadd_rn(acc.y, __fmul_rn(xs, __uint_as_float(wb.y)));
+                    if (!nonfinite) { acc.x = s0; acc.y = s1; }
+                    else {
+                        // exact: a column without an entry performs no operation (the row's column mask sits in the 4 words before its pairs)
+                        const uint32_t mw = *reinterpret_cast<const uint32_t*>(sbytes + (r & ~3u) - 16u + (((uint32_t)lane >> 4) << 2));
+                        const uint32_t mb = mw >> (((uint32_t)lane & 15u) << 1);
+                        const bool in_row = (uint32_t)lane < npairs;
+                        if (in_row && (mb & 1u)) acc.x = s0;
+                        if (in_row && (mb & 2u)) acc.y = s1;
+                    }
+                    if (r & 1u) {
+                        const uint32_t l1 = nx >> 8;
 #pragma unroll
                         for (int k = 0; k < TS; ++k) {
                             if ((uint32_t)k <= l1) {
                                 const uint32_t code = (uint32_t)__builtin_amdgcn_readlane((int)e[k].x, h);
                                 const float p = __fmul_rn(xs, __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)e[k].y, h)));
-                                if (NS == 1 || code < 64u) {
-                                    const float s = __fadd_rn(acc[0], p);
-                                    acc[0] = ((uint32_t)lane == code) ? s : acc[0];
-                                } else {
-                                    const float s = __fadd_rn(acc[NS - 1], p);
-                                    acc[NS - 1] = ((uint32_t)lane + 64u == code) ? s : acc[NS - 1];
-                                }
+                                const bool mine = (uint32_t)lane == (code >> 1);
+                                if (code & 1u) { const float s = __fadd_rn(acc.y, p); acc.y = mine ? s : acc.y; }
+                                else { const float s = __fadd_rn(acc.x, p); acc.x = mine ? s : acc.x; }
                             }
                         }
                     }
+                    if (hn == h) break;
+                    h = hn;
                 }
             }
             A = B; B = C;
         }
         // ---- bias LAST (inference.hpp:806-811), transform in fp64, combine with the parent's score, write the child block
         float* __restrict__ out = a.cand + it.out_off;
-#pragma unroll
-        for (int r = 0; r < NS; ++r) {
-            const uint32_t c = (uint32_t)(r * 64 + lane);
-            if (c < ncols) {
-                float s = acc[r];
-                if (a.has_bias) s = __fadd_rn(s, t_bias[c]);
-                float v = pp_transform<PPC>(a.pp_kind, a.pp_p, s);
-                if (!a.first_layer) v = pp_combine(a.pp_kind, v, it.pscore);
-                out[c] = v;
-            }
+        const uint32_t c = 2u * (uint32_t)lane;
+        if (c < ncols) {
+            float s = acc.x;
+            if (a.has_bias) s = __fadd_rn(s, t_bias[c]);
+            float v = pp_transform<PPC>(a.pp_kind, a.pp_p, s);
+            if (!a.first_layer) v = pp_combine(a.pp_kind, v, it.pscore);
+            out[c] = v;
+        }
+        if (c + 1u < ncols) {
+            float s = acc.y;
+            if (a.has_bias) s = __fadd_rn(s, t_bias[c + 1u]);
+            float v = pp_transform<PPC>(a.pp_kind, a.pp_p, s);
+            if (!a.first_layer) v = pp_combine(a.pp_kind, v, it.pscore);
+            out[c + 1u] = v;
         }
         it = it_n; it_n = it_nn; A = An; B = Bn;
     }
+    pos = b1;
+  }
 }
 
 bool k1r_eligible(const LayerDev& L) { return L.img != nullptr && L.max_tile_cols <= 128u && L.img_max_short <= kK1RMaxShort; }
 
 void launch_k1r(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
-                float* cand, uint32_t splits, hipStream_t s) {
+                float* cand, uint32_t items_per_block, hipStream_t s) {
     if (P.nrows == 0) return;
     if (!k1r_eligible(L) || X.dense || X.nnz == 0) fail("k1r: layer / queries not eligible");
     K1RArgs a;
     a.img = L.img; a.img_off = L.img_off; a.items = static_cast<const ItemDesc*>(items_sorted); a.start = start;
     a.xi = X.col_idx; a.xv = X.val; a.cand = cand;
-    a.w_rows = L.w_rows; a.splits = std::max(1u, splits);
+    a.w_rows = L.w_rows; a.n_tiles = L.n_tiles; a.ch = std::max(16u, items_per_block);
     a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer; a.has_bias = L.has_bias;
     const size_t lds = ((size_t)L.max_tile_img + 15) & ~(size_t)15;
     if (lds > 160 * 1024) fail("k1r: tile image exceeds the LDS");
-    const uint64_t blocks = (uint64_t)L.n_tiles * a.splits;
-    if (blocks > 0x7FFFFFFFull) fail("k1r: grid too large");
+    const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;   // upper bound of the sorted item count (known on the device only)
+    const uint64_t blocks = (n_slots + a.ch - 1) / a.ch;
+    if (blocks > 0x7FFFFFFFull) fail("k1r: grid too large; lower max_batch_rows");
     // one workgroup per CU when the image takes more than half of the LDS (16 wavefronts); two of 8 wavefronts otherwise
     const uint32_t threads = lds > 80 * 1024 ? 1024u : 512u;
     const int ppc = pp_class(P.pp);
-    const int ns = L.max_tile_cols <= 64u ? 1 : 2;
     const int ts = L.img_max_short <= 2u ? 2 : (L.img_max_short <= 4u ? 4 : 8);
-#define XRL_K1R_GO(NN, TT, PP) do { \
-        auto kern = &k1r_kernel<NN, TT, PP>; \
+#define XRL_K1R_GO(TT, PP) do { \
+        auto kern = &k1r_kernel<TT, PP>; \
         if (lds > 48 * 1024) XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(kern, dim3((uint32_t)blocks), dim3(threads), lds, s, a); } while (0)
-#define XRL_K1R_T(NN, PP) do { if (ts == 2) XRL_K1R_GO(NN, 2, PP); else if (ts == 4) XRL_K1R_GO(NN, 4, PP); else XRL_K1R_GO(NN, 8, PP); } while (0)
-#define XRL_K1R_N(PP) do { if (ns == 1) XRL_K1R_T(1, PP); else XRL_K1R_T(2, PP); } while (0)
-    if (ppc) XRL_K1R_N(1); else XRL_K1R_N(0);
-#undef XRL_K1R_N
+#define XRL_K1R_T(PP) do { if (ts == 2) XRL_K1R_GO(2, PP); else if (ts == 4) XRL_K1R_GO(4, PP); else XRL_K1R_GO(8, PP); } while (0)
+    if (ppc) XRL_K1R_T(1); else XRL_K1R_T(0);
 #undef XRL_K1R_T
 #undef XRL_K1R_GO
     XRL_LAUNCH_CHECK();

@@ -52,7 +52,7 @@ uint32_t sort_max_tiles();
 // K1R (xrl_k1r.hip): tile-resident K1 (sparse queries, tile-sorted items, tile image held in LDS, accumulators in registers)
 bool k1r_eligible(const LayerDev& L);   // the layer carries tile images (every tile fits in LDS)
 void launch_k1r(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
-                float* cand, uint32_t splits, hipStream_t s);
+                float* cand, uint32_t items_per_block, hipStream_t s);
 size_t sort_hist_bytes(uint64_t n_slots, uint32_t n_tiles);
 // K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,

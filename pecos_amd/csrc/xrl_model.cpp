@@ -134,14 +134,19 @@ uint64_t layout_tile_rows(const uint32_t* rptr, uint32_t nrows, bool align, uint
 
 // ---- tile images of the tile-RESIDENT kernel K1R (xrl_k1r.hip): one self-contained blob per tile, copied verbatim into LDS
 //      by the workgroup that owns the tile.  Row lookup = a rank-bitmap over the feature ids (one LDS read per probe); rows
-//      longer than a per-tile threshold T are held DENSE (ncols + 1 words: the weight bits, kMissing where the row has no
-//      entry -- lane == column, accumulators in registers), shorter ones as {column, value} pairs.  T is the smallest value
-//      in [2, kK1RMaxShort] for which the image fits `cap_bytes`.  Layout (u32 words):
-//        [0] words  [1] R  [2] ncols  [3] off_rank  [4] off_rowdesc  [5] off_bias  [6] nw64  [7] T
-//        bits u64[nw64] | rank u16[nw64] | rowdesc u32[R] | bias f32[ncols] | pairs (8-byte aligned) | dense rows
-//        rowdesc: dense  0x80000000 | word offset of the row's ncols + 1 words
-//                 short  word offset of the row's first pair | (len - 1) << 24
+//      longer than a per-tile threshold T are held DENSE (lane == column pair, accumulators in registers), shorter ones as
+//      {column, value} pairs.  T is the smallest value in [2, kK1RMaxShort] for which the image fits `cap_bytes`.
+//      Layout (u32 words):
+//        [0] words  [1] R  [2] ncols  [3] off_rank  [4] off_rowdesc  [5] off_bias  [6] nw64  [7] T  [8] off_zero_row  [9..11] 0
+//        bits u64[nw64] | rank u16[nw64] | rowdesc u32[R] | bias f32[ncols] | pairs (8-byte aligned) | zero row | dense rows
+//        dense row: 4 words of column mask, then (npairs + 1) x {w[2p], w[2p+1]} with npairs = ceil(ncols / 2): the weight bits,
+//                   +0.0 where the row has no entry (acc + x * 0 == acc for finite x: K1R's accumulators are never -0.0) and a
+//                   zero pair at the end (where lanes past the tile's width read); the mask serves the exact path taken for
+//                   non-finite x.  The zero row (mask 0) is what a short row's dense step reads.
+//        rowdesc: dense  0x80000000 | word offset of the row's first pair
+//                 short  word offset of the row's first {column, value} | (len - 1) << 24
 // k1r_image_words: size of the image in words (a multiple of 4) and T, or 0 when no T fits.
+static inline uint64_t k1r_dense_row_words(uint32_t ncols) { return 4 + 2 * (((uint64_t)ncols + 1) / 2 + 1); }
 uint64_t k1r_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t cap_bytes, uint32_t* thr_out) {
     if (R >= 65536 || ncols > kMaxTileCols) return 0;
     const uint64_t nw64 = ((uint64_t)w_rows + 63) / 64;
@@ -151,12 +156,12 @@ uint64_t k1r_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint3
         if (len == 0 || len > kMaxTileCols) return 0;
         n_len[len] += 1;
     }
-    const uint64_t fixed = 8 + 2 * nw64 + (nw64 + 1) / 2 + R + ncols + 1;   // + alignment of the pairs
+    const uint64_t fixed = 12 + 2 * nw64 + (nw64 + 1) / 2 + R + ncols + 1 + k1r_dense_row_words(ncols);   // + alignment of the pairs, + the zero row
     for (uint32_t thr = 2; thr <= kK1RMaxShort; ++thr) {
         uint64_t dense_rows = 0, short_ent = 0;
         for (uint32_t len = 1; len <= kMaxTileCols; ++len) { if (len <= thr) short_ent += n_len[len] * len; else dense_rows += n_len[len]; }
-        const uint64_t w = (fixed + dense_rows * (ncols + 1ull) + 2 * short_ent + 3) & ~3ull;
-        if (w * 4 <= cap_bytes && w < (1ull << 24)) { if (thr_out) *thr_out = thr; return w; }
+        const uint64_t w = (fixed + dense_rows * k1r_dense_row_words(ncols) + 2 * short_ent + 3) & ~3ull;
+        if (w * 4 <= cap_bytes && w < (1ull << 22)) { if (thr_out) *thr_out = thr; return w; }
     }
     return 0;
 }
@@ -166,8 +171,9 @@ uint64_t k1r_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint3
 bool k1r_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* ent, uint32_t R, uint32_t ncols, uint32_t w_rows,
                      uint32_t thr, uint64_t words, uint32_t* b) {
     const uint32_t nw64 = (uint32_t)(((uint64_t)w_rows + 63) / 64);
-    const uint32_t off_bits = 8, off_rank = off_bits + 2 * nw64, off_desc = off_rank + (nw64 + 1) / 2, off_bias = off_desc + R;
-    uint32_t cur = (off_bias + ncols + 1u) & ~1u;                          // {column, value} pairs are read as 8-byte words
+    const uint32_t off_bits = 12, off_rank = off_bits + 2 * nw64, off_desc = off_rank + (nw64 + 1) / 2, off_bias = off_desc + R;
+    const uint32_t drw = (uint32_t)k1r_dense_row_words(ncols);
+    uint32_t cur = (off_bias + ncols + 1u) & ~1u;                          // {column, value} pairs and dense pairs are read as 8-byte words
     b[0] = (uint32_t)words; b[1] = R; b[2] = ncols; b[3] = off_rank; b[4] = off_desc; b[5] = off_bias; b[6] = nw64; b[7] = thr;
     uint16_t* rank = reinterpret_cast<uint16_t*>(b + off_rank);
     bool ok = true;
@@ -180,17 +186,19 @@ bool k1r_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* en
         b[off_desc + r] = cur | ((len - 1u) << 24);
         for (uint32_t e = rptr[r]; e < rptr[r + 1]; ++e) { b[cur] = ent[e].col; std::memcpy(&b[cur + 1], &ent[e].val, 4); cur += 2; }
     }
+    b[8] = cur + 4; cur += drw;                                            // the zero row (already zero)
     for (uint32_t r = 0; r < R; ++r) {
         const uint32_t len = rptr[r + 1] - rptr[r];
         if (len <= thr) continue;
-        b[off_desc + r] = 0x80000000u | cur;
-        for (uint32_t c = 0; c <= ncols; ++c) b[cur + c] = kMissing;
+        b[off_desc + r] = 0x80000000u | (cur + 4);
         for (uint32_t e = rptr[r]; e < rptr[r + 1]; ++e) {
-            if (ent[e].col >= ncols) fail("layer: internal error, K1R column out of range");
-            if (b[cur + ent[e].col] != kMissing) ok = false;
-            std::memcpy(&b[cur + ent[e].col], &ent[e].val, 4);
+            const uint32_t c = ent[e].col;
+            if (c >= ncols) fail("layer: internal error, K1R column out of range");
+            if (b[cur + (c >> 5)] & (1u << (c & 31u))) ok = false;
+            b[cur + (c >> 5)] |= 1u << (c & 31u);
+            std::memcpy(&b[cur + 4 + c], &ent[e].val, 4);
         }
-        cur += ncols + 1;
+        cur += drw;
     }
     uint32_t run = 0;
     for (uint32_t w = 0; w < nw64; ++w) {

@@ -167,9 +167,9 @@ struct Model {
     int64_t max_batch_rows = 0;             // 0 = auto
     int overlap_min_rows = 0;               // split a predict of at least this many rows into two half batches on two streams so that one half's
                                             // K0/K2 run under the other half's K1; 0 = never (measured on Amazon-670K: 25.9 vs 25.5 ms, no gain)
-    int k1r_min_items = 128;                // sparse X: run a tile-format layer tile-RESIDENT (K1R: tile-sorted items, the tile's image in LDS) once a tile serves
-                                            // at least this many items on average (0 = never)
-    int k1r_split_items = 4096;             // K1R: a tile's items are shared by ceil(average items per tile / this) workgroups
+    int k1r_min_items = 0;                  // sparse X: run a tile-format layer tile-RESIDENT (K1R: tile-sorted items, the tile's image in LDS) once a tile serves
+                                            // at least this many items on average; 0 = never (default: measured slower than K1, profiles/r03_k1r_experiments.txt)
+    int k1r_items_per_block = 1024;         // K1R: consecutive tile-sorted items per workgroup
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
     int k1q_fuse = 3;                       // consecutive dense-format layers of <= this many candidate registers (1..3) share one K1Q launch (the beam stays in LDS); 0: one launch per layer

@@ -228,12 +228,8 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             const uint64_t n_slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
             if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
             if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));   // K1 launches take turns across the lanes
-            if (mode == 2) {
-                // a tile's items are shared by several workgroups once a tile serves many more items than one workgroup should walk
-                const uint64_t per_tile = n_slots / std::max<uint32_t>(1, L.n_tiles);
-                const uint32_t splits = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, (per_tile + (uint64_t)std::max(1, m.k1r_split_items) - 1) / (uint64_t)std::max(1, m.k1r_split_items)));
-                timed("k1r_sparse", (uint32_t)l, [&] { launch_k1r(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.cand.as<float>(), splits, S); });
-            }
+            if (mode == 2)
+                timed("k1r_sparse", (uint32_t)l, [&] { launch_k1r(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.cand.as<float>(), (uint32_t)std::max(16, m.k1r_items_per_block), S); });
             else
                 timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] {
                     launch_k1(L.dev, P, X, mode == 1 ? lw.items_sorted.p : lw.items.p, mode == 1 ? lw.sort_start.as<uint32_t>() + L.n_tiles : nullptr,

@@ -49,6 +49,24 @@ for f in glob.glob(f"{O}/ktrace/**/*kernel_stats.csv", recursive=True):
 os.system(f"rm -rf {O}/ktrace")
 PY
          cd $R ;;
+    pmcset) # pmcset:COUNTER,COUNTER,...[@BENCHARG,BENCHARG...]  one rocprofv3 --pmc pass with the given counters, per-kernel means printed
+         n=$((n+1)); cs=${args%%@*}; ba=""; [ "$args" != "$cs" ] && ba=${args#*@}
+         cd /tmp && export TMPDIR=/tmp
+         timeout 300 rocprofv3 --kernel-trace --pmc $cs --output-format csv -d $O/pmcset_$n -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats $ba > $O/pmcset_$n.log 2>&1
+         python - $O/pmcset_$n <<'PY'
+import csv, glob, os, sys, collections
+d = sys.argv[1]
+for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+    rows = [r for r in csv.DictReader(open(f)) if "xrl::" in r["Kernel_Name"]]
+    with open(d + ".csv", "w", newline="") as out:
+        w = csv.DictWriter(out, fieldnames=["Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"], extrasaction="ignore")
+        w.writeheader(); w.writerows(rows)
+    agg = collections.defaultdict(list)
+    for r in rows: agg[(r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for k, v in sorted(agg.items()): print(k, "n=%d mean=%.5g" % (len(v), sum(v) / len(v)))
+os.system(f"rm -rf {d}")
+PY
+         tail -3 $O/pmcset_$n.log; cd $R ;;
     *) echo "unknown stage $name" ;;
   esac
 done

@@ -250,37 +250,41 @@ def test_synthetic_queries_carry_the_specified_number_of_features():
 
 def _k1r_walk(img, x_idx, x_val, w_rows):
     """The traversal xrl_k1r.hip performs on a tile image, restated with numpy scalars: per query feature in ascending
-    order probe the rank-bitmap, then apply the row (dense: every column with a weight; short: its pairs in stored order)
-    with a separate fp32 multiply and add."""
-    kMissing = 0x7FA5A5A5
-    R, ncols, off_rank, off_desc, off_bias = (int(img[k]) for k in (1, 2, 3, 4, 5))
+    order probe the rank-bitmap, then apply the row -- a dense row to every column (its weight, or the +0.0 it holds where
+    the row has no entry), a short row as the all-zero row plus its pairs in stored order -- with a separate fp32 multiply and add."""
+    R, ncols, off_rank, off_desc, off_bias, zero_row = (int(img[k]) for k in (1, 2, 3, 4, 5, 8))
+    npairs = (ncols + 1) // 2
     rank16 = img[off_rank:].view(np.uint16)
-    acc = np.zeros(ncols, dtype=np.float32)
+    assert not img[zero_row - 4:zero_row + 2 * (npairs + 1)].any()
+    acc = np.zeros(2 * (npairs + 1), dtype=np.float32)
     for f, v in zip(x_idx, x_val):
         if f >= w_rows:
             continue
         w = int(f) >> 6
-        bits = int(img[8 + 2 * w]) | (int(img[8 + 2 * w + 1]) << 32)
+        bits = int(img[12 + 2 * w]) | (int(img[12 + 2 * w + 1]) << 32)
         b = int(f) & 63
         if not (bits >> b) & 1:
             continue
         slot = int(rank16[w]) + bin(bits & ((1 << b) - 1)).count("1")
         assert slot < R
         d = int(img[off_desc + slot])
-        if d & 0x80000000:
-            row = img[(d & 0xFFFFFF):(d & 0xFFFFFF) + ncols + 1]
-            assert row[ncols] == kMissing
-            for c in range(ncols):
-                if row[c] != kMissing:
-                    acc[c] = np.float32(acc[c] + np.float32(np.float32(v) * row[c:c + 1].view(np.float32)[0]))
-        else:
+        row_at = (d & 0x3FFFFF) if d & 0x80000000 else zero_row
+        assert row_at % 2 == 0
+        row = img[row_at:row_at + 2 * (npairs + 1)].view(np.float32)
+        mask = img[row_at - 4:row_at]
+        for c in range(2 * (npairs + 1)):
+            present = c < ncols and (int(mask[c >> 5]) >> (c & 31)) & 1
+            assert present or row[c:c + 1].view(np.uint32)[0] == 0          # no entry <-> +0.0
+            acc[c] = np.float32(acc[c] + np.float32(np.float32(v) * row[c]))
+        if not d & 0x80000000:
             n = ((d >> 24) & 7) + 1
             base = d & 0xFFFFFF
             assert base % 2 == 0
             for k in range(n):
                 c = int(img[base + 2 * k]); wv = img[base + 2 * k + 1:base + 2 * k + 2].view(np.float32)[0]
                 acc[c] = np.float32(acc[c] + np.float32(np.float32(v) * wv))
-    return acc
+    assert not acc[ncols:].any()
+    return acc[:ncols]
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -100,9 +100,9 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         clib.set_option(m.model.model_chain, "k1g_min_items", 1 if trial == 0 else 16)   # dense X: tiled SGEMM forced / by batch size
         clib.set_option(m.model.model_chain, "k1g_variant", int(rng.integers(0, 2)))      # its alternative tile shapes
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
-        # tile-resident kernel (K1R): off / forced for every layer whose tile images fit in LDS, one or several workgroups per tile
+        # tile-resident kernel (K1R): off / forced for every layer whose tile images fit in LDS, short and long item runs
         clib.set_option(m.model.model_chain, "k1r_min_items", int(rng.choice([0, 1, 1])))
-        clib.set_option(m.model.model_chain, "k1r_split_items", int(rng.choice([1, 3, 4096])))
+        clib.set_option(m.model.model_chain, "k1r_items_per_block", int(rng.choice([16, 100, 1024])))
         # one or two row batches in flight (two streams), whole or ragged batches
         clib.set_option(m.model.model_chain, "overlap_min_rows", int(rng.choice([0, 2])))
         clib.set_option(m.model.model_chain, "max_batch_rows", int(rng.choice([0, 0, 7, 32])))

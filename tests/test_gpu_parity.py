@@ -87,13 +87,12 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
         clib.set_option(m.model.model_chain, "k2_legacy", 0)
         clib.set_option(m.model.model_chain, "k1_group", 0)
         # tile-resident kernel (K1R) forced on every layer whose tile images fit in LDS; one / several workgroups per tile
-        for spl in (4096, 1):
+        for ipb in (16, 1024):
             clib.set_option(m.model.model_chain, "k1r_min_items", 1)
-            clib.set_option(m.model.model_chain, "k1r_split_items", spl)
+            clib.set_option(m.model.model_chain, "k1r_items_per_block", ipb)
             P = m.predict(X, **c["kwargs"])
-            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1R split_items={spl}")
-        clib.set_option(m.model.model_chain, "k1r_min_items", 128)
-        clib.set_option(m.model.model_chain, "k1r_split_items", 4096)
+            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1R items_per_block={ipb}")
+        clib.set_option(m.model.model_chain, "k1r_min_items", 0)
         clib.set_option(m.model.model_chain, "dense_layers", 1)
 
 
@@ -146,7 +145,7 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
     assert ("k1r_sparse" in names) == (clib.xlinear_get_int_attr(m.model.model_chain, "nr_k1r_layers") > 0), names
     if name != "wiki10-31k":
         assert "k1r_sparse" in names, names
-    clib.set_option(m.model.model_chain, "k1r_min_items", 128)
+    clib.set_option(m.model.model_chain, "k1r_min_items", 0)
     clib.set_option(m.model.model_chain, "dense_layers", 1)
     assert_same_topk(m.predict(X, beam_size=5, only_topk=3, max_pred_chunk=37), ref.predict(X, beam_size=5, only_topk=3),
                      exact_scores=True, what="max_pred_chunk")
