@@ -156,7 +156,8 @@ def main():
     use_dist = dist.is_initialized()
     # packed rows [idx(k) | val(k) | cnt].  With a process group the shard is computed in two halves: the all-gather of the
     # first half runs on a second stream under the second half's kernels, the gather of the second half closes the step.
-    parts = 2 if (use_dist and rows >= 1024 and int(np.diff(bounds).min()) >= 2) else 1
+    # (decided from the GLOBAL bounds: every rank must issue the same collectives)
+    parts = 2 if (use_dist and int(np.diff(bounds).min()) >= 1024) else 1
     cstream = torch.cuda.Stream(device=dev) if parts == 2 else None
     ev_half = torch.cuda.Event() if parts == 2 else None
     with torch.cuda.stream(tstream):

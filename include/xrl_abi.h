@@ -290,8 +290,8 @@ int xrl_set_option(void* model, const char* key, int64_t value);
 void xrl_debug_k1_phases(unsigned long long* out8, int reset);
 
 /* Single-layer API (c_xlinear_single_layer_predict*): compiled one-layer handles are cached by the identity of the caller's
- * W / C value arrays (pointers, shapes, nnz, bias) plus a fingerprint of the contents of all arrays, at most 8 entries, least recently used
- * evicted.  Clear the cache after modifying W / C in place.  stats: cumulative hits / misses and live entries (tests). */
+ * W / C value arrays (pointers, shapes, nnz, bias) plus a 64-bit hash of EVERY byte of all their arrays (an in-place edit is seen on
+ * the next call), at most 8 entries, least recently used evicted.  stats: cumulative hits / misses and live entries (tests). */
 void xrl_single_layer_cache_clear(void);
 void xrl_single_layer_cache_stats(uint64_t* hits, uint64_t* misses, uint64_t* entries);
 

@@ -59,8 +59,10 @@ struct K1GArgs {
 };
 
 // one wavefront per dense query row: 1 = all values finite.  With finite x a missing weight may be multiplied as +0.0 -- the
-// product is +-0 and leaves every reachable accumulator unchanged (it is never -0.0: it starts at +0.0 + bias and x*w + (-x*w)
-// rounds to +0.0) -- so K1G's inner loop needs no select; rows with an inf / NaN take the exact loop.
+// product is +-0 and leaves every reachable accumulator unchanged (it is never -0.0: it starts at bias_prod = (+0.0) + fl32(bias * w),
+// which the model compiler computes exactly like that, so even a -0.0 product gives +0.0; and x*w + (-x*w) rounds to +0.0) --
+// so K1G's inner loop needs no select; rows with an inf / NaN take the exact loop.  (A weight whose bits equal kMissing keeps
+// the whole layer out of the dense format at load, xrl_model.cpp.)
 __global__ void __launch_bounds__(256) xfinite_kernel(const float* __restrict__ x, uint32_t rows, uint32_t cols, uint32_t row0, uint32_t* __restrict__ ok) {
     const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (r >= rows) return;

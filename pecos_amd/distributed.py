@@ -169,7 +169,9 @@ class ShardedXLinear:
             raise ValueError("X_local does not hold the rows bounds assign to this rank")
         idx, val, cnt = self._fn(X_local, beam_size, only_topk, post_processor)
         if self.world > 1:
-            pk = PackedTopk(bounds, self.rank, idx.shape[1], idx.device, parts=2 if X_local.shape[0] >= 4 else 1)
+            # `parts` must be the same on every rank (it fixes the number and shapes of the collectives): derive it from the
+            # GLOBAL bounds, never from this rank's row count (nnz-balanced shards are uneven)
+            pk = PackedTopk(bounds, self.rank, idx.shape[1], idx.device, parts=2 if int(np.diff(bounds).min()) >= 4 else 1)
             pk.store(idx, val, cnt)
             for p in range(pk.parts):
                 pk.gather(p, self.group)

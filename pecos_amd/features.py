@@ -45,7 +45,13 @@ def predict_from_torch(model, crow, col, val, n_cols, beam_size=None, only_topk=
     crow, col, val = crow.contiguous(), col.contiguous(), val.contiguous()
     rows = crow.numel() - 1
     nnz = int(val.numel())
-    torch.cuda.current_stream().synchronize()          # the inputs were produced on torch's stream
+    # outputs first: their zero-fills run on torch's current stream and must be complete (like the inputs, produced on that
+    # stream) before the predict starts on `stream`
+    k = clib.effective_topk(h, only_topk)
+    idx = torch.zeros((rows, k), dtype=torch.int32, device=val.device)
+    sc = torch.zeros((rows, k), dtype=torch.float32, device=val.device)
+    cnt = torch.zeros((rows,), dtype=torch.int32, device=val.device)
+    torch.cuda.current_stream().synchronize()
     if emb is not None:
         assert emb.is_cuda and emb.dtype == torch.float32 and emb.shape[0] == rows
         emb = emb.contiguous()
@@ -53,10 +59,6 @@ def predict_from_torch(model, crow, col, val, n_cols, beam_size=None, only_topk=
     else:
         q = clib.queries_from_device_csr(h, rows, n_cols, crow.data_ptr(), col.data_ptr(), val.data_ptr(), nnz)
     try:
-        k = clib.effective_topk(h, only_topk)
-        idx = torch.zeros((rows, k), dtype=torch.int32, device=val.device)
-        sc = torch.zeros((rows, k), dtype=torch.float32, device=val.device)
-        cnt = torch.zeros((rows,), dtype=torch.int32, device=val.device)
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         if rows:
             clib.predict_device(h, q, beam_size, post_processor, only_topk, idx.data_ptr(), sc.data_ptr(), cnt.data_ptr(), k,

@@ -46,6 +46,13 @@ def _worker(rank, world, port, out_dir):
     assert_same_topk(Pl, P, exact_scores=True, what=f"rank {rank} predict_shard")
     full = om.predict(X, beam_size=10, only_topk=10)
     assert_same_topk(P, full, exact_scores=True, what=f"rank {rank}")
+    # uneven shards around the "two parts" threshold (4 rows): every rank must issue the same collectives
+    for n in (7, 5, 9):
+        Xn = X[:n]
+        for b in ([0, 4, n], [0, n - 4, n], [0, 3, n]):
+            bb = np.asarray(b, dtype=np.int64)
+            Pn = sh.predict_shard(take_rows(Xn, int(bb[rank]), int(bb[rank + 1])), bb, beam_size=5, only_topk=4)
+            assert_same_topk(Pn, om.predict(Xn, beam_size=5, only_topk=4), exact_scores=True, what=f"rank {rank} uneven shards {b}")
     # ragged: more ranks than useful rows on one side (tiny X)
     P2 = sh.predict(X[:1], beam_size=3, only_topk=5)
     assert_same_topk(P2, om.predict(X[:1], beam_size=3, only_topk=5), exact_scores=True, what="one row")

@@ -359,6 +359,16 @@ def test_single_layer_predict(clib, oracle_mod):
     Pd = ours(X, dup, L1, "l3-hinge", 12)
     if have_ref:
         assert_same_topk(Pd, oracle_mod.ref_single_layer_predict(X, dup, L1["W"], L1["C"], "l3-hinge", 12, L1["bias"]), exact_scores=True, what="duplicate parents")
+    # an IN-PLACE edit of one weight (same arrays, same addresses) must be seen: the cache key covers every byte of W and C
+    Wm = L0["W"]
+    old = float(Wm.data[len(Wm.data) // 3])
+    Wm.data[len(Wm.data) // 3] = old + 7.5
+    Pe = ours(X, None, L0, "noop", 3)
+    if have_ref:
+        assert_same_topk(Pe, oracle_mod.ref_single_layer_predict(X, None, L0["W"], L0["C"], "noop", 3, L0["bias"]), exact_scores=True, what="W edited in place")
+    Wm.data[len(Wm.data) // 3] = old
+    assert_same_topk(ours(X, None, L0, "noop", 3), P0n := ours(X, None, L0, "noop", 3), exact_scores=True, what="restored")
+    assert not np.array_equal(Pe.toarray(), P0n.toarray())
     bad = smat.csr_matrix((np.ones(1, np.float32), np.array([L1["C"].shape[1]]), np.array([0, 1] + [1] * (X.shape[0] - 1))), shape=(X.shape[0], L1["C"].shape[1] + 1))
     with pytest.raises(RuntimeError):
         ours(X, bad, L1, "l3-hinge", 3)
