@@ -16,18 +16,23 @@ On the JSON line:
   value           queries/s with X resident in HBM when the timed region starts (the contract's `value`)
   value_host_abi  queries/s through the drop-in entry point c_xlinear_predict_csr_f32 -- pageable host X in, H2D,
                   kernels, D2H, allocator callback, host CSR out -- the figure SURVEY.md 8(d) specifies (N=1 only)
-  roofline        the kernel family with the most GPU time.  `achieved` = MATCHED-WORK bytes per launch / average launch
-                  duration (hipEvent pairs recorded around every launch on the stream it runs on, during the timed steps).
-                  Matched work = the bytes the algorithm addresses for the rows a query actually matches, NO inter-query
-                  reuse assumed (every item re-reads its query row, its lookups, its matched rows):
-                    tile format (K1):   per (query, tile) item  8*nnz_x + probe_bytes*nnz_x + 4*hit_rows + 8*hit_entries + 4*ncols
-                    dense format (K1Q): per query  8*nnz_x (dense X: 4*D)  + 4 * sum over (feature, candidate column) + 16*beam
-                  counted by an untimed stats pass (xrl_predict_stats).  A layer structure that FITS the 288 MB of on-chip
-                  cache (Infinity Cache + L2; every layer of Eurlex-4K) is not re-read from HBM by every query: for such a
-                  layer the HBM-level figure is its compulsory traffic (the structure once + queries + beams + scores), and
-                  the matched-work rate is reported against the L2 peak in `l2` instead.  `alg_bytes_ref_layout` keeps SURVEY.md 8(d)'s own
-                  figure (every active REFERENCE chunk streamed whole) -- an upper bound no implementation that looks rows
-                  up needs to move, which is why round 1's frac came out as 34.  `kernels` lists every launch family.
+  roofline        the kernel family with the most GPU time (hipEvent pairs around every launch on the stream it runs on, during the
+                  timed steps).  Three fractions of the 8 TB/s HBM peak, side by side, because they answer different questions:
+                    frac            COUNTER bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, separate --pmc passes over this same
+                                    command, committed as profiles/pmc_traffic.json; fabric requests x 64 B, Infinity-Cache hits
+                                    included) / launch time.  This is the HBM-roofline fraction.  If no counter file matches the
+                                    configuration the line says so (`basis`) and falls back to frac_matched.
+                    frac_matched    MATCHED-WORK bytes / launch time: the bytes the algorithm addresses for the rows a query actually
+                                    matches, no inter-query reuse assumed (tile format: per (query, tile) item 8*nnz_x + probe bytes
+                                    + 4*hit_rows + 8*hit_entries + 4*ncols; dense format: per query 8*nnz_x + 4 * sum over (feature,
+                                    candidate column) + 16*beam), counted by an untimed stats pass.  Contains cache hits: can exceed
+                                    what HBM streams.
+                    frac_ref_layout SURVEY.md 8(d)'s own figure (every active REFERENCE chunk streamed whole) / step time.  It is >> 1:
+                                    the kernels look rows up instead of streaming chunks, so this model does not describe them.
+                  `requests` is the roof the memory side actually sits on (fabric read requests/s against the ceiling calibrated in
+                  profiles/r02_calib_fetch.md), `issue` the VALU-issue occupancy from the SQ counters (1 wavefront instruction per 4
+                  cycles per SIMD) -- on this workload the binding limit (profiles/r03_k1r_experiments.txt).  A layer structure that
+                  FITS the 288 MB of on-chip cache is reported against the L2 peak in `l2`.  `kernels` lists every launch family.
   cpu_baseline    the REAL reference (oracle/_ref, compiled from /root/reference's own sources) on this box's host cores,
                   bounded sample of the same workload, 1 warm-up + median of 5 calls (rank 0, N=1 only).
 """
@@ -43,6 +48,9 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 L2_PEAK_GBPS = 34500.0          # MI355X_MICROARCH.md: ~34.5 TB/s aggregate L2
 ONCHIP_CACHE_BYTES = 256e6 + 32e6  # MI355X_MICROARCH.md: 256 MB Infinity Cache + 8 x 4 MB L2
+FABRIC_REQ_CEILING_G = 57.0     # profiles/r02_calib_fetch.md: fabric read requests/s sustained by narrow gathers (51 G/s HBM .. 59 G/s Infinity Cache)
+SHADER_CLOCK_HZ = 2.4e9         # MI355X_MICROARCH.md
+N_CU, N_SIMD = 256, 1024
 
 
 def log(*a):
@@ -64,6 +72,10 @@ def main():
     ap.add_argument("--no-host-abi", action="store_true")
     ap.add_argument("--no-stats", action="store_true", help="skip the untimed matched-work stats pass (PMC collection runs: only the timed kernels launch)")
     ap.add_argument("--host-steps", type=int, default=5)
+    ap.add_argument("--include-upload", action="store_true",
+                    help="time the drop-in entry point instead: every rank calls c_xlinear_predict_* on ITS shard (pageable host X in, H2D, kernels, "
+                         "D2H, host CSR out); value = all queries / max-over-ranks time (what a caller that shards by process gets, PCIe included)")
+    ap.add_argument("--parity-rows", type=int, default=4096, help="rows per shard of the TIMED output compared with the reference after the timed loop (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--k1-group", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="library option key=int (xrl_set_option), repeatable")
@@ -143,6 +155,9 @@ def main():
     bounds = shard_bounds(X, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     Xs = take_rows(X, lo, hi)
+    # rows of the TIMED output that rank 0 compares with the reference afterwards: the first --parity-rows rows of EVERY shard
+    par_sel = np.concatenate([np.arange(int(bounds[r]), min(int(bounds[r + 1]), int(bounds[r]) + max(0, args.parity_rows))) for r in range(world)]).astype(np.int64)
+    Xpar = (X[par_sel] if sparse else np.ascontiguousarray(X[par_sel])) if (rank == 0 and len(par_sel)) else None
     if world > 1:
         del X
     q = clib.queries_upload(h, Xs)
@@ -163,7 +178,17 @@ def main():
     with torch.cuda.stream(tstream):
         pk = PackedTopk(bounds, rank, k, dev, parts=parts)
 
-    def step():
+    view = (ScipyCsrF32.init_from(Xs) if sparse else ScipyDrmF32.init_from(Xs)) if args.include_upload else None
+    last_host = [None]
+
+    def step_upload():
+        # the drop-in entry point on this rank's shard: pageable host X in, H2D, kernels, D2H, allocator callback, host CSR out
+        alloc = ScipyCompressedSparseAllocator()
+        if rows:
+            clib.xlinear_predict(h, view, beam, None, args.topk, -1, alloc)
+            last_host[0] = alloc
+
+    def step_resident():
         for p in range(parts):
             with torch.cuda.stream(tstream):
                 b, e = pk.rows(p)
@@ -180,6 +205,8 @@ def main():
                     pk.gather(0)                           # overlaps the second half's kernels
         if parts == 2:
             tstream.wait_stream(cstream)
+
+    step = step_upload if args.include_upload else step_resident
 
     def sync_all():
         torch.cuda.synchronize()
@@ -206,6 +233,32 @@ def main():
         dt = float(tt.item())
     prof = clib.profile_get(h)
 
+    # ---- what the TIMED steps produced, compared with the reference on rows of every shard (rank 0)
+    timed_parity = None
+    if len(par_sel):
+        n_sel = [int(min(int(bounds[r + 1]), int(bounds[r]) + max(0, args.parity_rows)) - int(bounds[r])) for r in range(world)]
+        if args.include_upload:
+            mine = last_host[0].get()[: n_sel[rank]] if (last_host[0] is not None and n_sel[rank]) else None
+            pieces = [mine]
+            if use_dist and world > 1:
+                pieces = [None] * world if rank == 0 else None
+                dist.gather_object(mine, pieces, dst=0)
+            if rank == 0:
+                G = smat.vstack([pc for pc in pieces if pc is not None], format="csr")
+        else:
+            if not use_dist:
+                with torch.cuda.stream(tstream):
+                    for p in range(parts):
+                        pk.gather(p)                       # no process group: copies the send buffers into the receive side
+            torch.cuda.synchronize()
+            if rank == 0:
+                gi, gv, gc = pk.unpack()
+                from pecos_amd.distributed import rows_to_csr
+                sel_t = torch.from_numpy(par_sel).to(gi.device)
+                G = rows_to_csr(gi[sel_t].cpu().numpy().view(np.uint32), gv[sel_t].cpu().numpy(), gc[sel_t].cpu().numpy(), model.nr_pred_cols)
+        if rank == 0:
+            timed_parity = timed_output_parity(folder, Xpar, G, beam, args.topk, world, args.parity_rows, log)
+
     out = None
     if rank == 0:
         ms_per_step = dt / max(1, args.steps) * 1e3
@@ -221,8 +274,10 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                    scaling="strong", vs_baseline=None, dtype="f32", data="synthetic", config=cfg_out, roofline=roof)
 
+        if args.include_upload:
+            cfg_out["mode"] = "include-upload: every rank times c_xlinear_predict_* on its shard (pageable host X in, H2D, kernels, D2H, host CSR out); no gather"
         # ---- the SURVEY 8(d) figure: the drop-in C-ABI entry point, pageable host X in, host CSR out (N=1)
-        if world == 1 and not args.no_host_abi:
+        if world == 1 and not args.no_host_abi and not args.include_upload:
             view = ScipyCsrF32.init_from(Xs) if sparse else ScipyDrmF32.init_from(Xs)
             times = []
             for it in range(1 + max(1, args.host_steps)):
@@ -243,6 +298,8 @@ def main():
         # ---- CPU baseline + parity on a bounded sample (N=1 only)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(folder, Xs, model, beam, args.topk, args.cpu_seconds, log)
+        if timed_parity is not None:
+            out["parity"] = dict(out.get("parity") or {}, **timed_parity)
         print(json.dumps(out), flush=True)
 
     clib.queries_free(q)
@@ -318,12 +375,13 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
     step_bytes = sum(kk["alg_bytes"] for kk in kernels)
     matched_rate = fam[dom]["matched"] / max(1, fam[dom]["launches"]) / (avg_ms * 1e-3) / 1e9
     cache_resident = fam[dom]["matched"] > fam[dom]["bytes"] * 1.0001
-    traffic, tsrc, l2 = None, None, None
+    traffic, tsrc, l2, requests, issue = None, None, None, None, None
     tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")     # written from separate rocprofv3 --pmc passes (scripts/pmc_traffic.py)
+    pmc_family = "k1q_dense" if dom.startswith("k1q") else dom
     if os.path.exists(tfile):
         tj = json.load(open(tfile))
-        ent = tj.get("kernels", {}).get(dom)
-        if tj.get("config") == args.config and tj.get("scale") == args.scale and tj.get("n_gpus") == world and ent:
+        ent = tj.get("kernels", {}).get(pmc_family)
+        if tj.get("config") == args.config and tj.get("scale") == args.scale and tj.get("n_gpus") == world and ent and not args.opt and not args.include_upload:
             traffic, tsrc = ent.get("hbm_bytes_per_launch"), tj.get("source")
             if ent.get("l2_read_req_per_launch"):
                 req = ent["l2_read_req_per_launch"]
@@ -331,6 +389,20 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
                 l2 = dict(bound="l2", read_requests_per_launch=req, request_bytes=64, achieved=round(l2b, 1), peak=L2_PEAK_GBPS, unit="GB/s",
                           frac=round(l2b / L2_PEAK_GBPS, 4), requests_per_s_G=round(req / (avg_ms * 1e-3) / 1e9, 1),
                           note="TCP_TCC_READ_REQ (L1->L2 read requests) x 64 B / launch time; the gathers of this kernel use 8-16 B of every request")
+            if ent.get("fabric_read_req_per_launch"):
+                fr = ent["fabric_read_req_per_launch"]
+                rate = fr / (avg_ms * 1e-3) / 1e9
+                requests = dict(fabric_read_req_per_launch=fr, fabric_req_per_s_G=round(rate, 1), ceiling_G=FABRIC_REQ_CEILING_G, frac=round(rate / FABRIC_REQ_CEILING_G, 3),
+                                note="L2 misses (TCC_MISS) / launch time against the fabric read-request ceiling measured with 8-byte gathers "
+                                     "(profiles/r02_calib_fetch.md: 51 G/s from HBM, 59 G/s from the Infinity Cache; 57 used)")
+            if ent.get("valu_insts_per_launch"):
+                cu_cycles = avg_ms * 1e-3 * SHADER_CLOCK_HZ
+                issue = dict(valu_insts_per_launch=ent["valu_insts_per_launch"], salu_insts_per_launch=ent.get("salu_insts_per_launch"),
+                             valu_busy_frac=round(ent.get("valu_active_quad_cycles_per_launch", 0.0) * 4.0 / (cu_cycles * N_SIMD), 3),
+                             salu_issue_frac=round((ent.get("salu_insts_per_launch") or 0.0) / (cu_cycles * N_CU), 3),
+                             note="SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (launch time x 2.4 GHz x 1024 SIMDs); SQ_INSTS_SALU / (launch time x 2.4 GHz x 256 CUs: "
+                                  "one scalar issue per CU per cycle).  A wavefront VALU instruction occupies its SIMD for 4 cycles, so instruction COUNT per "
+                                  "query is what these kernels run on (profiles/r03_k1r_experiments.txt)")
     if l2 is None and cache_resident:
         l2 = dict(bound="l2", achieved=round(matched_rate, 1), peak=L2_PEAK_GBPS, unit="GB/s", frac=round(matched_rate / L2_PEAK_GBPS, 4),
                   note="the structure this kernel gathers from fits the on-chip cache: matched-work bytes (no inter-query reuse) / launch time against the L2 peak")
@@ -347,13 +419,25 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
                           "so MFMA (fused) cannot be used and half the fp32 peak is the reachable rate",
                     per_kernel_ms_per_step={n: round(v["ms"] / max(1, args.steps), 4) for n, v in fam.items()}, kernels=kernels,
                     work=[dict(layer=l, **{kk: st[l][kk] for kk in ("items", "probes", "hit_rows", "hit_entries", "candidates")}) for l in range(len(st))])
-    return dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4),
-                traffic=traffic, traffic_source=tsrc, l2=l2,
+    ref_layout = (sum(s_["ref_chunk_bytes"] + 4.0 * s_["candidates"] for s_ in st) + x_bytes_q) if st else None
+    if traffic is not None:
+        ach_c = traffic / (avg_ms * 1e-3) / 1e9
+        head = dict(achieved=round(ach_c, 1), frac=round(ach_c / HBM_PEAK_GBPS, 4),
+                    basis="pmc: rocprofv3 FETCH_SIZE + WRITE_SIZE per launch (profiles/pmc_traffic.json) / hipEvent launch time measured in this run")
+    else:
+        head = dict(achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBPS, 4),
+                    basis="matched-work bytes (no counter file for this configuration / option set): NOT an HBM fraction, see frac_matched")
+    return dict(bound="hbm", kernel=dom, **head, peak=HBM_PEAK_GBPS, unit="GB/s",
+                traffic=traffic, traffic_source=tsrc,
+                frac_matched=round(matched_rate / HBM_PEAK_GBPS, 4), matched_gbps=round(matched_rate, 1),
+                frac_ref_layout=round(ref_layout / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 2) if ref_layout else None,
+                frac_ref_layout_note="SURVEY.md 8(d): every active reference chunk streamed whole, over the whole step; > 1 because chunks are looked up, not streamed",
+                requests=requests, issue=issue, l2=l2,
                 alg_bytes_per_launch=per_launch, avg_launch_ms=round(avg_ms, 4), launches_per_step=launches_per_step,
-                model="matched work, no inter-query reuse, for layer structures larger than the 288 MB of on-chip cache; compulsory bytes "
-                      "(structure once + queries + beams + scores) for cache-resident ones (see bench.py docstring / DESIGN.md section 5)",
-                matched_gbps=round(matched_rate, 1), step_alg_bytes=step_bytes, step_gbps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                alg_bytes_ref_layout=(sum(s["ref_chunk_bytes"] + 4.0 * s["candidates"] for s in st) + x_bytes_q) if st else None,
+                model="frac: counter bytes; frac_matched: matched work, no inter-query reuse (compulsory bytes for cache-resident structures); "
+                      "frac_ref_layout: SURVEY 8(d) chunk streaming (see bench.py docstring / DESIGN.md section 4)",
+                step_alg_bytes=step_bytes, step_gbps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                alg_bytes_ref_layout=ref_layout,
                 per_kernel_ms_per_step={n: round(v["ms"] / max(1, args.steps), 4) for n, v in fam.items()},
                 kernels=kernels,
                 work=[dict(layer=l, **{kk: st[l][kk] for kk in ("items", "probes", "hit_rows", "hit_entries", "candidates")}) for l in range(len(st))])
@@ -365,6 +449,26 @@ def baseline_metric():
         return json.load(open(os.path.join(REPO, "BASELINE.json")))["metric"]
     except Exception:
         return "XLinear queries/sec @ beam=10 top-k=10; P@1 vs reference; 1/2/4/8 GPU"
+
+
+def timed_output_parity(folder, Xpar, G, beam, topk, world, rows_per_shard, log):
+    """The buffers the TIMED steps filled (after the all-gather at N > 1), rows of every shard, against the reference
+    (oracle/_ref when present, else the C restatement on fewer rows): label ids, order and fp32 score bits."""
+    import numpy as np
+    from oracle import xrl_oracle as O
+    if O.ref_available():
+        ref, kind, n = O.RefModel(folder), "reference BINARY_SEARCH_CHUNKED", Xpar.shape[0]
+        P = ref.predict(Xpar, beam_size=beam, only_topk=topk, threads=min(os.cpu_count() or 1, 32))
+    else:
+        ref, kind, n = O.OracleModel.load(folder), "C restatement (oracle/_ref absent)", min(Xpar.shape[0], 512)
+        P = ref.predict(Xpar[:n], beam_size=beam, only_topk=topk)
+        G = G[:n]
+    same_rows = np.array_equal(G.indptr, P.indptr)
+    same_idx = bool(same_rows and np.array_equal(G.indices, P.indices))
+    bit = bool(same_idx and np.array_equal(G.data.astype(np.float32).view(np.uint32), P.data.astype(np.float32).view(np.uint32)))
+    log(f"timed output vs {kind}: {n} rows ({rows_per_shard} per shard x {world}): indices identical={same_idx} scores bit-identical={bit}")
+    return dict(timed_output_identical=bool(same_idx and bit), timed_output_sample=f"first {rows_per_shard} rows of each of the {world} shard(s) = {n} rows, "
+                f"read back from the buffers the timed steps wrote, vs {kind}", timed_output_indices_identical=same_idx, timed_output_scores_bit_identical=bit)
 
 
 def cpu_baseline(folder, X, model, beam, topk, budget_s, log):

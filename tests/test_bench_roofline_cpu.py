@@ -24,7 +24,7 @@ class _FakeClib:
 
 
 def _args(config="amazon-670k", scale=1.0, steps=100):
-    return argparse.Namespace(topk=10, no_stats=False, steps=steps, config=config, scale=scale)
+    return argparse.Namespace(topk=10, no_stats=False, steps=steps, config=config, scale=scale, opt=[], include_upload=False)
 
 
 def _recorded(name):
@@ -62,6 +62,9 @@ def test_roofline_function_on_synthetic_counters():
     r = bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, _args(config="unit-test", steps=10), k, rows, 1, 2.2)
     assert r["bound"] == "hbm" and r["kernel"] == "k1_sparse" and r["traffic"] is None
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # no counter file for this configuration: the line says that its frac is the matched-work one, and carries the other two models
+    assert r["basis"].startswith("matched-work") and abs(r["frac"] - r["frac_matched"]) < 1e-3 and r["requests"] is None and r["issue"] is None
+    assert r["frac_ref_layout"] is not None and abs(r["frac_ref_layout"] - r["alg_bytes_ref_layout"] / 2.2e-3 / 1e9 / r["peak"]) < 0.01
     kern = {(e["name"], e["layer"]): e for e in r["kernels"]}
     # the 3 GB tile structure is larger than the on-chip cache: matched work is the HBM-level figure
     assert kern[("k1_sparse", 1)]["alg_bytes"] == kern[("k1_sparse", 1)]["matched_bytes"]
@@ -85,3 +88,29 @@ def test_dense_query_line_is_priced_on_flops():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
     assert abs(r["flops_per_launch"] - 2.0 * 64 * 32 * 16) < 1e-6
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+
+
+def test_counter_based_frac_when_the_counter_file_matches():
+    # profiles/pmc_traffic.json is keyed by (config, scale, n_gpus): for that configuration `frac` is counter bytes / launch time,
+    # the request and issue roofs are attached, and frac_matched / frac_ref_layout stand beside it
+    tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+    fam = "k1_sparse" if "k1_sparse" in tj["kernels"] else sorted(tj["kernels"])[0]
+    ent = tj["kernels"][fam]
+    rows, k = 1000, 10
+    X = smat.random(rows, 5000, density=0.01, format="csr", dtype=np.float32, random_state=0)
+    stats = [dict(ref_chunk_bytes=5e10, candidates=rows * 800.0, items=rows * 10.0, probes=float(X.nnz) * 10, hit_rows=float(X.nnz) * 4,
+                  hit_entries=float(X.nnz) * 60, item_cols=rows * 800.0, x_cols=float(X.nnz) * 800)]
+    linfo = [dict(lookup=2, bucket_levels=0, dense=0, dense_bytes=0, device_bytes=3_000_000_000)]
+    ms = 9.0
+    prof = [dict(name=fam if not fam.startswith("k1q") else "k1q_fused_0_0", layer=0, ms=ms * 10, launches=10)]
+    r = bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, _args(config=tj["config"], scale=tj["scale"], steps=10), k, rows, tj["n_gpus"], 9.5)
+    assert r["basis"].startswith("pmc") and r["traffic"] == ent["hbm_bytes_per_launch"]
+    assert abs(r["achieved"] - ent["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9) < 1.0 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    assert r["frac_matched"] is not None and r["frac_ref_layout"] is not None
+    if ent.get("fabric_read_req_per_launch"):
+        assert abs(r["requests"]["fabric_req_per_s_G"] - ent["fabric_read_req_per_launch"] / (ms * 1e-3) / 1e9) < 0.1
+    if ent.get("valu_insts_per_launch"):
+        assert 0.0 < r["issue"]["valu_busy_frac"] < 2.0
+    # tuning options or the upload mode change what runs: the recorded counters then do not apply
+    a2 = _args(config=tj["config"], scale=tj["scale"], steps=10); a2.opt = ["k1r_min_items=1"]
+    assert bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, a2, k, rows, tj["n_gpus"], 9.5)["traffic"] is None

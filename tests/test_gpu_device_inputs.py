@@ -66,6 +66,51 @@ def test_device_resident_queries_and_concat():
     assert nrm.shape == host_cat.shape and np.allclose(np.asarray(nrm[:, D - H:].multiply(nrm[:, D - H:]).sum(axis=1)).ravel(), 1.0, atol=1e-5)
 
 
+def test_predict_device_rows_ranges_vs_oracle(oracle_mod):
+    # xrl_predict_device_rows (what bench.py's timed step and the sharded path call): arbitrary row ranges with row_begin > 0,
+    # results landing at the SAME rows of the caller's buffers (rows outside the range untouched), sparse and dense X, tile-format
+    # and dense-format kernels, against the CPU oracle -- label ids, order and score bits
+    import torch
+    from pecos_amd import XLinearModel, clib
+    from pecos_amd.distributed import PackedTopk
+    folder = os.path.join(GOLDEN, "synth", "s_eurlex")
+    X = load_X(os.path.join(GOLDEN, "synth", "s_eurlex__X.npz"))
+    X = smat.vstack([X, X[::-1]]).tocsr(); X.sort_indices()
+    n = X.shape[0]
+    m = XLinearModel.load(folder)
+    om = oracle_mod.OracleModel.load(folder)
+    h = m.model.model_chain
+    dev = torch.device("cuda", 0)
+    kw = dict(beam_size=6, only_topk=9)
+    k = clib.effective_topk(h, 9)
+    for Xq in (X, np.ascontiguousarray(X.toarray())):
+        want = om.predict(Xq, **kw)
+        q = clib.queries_upload(h, Xq)
+        for dl in (1, 0):
+            clib.set_option(h, "dense_layers", dl)
+            for (b, e) in ((0, n), (1, n), (n // 3, n // 3 + 1), (n // 2, n), (7, n - 5), (n - 1, n), (n, n)):
+                idx = torch.full((n, k), -1, dtype=torch.int32, device=dev); sc = torch.full((n, k), -7.0, dtype=torch.float32, device=dev)
+                cnt = torch.full((n,), -3, dtype=torch.int32, device=dev)
+                torch.cuda.synchronize()
+                clib.predict_device_rows(h, q, 6, None, 9, idx.data_ptr(), sc.data_ptr(), cnt.data_ptr(), k, b, e - b, sync=True)
+                got = _rows_to_csr(idx[b:e], sc[b:e], cnt[b:e], m.nr_pred_cols)
+                assert_same_topk(got, want[b:e], exact_scores=True, what=f"rows [{b},{e}) dense_layers={dl} dense_x={not smat.issparse(Xq)}")
+                out = torch.ones(n, dtype=torch.bool, device=dev); out[b:e] = False
+                assert bool((cnt[out] == -3).all()) and bool((idx[out] == -1).all()), "rows outside the range were written"
+        clib.set_option(h, "dense_layers", 1)
+        # the packed two-part layout bench.py uses: absolute local row indexing into per-part buffers
+        bounds = np.array([0, n])
+        pk = PackedTopk(bounds, 0, k, dev, parts=2)
+        for p in range(2):
+            b, e = pk.rows(p)
+            pi, pv, pc, ps = pk.pointers(p)
+            clib.predict_device_rows(h, q, 6, None, 9, pi, pv, pc, ps, b, e - b, sync=True)
+            pk.gather(p)
+        gi, gv, gc = pk.unpack()
+        assert_same_topk(_rows_to_csr(gi, gv, gc, m.nr_pred_cols), want, exact_scores=True, what="PackedTopk two parts")
+        clib.queries_free(q)
+
+
 def test_async_predicts_on_two_streams_share_the_handle():
     # xrl_predict_device(sync=0) on two caller streams: the handle's scratch buffers are shared, so the second predict must be
     # ordered after the first (event recorded at the end of every predict); both results equal the synchronous ones

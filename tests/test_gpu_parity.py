@@ -543,6 +543,88 @@ def test_full_size_vs_reference(name, XLM, clib, oracle_mod, tmp_path):
         assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{name} full size, dense_layers={dl}")
 
 
+def _bench_workload(name, cache=None):
+    """The folder bench.py generates / re-uses for a workload at scale 1.0 (so that the driver's pytest and bench runs build it once)."""
+    import json
+    import xrl_synth
+    folder = os.path.join(cache or os.environ.get("XRL_BENCH_CACHE", "/tmp/xrl_bench"), f"{name}_1.0")
+    if not os.path.exists(os.path.join(folder, ".done")):
+        os.makedirs(folder, exist_ok=True)
+        ks, X, cfg = xrl_synth.make_config(name, folder, scale=1.0)
+        if smat.issparse(X):
+            smat.save_npz(os.path.join(folder, "X.npz"), X, compressed=False)
+        else:
+            np.save(os.path.join(folder, "X.npy"), X)
+        json.dump({"ks": ks, "cfg": cfg}, open(os.path.join(folder, "meta.json"), "w"))
+        open(os.path.join(folder, ".done"), "w").write("ok")
+    meta = json.load(open(os.path.join(folder, "meta.json")))
+    return folder, meta["ks"], meta["cfg"]
+
+
+@pytest.mark.timeout(1500)
+def test_headline_config_full_size_all_rows_vs_reference(XLM, clib, oracle_mod):
+    # BASELINE.json configs[3], the configuration the target is quoted on, at FULL size: Amazon-670K shape, N = 490 000 queries,
+    # D = 135 000, L = 670 091, tree [2, 32, 512, 8192, 670091], beam 10, top-k 10 -- EVERY row against the compiled reference
+    # (test/pecos/xmc/xlinear/test_xlinear.py:106-245 in spirit): label ids, order and fp32 score bits.  The default policy runs the
+    # kernel instantiations bench.py times (fused k1q_kernel<3,0,false,true> over levels 0-3, leaf k1_kernel<32,3,0,false,2>);
+    # dense_layers=0 sends every level through the tile-format kernels, k1r_min_items=1 the leaf through the tile-resident kernel.
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref (the compiled reference) is not built: 490 k rows are out of reach of the single-threaded restatement")
+    folder, ks, cfg = _bench_workload("amazon-670k")
+    X = smat.load_npz(os.path.join(folder, "X.npz")).tocsr().astype(np.float32); X.sort_indices()
+    assert X.shape == (490000, 135000) and ks == [2, 32, 512, 8192, 670091]
+    kw = dict(beam_size=10, only_topk=10)
+    want = oracle_mod.RefModel(folder).predict(X, threads=min(os.cpu_count() or 1, 64), **kw)
+    m = XLM.load(folder)
+    h = m.model.model_chain
+    clib.profile_enable(h, True); clib.profile_reset(h)
+    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, default policy")
+    names = {r["name"] for r in clib.profile_get(h)}
+    clib.profile_enable(h, False)
+    assert "k1q_fused_0_3" in names and "k1_sparse" in names, names
+    clib.set_option(h, "dense_layers", 0)
+    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, tile format everywhere")
+    clib.set_option(h, "dense_layers", 1)
+    if clib.xlinear_get_int_attr(h, "nr_k1r_layers") > 0:
+        clib.set_option(h, "k1r_min_items", 1)
+        assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, tile-resident leaf (K1R)")
+        clib.set_option(h, "k1r_min_items", 0)
+
+
+@pytest.mark.timeout(2400)
+def test_dense768_full_size_model_vs_reference(XLM, clib, oracle_mod, tmp_path):
+    # BASELINE.json configs[4] with the FULL-size model (D = 768 dense fp32 queries, L = 3 000 000, tree [8, 128, 2048, 32768, 3 M],
+    # 17 GB on the GPU): 32 768 queries, every one against the compiled reference -- the tiled SGEMM K1G on every level by default,
+    # the query-stationary kernel on a slice.  XRL_SKIP_HUGE=1 skips it (builder iterations: the model takes minutes to generate).
+    if os.environ.get("XRL_SKIP_HUGE") == "1":
+        pytest.skip("XRL_SKIP_HUGE=1")
+    if not oracle_mod.ref_available():
+        pytest.skip("oracle/_ref (the compiled reference) is not built")
+    import xrl_synth
+    cfg = xrl_synth.CONFIGS["dense-768"]
+    folder = os.path.join(os.environ.get("XRL_BENCH_CACHE", "/tmp/xrl_bench"), "dense-768_1.0")
+    if os.path.exists(os.path.join(folder, ".done")):
+        ks = xrl_synth.tree_shape(cfg["L"])
+    else:
+        folder = str(tmp_path / "m")
+        ks = xrl_synth.make_model(folder, cfg["D"], cfg["L"], cfg["w_nnz"], seed=0)
+    assert ks == [8, 128, 2048, 32768, 3000000]
+    X = xrl_synth.make_queries(32768, cfg["D"], None, seed=1)
+    kw = dict(beam_size=10, only_topk=10)
+    m = XLM.load(folder)
+    h = m.model.model_chain
+    clib.profile_enable(h, True); clib.profile_reset(h)
+    P = m.predict(X, **kw)
+    names = {r["name"] for r in clib.profile_get(h)}
+    clib.profile_enable(h, False)
+    assert "k1g_dense_x" in names, names
+    want = oracle_mod.RefModel(folder).predict(X, threads=min(os.cpu_count() or 1, 64), **kw)
+    assert_same_topk(P, want, exact_scores=True, what="dense-768 full-size model, 32768 queries (K1G)")
+    clib.set_option(h, "k1g_min_items", 0)
+    assert_same_topk(m.predict(X[:2048], **kw), want[:2048], exact_scores=True, what="dense-768 full-size model, query-stationary kernels")
+    clib.set_option(h, "k1g_min_items", 16)
+
+
 def test_dense_input_config_vs_reference(XLM, clib, oracle_mod, tmp_path):
     # BASELINE.json configs[4] (dense fp32 X, D=768) at a tenth of its label count: N=50k x 768, L=300k, tree
     # [16, 256, 4096, 300000].  Every layer fits the dense row format, so the whole beam search runs in K1Q with dense
