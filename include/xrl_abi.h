@@ -189,10 +189,19 @@ void* xrl_queries_from_device_csr(void* model, uint32_t rows, uint32_t cols, con
 void* xrl_queries_from_device_drm(void* model, uint32_t rows, uint32_t cols, const float* d_val);
 /* The query form of XR-Transformer's concat_model (TransformerMatcher.concat_features + smat_util.hstack_csr,
  * pecos/xmc/xtransformer/matcher.py:864-890, model.py:589-603): [X_feat (device CSR, sparse_cols columns) | X_emb (device dense
- * rows x dense_cols, already normalised by the caller)] assembled into one device CSR owned by the returned handle. */
+ * rows x dense_cols)] assembled into one device CSR owned by the returned handle; every cell of the dense block becomes a stored
+ * entry (zeros included), as smat_util.dense_to_csr does.  _ex with normalize_emb != 0 also applies sklearn's row-wise l2
+ * normalize to X_emb on the device (the reference's default, matcher.py:879-880; values agree to ~1e-7 relative). */
 void* xrl_queries_concat_device(void* model, uint32_t rows, uint32_t sparse_cols, const uint64_t* d_row_ptr,
                                 const uint32_t* d_col_idx, const float* d_val, uint64_t nnz, uint32_t dense_cols,
                                 const float* d_emb, void* hip_stream);
+void* xrl_queries_concat_device_ex(void* model, uint32_t rows, uint32_t sparse_cols, const uint64_t* d_row_ptr,
+                                   const uint32_t* d_col_idx, const float* d_val, uint64_t nnz, uint32_t dense_cols,
+                                   const float* d_emb, int normalize_emb, void* hip_stream);
+/* Shape of a query handle: out4 = {rows, cols, stored values (nnz, or rows x cols for a dense one), dense (0/1)}; and a copy of its
+ * arrays back to the host (tests, debugging): CSR handles fill row_ptr[rows+1] / col_idx[nnz] / val[nnz], dense ones val[rows x cols]. */
+int xrl_queries_info(void* queries, uint64_t* out4);
+int xrl_queries_download(void* queries, uint64_t* row_ptr, uint32_t* col_idx, float* val);
 void xrl_queries_free(void* queries);
 
 /* Beam search with inputs already resident in HBM.  Writes fixed-stride results

@@ -99,6 +99,12 @@ static int orc_cand_cmp(const void* a, const void* b) {
  *   out_*:  new beam, stride `out_stride` (>= k).
  * Returns 0, or -1 on allocation failure / bad shape.
  */
+/* weight_matrix_type HASH_CHUNKED with sparse X: chunk_ops<csr, hash_chunked> (inference.hpp:705-735) adds the bias row FIRST
+ * and then the query's features in ascending order (the hash map only replaces the row lookup); set by the tests that pin
+ * that layout.  Dense X under the hash layout walks the hash map in ITS order (:737-768) -- not restated. */
+static int orc_hash_arith = 0;
+void orc_set_hash_arith(int on) { orc_hash_arith = on; }
+
 int orc_layer_predict(const orc_layer_t* L, uint32_t n_rows,
                       const uint64_t* x_indptr, const uint32_t* x_idx, const float* x_val,
                       const float* x_dense, uint32_t x_cols,
@@ -155,12 +161,13 @@ int orc_layer_predict(const orc_layer_t* L, uint32_t n_rows,
                     }
                 } else {
                     /* chunk_ops<csr, bin_search>, inference.hpp:769-813: matched rows ascending,
-                     * out += x_f * w (mul then add, :512-517); bias last (:806-811) */
+                     * out += x_f * w (mul then add, :512-517); bias last (:806-811) -- or first, hash layout (:716-722) */
+                    if (has_bias && orc_hash_arith) { float pr = L->bias * W->val[ce - 1]; acc = acc + pr; }
                     for (uint64_t e = cb; e < ce_nb; ++e) {
                         const uint32_t f = W->row_idx[e];
                         if (touched[f]) { float pr = xs[f] * W->val[e]; acc = acc + pr; }
                     }
-                    if (has_bias) { float pr = L->bias * W->val[ce - 1]; acc = acc + pr; }
+                    if (has_bias && !orc_hash_arith) { float pr = L->bias * W->val[ce - 1]; acc = acc + pr; }
                 }
                 float v = orc_transform(pp_kind, pp_p, acc);            /* inference.hpp:1360-1371 */
                 if (!no_prev_pred) v = orc_combine(pp_kind, v, p_val[b]); /* inference.hpp:2071-2073 */

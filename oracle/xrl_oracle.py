@@ -98,9 +98,11 @@ def _dense_rows_to_csr(idx, val, cnt, n_cols):
 
 
 class OracleModel:
-    def __init__(self, layers):
+    def __init__(self, layers, weight_matrix_type="BINARY_SEARCH_CHUNKED"):
+        """weight_matrix_type "HASH_CHUNKED": sparse X takes that layout's arithmetic (bias first, inference.hpp:705-735)."""
         build()
         self.lib = C.CDLL(ORACLE_SO)
+        self.hash_arith = 1 if weight_matrix_type == "HASH_CHUNKED" else 0
         self.layers = layers
         self._keep = []
         arr = (_Layer * len(layers))()
@@ -118,8 +120,8 @@ class OracleModel:
         self.nr_features = layers[0]["W"].shape[0] - (1 if layers[0]["bias"] > 0 else 0)
 
     @classmethod
-    def load(cls, folder):
-        return cls(load_model_folder(folder))
+    def load(cls, folder, weight_matrix_type="BINARY_SEARCH_CHUNKED"):
+        return cls(load_model_folder(folder), weight_matrix_type)
 
     def predict_arrays(self, X, beam_size=0, only_topk=0, post_processor=None, trace=False):
         n = X.shape[0]
@@ -146,6 +148,7 @@ class OracleModel:
         f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                       C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.orc_set_hash_arith(self.hash_arith if smat.issparse(X) else 0)
         rc = f(C.addressof(self._arr), depth, n, *xargs, beam_size, only_topk, kind, p,
                out_idx.ctypes.data, out_val.ctypes.data, out_cnt.ctypes.data, stride,
                tr[0].ctypes.data if tr else None, tr[1].ctypes.data if tr else None,

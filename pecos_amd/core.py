@@ -197,6 +197,7 @@ class corelib(object):
             "xrl_queries_from_device_csr": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64]),
             "xrl_queries_from_device_drm": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p]),
             "xrl_queries_concat_device": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_void_p]),
+            "xrl_queries_concat_device_ex": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_int, c_void_p]),
             "xrl_queries_free": (None, [c_void_p]),
             "xrl_predict_device": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int]),
             "xrl_predict_device_rows": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int, c_uint32, c_uint32]),
@@ -428,12 +429,34 @@ class corelib(object):
         self._check()
         return h
 
-    def queries_concat_device(self, c_model, rows, sparse_cols, row_ptr_addr, col_idx_addr, val_addr, nnz, dense_cols, emb_addr, stream=None):
-        """[X_feat (device CSR) | X_emb (device dense)] -> one device CSR (XR-Transformer concat_model's query form)."""
-        h = self.clib_float32.xrl_queries_concat_device(c_void_p(c_model), rows, sparse_cols, c_void_p(row_ptr_addr), c_void_p(col_idx_addr),
-                                                        c_void_p(val_addr), nnz, dense_cols, c_void_p(emb_addr), c_void_p(stream or 0))
+    def queries_concat_device(self, c_model, rows, sparse_cols, row_ptr_addr, col_idx_addr, val_addr, nnz, dense_cols, emb_addr, stream=None,
+                              normalize_emb=False):
+        """[X_feat (device CSR) | X_emb (device dense)] -> one device CSR (XR-Transformer concat_model's query form);
+        normalize_emb: l2-normalise the rows of X_emb on the device first (the reference's default)."""
+        h = self.clib_float32.xrl_queries_concat_device_ex(c_void_p(c_model), rows, sparse_cols, c_void_p(row_ptr_addr), c_void_p(col_idx_addr),
+                                                           c_void_p(val_addr), nnz, dense_cols, c_void_p(emb_addr), 1 if normalize_emb else 0,
+                                                           c_void_p(stream or 0))
         self._check()
         return h
+
+    def queries_download(self, h):
+        """Copy of a query handle's matrix back to the host (scipy CSR with the stored order, or ndarray)."""
+        info = (ctypes.c_uint64 * 4)()
+        fn = self.clib_float32.xrl_queries_info
+        fn.restype = ctypes.c_int; fn.argtypes = [c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+        fn(c_void_p(h), info); self._check()
+        rows, cols, nnz, dense = (int(v) for v in info)
+        dl = self.clib_float32.xrl_queries_download
+        dl.restype = ctypes.c_int; dl.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+        if dense:
+            out = np.zeros((rows, cols), dtype=np.float32)
+            dl(c_void_p(h), None, None, out.ctypes.data_as(c_void_p)); self._check()
+            return out
+        ptr = np.zeros(rows + 1, dtype=np.uint64); idx = np.zeros(max(nnz, 1), dtype=np.uint32); val = np.zeros(max(nnz, 1), dtype=np.float32)
+        dl(c_void_p(h), ptr.ctypes.data_as(c_void_p), idx.ctypes.data_as(c_void_p), val.ctypes.data_as(c_void_p)); self._check()
+        m = smat.csr_matrix((rows, cols), dtype=np.float32)
+        m.indptr, m.indices, m.data = ptr.astype(np.int64), idx[:nnz].astype(np.int64), val[:nnz]      # assigned directly: keeps explicit zeros / order
+        return m
 
     def queries_free(self, h):
         if self._lib is not None and h:

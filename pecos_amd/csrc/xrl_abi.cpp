@@ -765,6 +765,11 @@ void* xrl_queries_from_device_drm(void* model, uint32_t rows, uint32_t cols, con
 
 void* xrl_queries_concat_device(void* model, uint32_t rows, uint32_t sparse_cols, const uint64_t* d_row_ptr, const uint32_t* d_col_idx,
                                 const float* d_val, uint64_t nnz, uint32_t dense_cols, const float* d_emb, void* hip_stream) {
+    return xrl_queries_concat_device_ex(model, rows, sparse_cols, d_row_ptr, d_col_idx, d_val, nnz, dense_cols, d_emb, 0, hip_stream);
+}
+
+void* xrl_queries_concat_device_ex(void* model, uint32_t rows, uint32_t sparse_cols, const uint64_t* d_row_ptr, const uint32_t* d_col_idx,
+                                   const float* d_val, uint64_t nnz, uint32_t dense_cols, const float* d_emb, int normalize_emb, void* hip_stream) {
     void* out = nullptr;
     guarded([&] {
         Model& m = *as_model(model);
@@ -775,7 +780,7 @@ void* xrl_queries_concat_device(void* model, uint32_t rows, uint32_t sparse_cols
         const uint64_t out_nnz = nnz + (uint64_t)rows * dense_cols;
         q->ptr.reserve(((size_t)rows + 1) * 8); q->idx.reserve(out_nnz * 4); q->val.reserve(out_nnz * 4);
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m.stream;
-        launch_concat_csr(d_row_ptr, d_col_idx, d_val, d_emb, rows, sparse_cols, dense_cols, q->ptr.as<uint64_t>(), q->idx.as<uint32_t>(),
+        launch_concat_csr(d_row_ptr, d_col_idx, d_val, d_emb, rows, sparse_cols, dense_cols, normalize_emb, q->ptr.as<uint64_t>(), q->idx.as<uint32_t>(),
                           q->val.as<float>(), s);
         XRL_HIP(hipStreamSynchronize(s));
         q->nnz = out_nnz;
@@ -784,6 +789,39 @@ void* xrl_queries_concat_device(void* model, uint32_t rows, uint32_t sparse_cols
         out = q.release();
     });
     return out;
+}
+
+int xrl_queries_info(void* queries, uint64_t* out4) {
+    int rc = -1;
+    guarded([&] {
+        if (!queries || !out4) fail("null argument");
+        const Queries* q = static_cast<const Queries*>(queries);
+        out4[0] = q->dev.rows; out4[1] = q->dev.cols; out4[2] = q->dev.dense ? (uint64_t)q->dev.rows * q->dev.cols : q->dev.nnz; out4[3] = q->dev.dense ? 1 : 0;
+        rc = 0;
+    });
+    return rc;
+}
+
+int xrl_queries_download(void* queries, uint64_t* row_ptr, uint32_t* col_idx, float* val) {
+    int rc = -1;
+    guarded([&] {
+        if (!queries || !val) fail("null argument");
+        const Queries* q = static_cast<const Queries*>(queries);
+        XRL_HIP(hipSetDevice(q->device));
+        XRL_HIP(hipDeviceSynchronize());
+        if (q->dev.dense) {
+            XRL_HIP(hipMemcpy(val, q->dev.val, (size_t)q->dev.rows * q->dev.cols * 4, hipMemcpyDeviceToHost));
+        } else {
+            if (!row_ptr || (q->dev.nnz && !col_idx)) fail("null argument");
+            XRL_HIP(hipMemcpy(row_ptr, q->dev.row_ptr, ((size_t)q->dev.rows + 1) * 8, hipMemcpyDeviceToHost));
+            if (q->dev.nnz) {
+                XRL_HIP(hipMemcpy(col_idx, q->dev.col_idx, (size_t)q->dev.nnz * 4, hipMemcpyDeviceToHost));
+                XRL_HIP(hipMemcpy(val, q->dev.val, (size_t)q->dev.nnz * 4, hipMemcpyDeviceToHost));
+            }
+        }
+        rc = 0;
+    });
+    return rc;
 }
 
 void xrl_queries_free(void* queries) {

@@ -39,6 +39,7 @@ struct K1QLayer {
     uint32_t d_gp_log2, d_max_tiles, n_parents, w_rows;
     uint32_t beam_in, k, ns;          // ns: candidate registers per lane this layer needs
     int has_bias, pp_kind, pp_p, first_layer, implicit_root;
+    int bias_first;                   // sparse X, HASH_CHUNKED arithmetic (inference.hpp:705-735): bias before the features, like dense X
 };
 constexpr int kK1QMaxLayers = 8;
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         child[r] = v ? cb + col : 0u;
         ps[r] = pscore; valid[r] = v;
         // dense queries: bias FIRST (inference.hpp:824-830); bias_prod holds fl32(bias * w) or +0.0
-        acc[r] = (DENSEX && Ly.has_bias) ? Ly.bias_prod[child[r]] : 0.0f;
+        acc[r] = ((DENSEX || Ly.bias_first) && Ly.has_bias) ? Ly.bias_prod[child[r]] : 0.0f;
     }
     wave_sync_lds();                                                   // the beam has been read: the arrays may be overwritten below
 
@@ -161,7 +162,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
         float s = acc[r];
-        if (!DENSEX && Ly.has_bias) s = __fadd_rn(s, Ly.bias_prod[child[r]]);
+        if (!DENSEX && !Ly.bias_first && Ly.has_bias) s = __fadd_rn(s, Ly.bias_prod[child[r]]);
         float v = pp_transform<PPC>(Ly.pp_kind, Ly.pp_p, s);
         if (!Ly.first_layer) v = pp_combine(Ly.pp_kind, v, ps[r]);
         sbits[r] = __float_as_uint(v);
@@ -254,7 +255,7 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
         y.wd = L.wd; y.d_ld = L.d_ld; y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
         y.d_gp_log2 = L.d_gp_log2; y.d_max_tiles = L.d_max_tiles; y.n_parents = L.n_parents; y.w_rows = L.w_rows;
         y.beam_in = P.beam_in; y.k = P.k; y.ns = k1q_bucket(ns);
-        y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root;
+        y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root; y.bias_first = P.bias_first;
         nsmax = std::max(nsmax, y.ns); ppc |= pp_class(P.pp);
     }
     a.n_layers = n; a.X = X;

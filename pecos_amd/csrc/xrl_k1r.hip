@@ -45,6 +45,7 @@ struct K1RArgs {
     float* cand;
     uint32_t w_rows, n_tiles, ch;                    // ch: sorted items per workgroup
     int pp_kind, pp_p, first_layer, has_bias;
+    int bias_first;                                  // HASH_CHUNKED arithmetic: accumulators start at the bias product
 };
 
 struct XChunk { uint32_t f; uint32_t v; };           // one query feature per lane: id (0xFFFFFFFF past the row's end), value bits
@@ -116,6 +117,11 @@ __global__ void __launch_bounds__(1024) k1r_kernel(K1RArgs a) {
         const XChunk An = ld_chunk(it_n, 0u), Bn = ld_chunk(it_n, 64u);
 
         float2 acc = make_float2(0.0f, 0.0f);                           // std::fill(..., 0.0), inference.hpp:964
+        if (a.bias_first && a.has_bias) {                               // chunk_ops<csr, hash>, inference.hpp:716-722 (bias_prod = 0.0 + bias * w: never -0.0)
+            const uint32_t cb = 2u * (uint32_t)lane;
+            if (cb < ncols) acc.x = t_bias[cb];
+            if (cb + 1u < ncols) acc.y = t_bias[cb + 1u];
+        }
         const uint32_t x_len = it.x_len;
         for (uint32_t c0 = 0; c0 < x_len; c0 += 64u) {
             XChunk C; C.f = 0xFFFFFFFFu; C.v = 0u;
@@ -194,14 +200,14 @@ __global__ void __launch_bounds__(1024) k1r_kernel(K1RArgs a) {
         const uint32_t c = 2u * (uint32_t)lane;
         if (c < ncols) {
             float s = acc.x;
-            if (a.has_bias) s = __fadd_rn(s, t_bias[c]);
+            if (a.has_bias && !a.bias_first) s = __fadd_rn(s, t_bias[c]);
             float v = pp_transform<PPC>(a.pp_kind, a.pp_p, s);
             if (!a.first_layer) v = pp_combine(a.pp_kind, v, it.pscore);
             out[c] = v;
         }
         if (c + 1u < ncols) {
             float s = acc.y;
-            if (a.has_bias) s = __fadd_rn(s, t_bias[c + 1u]);
+            if (a.has_bias && !a.bias_first) s = __fadd_rn(s, t_bias[c + 1u]);
             float v = pp_transform<PPC>(a.pp_kind, a.pp_p, s);
             if (!a.first_layer) v = pp_combine(a.pp_kind, v, it.pscore);
             out[c + 1u] = v;
@@ -222,7 +228,7 @@ void launch_k1r(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, cons
     a.img = L.img; a.img_off = L.img_off; a.items = static_cast<const ItemDesc*>(items_sorted); a.start = start;
     a.xi = X.col_idx; a.xv = X.val; a.cand = cand;
     a.w_rows = L.w_rows; a.n_tiles = L.n_tiles; a.ch = std::max(16u, items_per_block);
-    a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer; a.has_bias = L.has_bias;
+    a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer; a.has_bias = L.has_bias; a.bias_first = P.bias_first;
     const size_t lds = ((size_t)L.max_tile_img + 15) & ~(size_t)15;
     if (lds > 160 * 1024) fail("k1r: tile image exceeds the LDS");
     const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;   // upper bound of the sorted item count (known on the device only)

@@ -33,6 +33,8 @@ struct LayerPlan {
     PostProc pp;
     int first_layer;            // no combine (no_prev_pred)
     int implicit_root;          // previous beam is the implicit all-ones root
+    int bias_first;             // sparse X under weight_matrix_type HASH_CHUNKED: the bias row is applied BEFORE the query's features
+                                // (chunk_ops<csr, hash>, inference.hpp:705-735); dense X is bias-first in every layout
     int layer;                  // index in the chain (profiling only)
     K1Tune tune;
 };
@@ -86,7 +88,7 @@ void launch_k1c_csc(const LayerDev& L, const uint64_t* col_ptr, const uint32_t* 
                     const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* ncand, float* cand, hipStream_t s);
 // [X_feat | X_emb] -> one CSR on the device (concat_model's query form, matcher.py:864-890)
 void launch_concat_csr(const uint64_t* in_ptr, const uint32_t* in_idx, const float* in_val, const float* emb, uint32_t rows,
-                       uint32_t sparse_cols, uint32_t dense_cols, uint64_t* out_ptr, uint32_t* out_idx, float* out_val, hipStream_t s);
+                       uint32_t sparse_cols, uint32_t dense_cols, int normalize_emb, uint64_t* out_ptr, uint32_t* out_idx, float* out_val, hipStream_t s);
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
 // K1Q (xrl_k1q.hip): a whole layer -- prolongate, chunk products against the DENSE row format, post-processor,
 // combine, top-k, child re-ordering -- in one query-stationary kernel: previous beam in, next beam out.

@@ -201,6 +201,7 @@ struct K1Args {
     uint64_t n_slots;
     uint32_t row0, acc_stride;
     int pp_kind, pp_p, first_layer;
+    int bias_first;              // sparse X, HASH_CHUNKED arithmetic: accumulators start at the bias product, nothing is added at the end
     int ablate;                  // debug: phase-skipping mask for timing ablations (0 in production)
     uint32_t lds_per_wave;       // bytes of dynamic LDS owned by each wavefront of a block
     uint32_t n_vblocks;          // number of wavefront-sized work blocks
@@ -309,6 +310,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
     uint2* __restrict__ my_uq = uq + (size_t)grp * (UH + TAIL);
     const uint32_t dummy = a.acc_stride + (uint32_t)lig;
     if (DENSE) {   // dense queries: bias FIRST (inference.hpp:824-830); bias_prod already holds 0.0f + bias*w
+        const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
+        for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = a.L.has_bias ? bp[c] : 0.0f;
+    } else if (a.bias_first) {   // chunk_ops<csr, hash> (inference.hpp:716-722): 0.0 + bias * w first
         const float* __restrict__ bp = a.L.bias_prod + td.col_begin;
         for (uint32_t c = lig; c < td.ncols; c += G) my_acc[c] = a.L.has_bias ? bp[c] : 0.0f;
     } else if (!(a.ablate & 32)) {
@@ -528,7 +532,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
         if (__any(overflow)) drain();
     }
     drain();
-    k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0);
+    k1_epilogue<G, PPC>(a, it, td, lig, [&](uint32_t c) { return my_acc[c]; }, a.L.has_bias != 0 && !a.bias_first);
 #ifdef XRL_K1_PHASE_PROF
     if (prof) {
         tick(4);
@@ -579,7 +583,7 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     K1Args a;
     a.L = L; a.X = X; a.items = static_cast<const ItemDesc*>(items); a.n_items = n_items; a.cand = cand;
     a.n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
-    a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer;
+    a.row0 = P.row0; a.pp_kind = P.pp.kind; a.pp_p = P.pp.p; a.first_layer = P.first_layer; a.bias_first = P.bias_first;
     a.acc_stride = L.max_tile_cols | 1u;
     const int ablate = P.tune.ablate;
     a.ablate = ablate & 0xFF;
@@ -827,7 +831,7 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 concat_csr_kernel(const uint64_t* __restrict__ in_ptr, const uint32_t* __restrict__ in_idx, const float* __restrict__ in_val,
-                  const float* __restrict__ emb, uint32_t rows, uint32_t sparse_cols, uint32_t dense_cols,
+                  const float* __restrict__ emb, uint32_t rows, uint32_t sparse_cols, uint32_t dense_cols, int normalize,
                   uint64_t* __restrict__ out_ptr, uint32_t* __restrict__ out_idx, float* __restrict__ out_val) {
     const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
@@ -839,13 +843,24 @@ concat_csr_kernel(const uint64_t* __restrict__ in_ptr, const uint32_t* __restric
     const uint32_t n = (uint32_t)(in_ptr[r + 1] - ib);
     for (uint32_t t = lane; t < n; t += 64u) { out_idx[ob + t] = in_idx[ib + t]; out_val[ob + t] = in_val[ib + t]; }
     const float* __restrict__ e = emb + (uint64_t)r * dense_cols;
-    for (uint32_t j = lane; j < dense_cols; j += 64u) { out_idx[ob + n + j] = sparse_cols + j; out_val[ob + n + j] = e[j]; }
+    // normalize != 0: sklearn.preprocessing.normalize(X_emb) (l2, rows; matcher.py:879-880) on the device: x / sqrt(sum x^2), rows of
+    // norm < 10 eps left as they are.  The sum is a wavefront tree reduction, so values agree with numpy's to ~1e-7 relative, not bitwise.
+    float scale = 1.0f;
+    if (normalize) {
+        float ss = 0.0f;
+        for (uint32_t j = lane; j < dense_cols; j += 64u) ss += e[j] * e[j];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) ss += __shfl_xor(ss, d, 64);
+        const float nrm = sqrtf(ss);
+        scale = nrm < 10.0f * FLT_EPSILON ? 1.0f : nrm;
+    }
+    for (uint32_t j = lane; j < dense_cols; j += 64u) { out_idx[ob + n + j] = sparse_cols + j; out_val[ob + n + j] = normalize ? e[j] / scale : e[j]; }
 }
 
 void launch_concat_csr(const uint64_t* in_ptr, const uint32_t* in_idx, const float* in_val, const float* emb, uint32_t rows,
-                       uint32_t sparse_cols, uint32_t dense_cols, uint64_t* out_ptr, uint32_t* out_idx, float* out_val, hipStream_t s) {
+                       uint32_t sparse_cols, uint32_t dense_cols, int normalize, uint64_t* out_ptr, uint32_t* out_idx, float* out_val, hipStream_t s) {
     hipLaunchKernelGGL(concat_csr_kernel, dim3((rows + 1u + 3u) / 4u), dim3(256), 0, s, in_ptr, in_idx, in_val, emb, rows, sparse_cols,
-                       dense_cols, out_ptr, out_idx, out_val);
+                       dense_cols, normalize, out_ptr, out_idx, out_val);
     XRL_LAUNCH_CHECK();
 }
 

@@ -162,6 +162,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             P.tune.wpb = m.k1_wpb; P.tune.lds_pad = m.k1_lds_pad; P.tune.ablate = m.k1_ablate; P.tune.k1g_variant = m.k1g_variant;
             P.first_layer = (l == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;   // no_prev_pred
             P.implicit_root = (l == 0 && !has_init) ? 1 : 0;
+            P.bias_first = (m.weight_matrix_type == 1 && !X.dense) ? 1 : 0;
             BeamDev prev{};
             if (l == 0 && has_init) {
                 prev = *o.initial;

@@ -21,8 +21,12 @@ def concat_features(X_feat, X_emb, normalize_emb=True):
     else:
         X_cat = X_emb
     if isinstance(X_feat, smat.csr_matrix):
-        X_cat = smat.hstack([X_feat, smat.csr_matrix(X_cat, dtype=np.float32)], format="csr", dtype=np.float32)
-        X_cat.sort_indices()
+        # smat_util.dense_to_csr keeps EVERY cell of the dense block as a stored entry (zeros included) and hstack_csr appends
+        # it after the row's sparse features (pinned on the reference's outputs, tests/golden/concat/)
+        X_cat = np.ascontiguousarray(X_cat, dtype=np.float32)
+        n, H = X_cat.shape
+        E = smat.csr_matrix((X_cat.ravel(), np.tile(np.arange(H, dtype=np.int64), n), np.arange(n + 1, dtype=np.int64) * H), shape=(n, H))
+        X_cat = smat.hstack([X_feat.astype(np.float32), E], format="csr", dtype=np.float32)
     elif isinstance(X_feat, np.ndarray):
         X_cat = np.hstack([X_feat, X_cat])
     elif X_feat is None:
@@ -32,12 +36,13 @@ def concat_features(X_feat, X_emb, normalize_emb=True):
     return X_cat
 
 
-def predict_from_torch(model, crow, col, val, n_cols, beam_size=None, only_topk=None, post_processor=None, emb=None, stream=None):
+def predict_from_torch(model, crow, col, val, n_cols, beam_size=None, only_topk=None, post_processor=None, emb=None, stream=None,
+                       normalize_emb=False):
     """Beam search on queries that are already on the GPU.
 
     crow: int64 [rows+1], col: int32 [nnz] (sorted inside every row), val: float32 [nnz] -- CUDA tensors of a CSR with
     ``n_cols`` columns; emb: optional float32 [rows, H] CUDA tensor appended as columns n_cols .. n_cols+H-1 on the device
-    (normalise it first if the model was trained on normalised embeddings).  Returns CUDA tensors
+    (``normalize_emb=True`` l2-normalises its rows on the device first, like the reference's concat_features).  Returns CUDA tensors
     (labels int32 [rows, k], scores float32 [rows, k], counts int32 [rows]); row r holds counts[r] valid entries, best first."""
     import torch
     h = model.model.model_chain
@@ -55,7 +60,8 @@ def predict_from_torch(model, crow, col, val, n_cols, beam_size=None, only_topk=
     if emb is not None:
         assert emb.is_cuda and emb.dtype == torch.float32 and emb.shape[0] == rows
         emb = emb.contiguous()
-        q = clib.queries_concat_device(h, rows, n_cols, crow.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, emb.shape[1], emb.data_ptr())
+        q = clib.queries_concat_device(h, rows, n_cols, crow.data_ptr(), col.data_ptr(), val.data_ptr(), nnz, emb.shape[1], emb.data_ptr(),
+                                       normalize_emb=normalize_emb)
     else:
         q = clib.queries_from_device_csr(h, rows, n_cols, crow.data_ptr(), col.data_ptr(), val.data_ptr(), nnz)
     try:

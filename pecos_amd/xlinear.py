@@ -300,8 +300,11 @@ class XLinearModel:
     def load(cls, model_folder, is_predict_only=True, **kwargs):
         """kwargs: weight_matrix_type in {"BINARY_SEARCH_CHUNKED", "HASH_CHUNKED", "CSC"} (pecos/core/base.py:49).
         "CSC" runs the reference's CSC arithmetic (bias first, dot product summed separately, inference.hpp:1018-1149) and is
-        bit-identical to the reference loaded with the same type; the two chunked types share one device layout and the
-        arithmetic of BINARY_SEARCH_CHUNKED (the reference's default; its hash layout iterates rows in hash order)."""
+        bit-identical to the reference loaded with the same type.  The two chunked types share one device layout; with SPARSE
+        queries "HASH_CHUNKED" takes that layout's arithmetic (bias first, then the query's features ascending,
+        inference.hpp:705-735) and is bit-identical to the reference loaded as HASH_CHUNKED too; with DENSE queries the reference's
+        hash layout walks its hash map in the map's own order (:737-768), which no other implementation can reproduce -- dense
+        queries get the BINARY_SEARCH_CHUNKED arithmetic there (same labels, scores within ~3e-6 relative of the hash layout's)."""
         model = HierarchicalMLModel.load(path.join(model_folder, "ranker"), is_predict_only, **kwargs)
         return cls(model)
 

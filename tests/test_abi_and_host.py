@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import scipy.sparse as smat
 
-from conftest import GOLDEN, REPO
+from conftest import GOLDEN, REPO, load_X
 
 
 def _declared_symbols():
@@ -319,3 +319,22 @@ def test_k1r_tile_image_walk(seed):
                     want[c] = np.float32(want[c] + np.float32(np.float32(v) * vals[f, c]))
         got = _k1r_walk(img, x_idx, x_val, w_rows)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_concat_features_vs_reference_goldens(manifest):
+    # pecos_amd.features.concat_features against outputs of the reference's own TransformerMatcher.concat_features
+    # (pecos/xmc/xtransformer/matcher.py:864-890; tests/golden/make_golden_r03.py): same pattern, same order, same bits
+    from pecos_amd.features import concat_features
+    X = load_X(os.path.join(GOLDEN, "synth", "s_eurlex__X.npz"))
+    emb = np.load(os.path.join(GOLDEN, "concat", "X_emb.npy"))
+    for c in manifest["concat"]:
+        X_feat = {"csr": X, "dense": np.ascontiguousarray(X.toarray()[:, :50]), "none": None}[c["feat"]]
+        got = concat_features(X_feat, emb.copy(), normalize_emb=c["normalize_emb"])
+        z = np.load(os.path.join(GOLDEN, "concat", c["out"]))
+        if "dense" in z.files:
+            assert not smat.issparse(got) and got.dtype == z["dense"].dtype and np.array_equal(got.view(np.uint32), z["dense"].view(np.uint32)), c
+        else:
+            assert smat.issparse(got) and got.shape == tuple(z["shape"]) and got.dtype == np.float32, c
+            got = got.tocsr()
+            assert np.array_equal(got.indptr, z["indptr"]) and np.array_equal(got.indices, z["indices"]), c
+            assert np.array_equal(got.data.view(np.uint32), z["data"].view(np.uint32)), c

@@ -66,6 +66,38 @@ def test_device_resident_queries_and_concat():
     assert nrm.shape == host_cat.shape and np.allclose(np.asarray(nrm[:, D - H:].multiply(nrm[:, D - H:]).sum(axis=1)).ravel(), 1.0, atol=1e-5)
 
 
+def test_device_concat_vs_reference_concat_features(manifest):
+    # xrl_queries_concat_device_ex with the embedding normalisation done ON THE DEVICE, read back and compared with the output of the
+    # reference's own TransformerMatcher.concat_features (tests/golden/concat/, made by make_golden_r03.py): pattern and order
+    # identical (every cell of the dense block is a stored entry), sparse part bit-identical, normalised block within 1e-6 relative
+    # (sklearn sums the squares in numpy's order, the kernel in a wavefront tree)
+    import torch
+    from pecos_amd import XLinearModel, clib
+    folder = os.path.join(GOLDEN, "synth", "s_eurlex")
+    X = load_X(os.path.join(GOLDEN, "synth", "s_eurlex__X.npz"))
+    emb = np.load(os.path.join(GOLDEN, "concat", "X_emb.npy"))
+    m = XLinearModel.load(folder)
+    h = m.model.model_chain
+    dev = torch.device("cuda", 0)
+    crow = torch.from_numpy(X.indptr.astype(np.int64)).to(dev); col = torch.from_numpy(X.indices.astype(np.int32)).to(dev)
+    val = torch.from_numpy(X.data.astype(np.float32)).to(dev); temb = torch.from_numpy(emb).to(dev)
+    for c in manifest["concat"]:
+        if c["feat"] != "csr":
+            continue
+        z = np.load(os.path.join(GOLDEN, "concat", c["out"]))
+        q = clib.queries_concat_device(h, X.shape[0], X.shape[1], crow.data_ptr(), col.data_ptr(), val.data_ptr(), int(X.nnz), emb.shape[1],
+                                       temb.data_ptr(), normalize_emb=c["normalize_emb"])
+        got = clib.queries_download(q)
+        clib.queries_free(q)
+        assert got.shape == tuple(z["shape"]) and np.array_equal(got.indptr, z["indptr"]) and np.array_equal(got.indices, z["indices"]), c
+        is_emb = got.indices >= X.shape[1]
+        assert np.array_equal(got.data[~is_emb].view(np.uint32), z["data"][~is_emb].view(np.uint32))
+        if c["normalize_emb"]:
+            assert np.all(np.abs(got.data[is_emb] - z["data"][is_emb]) <= 1e-6 * np.abs(z["data"][is_emb]) + 1e-30)
+        else:
+            assert np.array_equal(got.data[is_emb].view(np.uint32), z["data"][is_emb].view(np.uint32))
+
+
 def test_predict_device_rows_ranges_vs_oracle(oracle_mod):
     # xrl_predict_device_rows (what bench.py's timed step and the sharded path call): arbitrary row ranges with row_begin > 0,
     # results landing at the SAME rows of the caller's buffers (rows outside the range untouched), sparse and dense X, tile-format

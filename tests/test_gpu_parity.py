@@ -543,6 +543,40 @@ def test_full_size_vs_reference(name, XLM, clib, oracle_mod, tmp_path):
         assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{name} full size, dense_layers={dl}")
 
 
+def test_hash_chunked_sparse_queries_bit_exact(manifest, XLM, clib, oracle_mod, tmp_path):
+    # weight_matrix_type="HASH_CHUNKED" with CSR queries: the reference adds the bias row FIRST and then the query's features in
+    # ascending order (chunk_ops<csr, hash_chunked>, inference.hpp:705-735) -- deterministic, so it is matched bit for bit:
+    # reference-generated goldens (make_golden_r03.py) through every kernel family, then a fresh model against the live reference
+    models = {}
+    for c in manifest["synth_hash"]:
+        if c["model"] not in models:
+            models[c["model"]] = XLM.load(os.path.join(GOLDEN, "synth", c["model"]), weight_matrix_type="HASH_CHUNKED")
+        m = models[c["model"]]
+        h = m.model.model_chain
+        X = load_X(os.path.join(GOLDEN, "synth", c["model"] + "__X.npz"))
+        G = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"]))
+        ex = EXACT_PP(c["kwargs"].get("post_processor"))
+        for dl, k1r in ((1, 0), (2, 0), (0, 0), (0, 1)):
+            clib.set_option(h, "dense_layers", dl); clib.set_option(h, "k1r_min_items", k1r)
+            assert_same_topk(m.predict(X, **c["kwargs"]), G, exact_scores=ex, what=f"HASH_CHUNKED {c} dense_layers={dl} k1r={k1r}")
+        clib.set_option(h, "dense_layers", 1); clib.set_option(h, "k1r_min_items", 0)
+    if oracle_mod.ref_available():
+        import xrl_synth
+        folder = str(tmp_path / "m")
+        ks, X, cfg = xrl_synth.make_config("eurlex-4k", folder, scale=0.5)
+        X = X[:2000]
+        m = XLM.load(folder, weight_matrix_type="HASH_CHUNKED")
+        ref = oracle_mod.RefModel(folder, "HASH_CHUNKED")
+        ref_bs = oracle_mod.RefModel(folder)
+        for kw in (dict(beam_size=10, only_topk=10), dict(beam_size=4, only_topk=20, post_processor="log-l1-hinge")):
+            want = ref.predict(X, **kw)
+            for dl in (1, 0):
+                clib.set_option(m.model.model_chain, "dense_layers", dl)
+                assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"HASH_CHUNKED vs live reference {kw} dense_layers={dl}")
+            other = ref_bs.predict(X, **kw)
+            assert not np.array_equal(other.data.view(np.uint32), want.data.view(np.uint32))     # the two layouts do differ in the last bits
+
+
 def _bench_workload(name, cache=None):
     """The folder bench.py generates / re-uses for a workload at scale 1.0 (so that the driver's pytest and bench runs build it once)."""
     import json

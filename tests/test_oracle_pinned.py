@@ -136,3 +136,20 @@ def test_mmap_writer_is_readable_by_the_reference(oracle_mod, tmp_path):
                     assert open(fo, "rb").read() == open(fr, "rb").read(), (name, layer, f)
     with pytest.raises(RuntimeError):
         clib.xlinear_compile_mmap_model(str(tmp_path / "nope"), str(tmp_path / "out"))
+
+
+def test_oracle_hash_chunked_arithmetic_vs_reference(manifest, oracle_mod):
+    # weight_matrix_type=HASH_CHUNKED with sparse queries (inference.hpp:705-735: bias first, then the query's features ascending):
+    # the restatement's second arithmetic, pinned bit for bit on outputs of the compiled reference (make_golden_r03.py)
+    models = {}
+    differs = 0
+    for c in manifest["synth_hash"]:
+        if c["model"] not in models:
+            models[c["model"]] = oracle_mod.OracleModel.load(os.path.join(GOLDEN, "synth", c["model"]), "HASH_CHUNKED")
+        X = load_X(os.path.join(GOLDEN, "synth", c["model"] + "__X.npz"))
+        P = models[c["model"]].predict(X, **c["kwargs"])
+        G = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"]))
+        assert_same_topk(P, G, exact_scores=True, what=f"HASH_CHUNKED {c}")
+        B = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"].replace("__hash__", "__")))
+        differs += int(not np.array_equal(B.data.view(np.uint32), G.data.view(np.uint32)))
+    assert differs > 10      # the fixtures do tell the two layouts apart
