@@ -266,6 +266,11 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *   "k1_group"            lanes per (query, tile) item in K1: 0 = auto, else a power of two <= 64
  *   "max_batch_rows"      rows of X per internal batch (0 = auto: candidate buffer <= 6 GiB)
  *   "sort_min_tiles"      tile-sort the items of layers with at least this many tiles (0 = never)
+ *   "devices"             MULTI-GPU BEHIND THE DROP-IN ENTRY POINTS: the handle serves c_xlinear_predict_{csr,drm}_f32 from this many
+ *                         devices -- its own plus value-1 replicas of the compiled model on the following devices (wrapping around when
+ *                         the box has fewer).  A predict then cuts X into nnz-balanced row shards, one host thread + stream + pinned
+ *                         staging per device, no inter-GPU traffic, results of all shards into the arrays of the ONE allocator call.
+ *                         Only for models loaded from a folder.  c_xlinear_get_int_attr "nr_devices" reads it back.
  *   "k1r_min_items"       sparse X: run a tile-format layer with the tile-RESIDENT kernel K1R (tile-sorted items, the tile's
  *                         image in LDS, accumulators in registers) once a tile serves this many items on average
  *                         (0 = never, the default: profiles/r03_k1r_experiments.txt); needs the tile images (every tile of the layer fits in LDS; XRL_K1R=0

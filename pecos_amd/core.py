@@ -265,7 +265,7 @@ class corelib(object):
             self._lib.c_xlinear_destruct_model(c_void_p(c_model))
 
     def xlinear_get_int_attr(self, c_model, attr):
-        assert attr in {"depth", "nr_features", "nr_labels", "nr_codes", "nr_pred_cols", "nr_bucket_layers", "nr_bitmap64_layers", "nr_k1r_layers", "nr_dense_layers", "device"}, f"attr {attr} not implemented"
+        assert attr in {"depth", "nr_features", "nr_labels", "nr_codes", "nr_pred_cols", "nr_bucket_layers", "nr_bitmap64_layers", "nr_k1r_layers", "nr_dense_layers", "device", "nr_devices"}, f"attr {attr} not implemented"
         v = self.clib_float32.c_xlinear_get_int_attr(c_void_p(c_model), c_char_p(attr.encode("utf-8")))
         self._check()
         return v

@@ -133,17 +133,13 @@ void run_and_emit(Model& m, const QueriesDev& X, const PredictOpts& o, py_sparse
 // stream while batch b's kernels run; every batch's results start their way back as soon as its last kernel is queued.
 // The allocator callback is invoked once, synchronously, on the calling thread, after everything has finished
 // (pecos/core/base.py:431-464 discipline).  Small inputs take the single-batch path.
+// Runs the whole host-ABI pipeline of ONE device for the rows of `input_x` and leaves the fixed-stride results in the handle's
+// pinned host buffers (ws.h_idx / h_val / h_cnt, stride k); the caller holds m.mu and emits the CSR afterwards.
 template <class XT>
-void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, uint32_t topk,
-                  py_sparse_allocator_t alloc, bool is_csr) {
-    Model& m = *as_model(ptr);
-    if (!alloc) fail("null allocator callback");
-    if (!input_x) fail("null X");
-    std::lock_guard<std::mutex> g(m.mu);
+void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     use_device(m.device);
     if (!m.ws) m.ws = std::make_unique<Workspace>();
     Workspace& ws = *m.ws;
-    PredictOpts o; o.beam_size = beam; o.only_topk = topk; o.post_processor = pp;
     const ScipyCsrF32* Xs = is_csr ? reinterpret_cast<const ScipyCsrF32*>(input_x) : nullptr;
     const ScipyDrmF32* Xd = is_csr ? nullptr : reinterpret_cast<const ScipyDrmF32*>(input_x);
     const uint32_t rows = is_csr ? Xs->rows : Xd->rows;
@@ -162,7 +158,11 @@ void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, u
     if (!staged) {
         if (is_csr) upload_csr(Xs, ws.x_ptr, ws.x_idx, ws.x_val, X);
         else upload_drm(Xd, ws.x_val, X);
-        run_and_emit(m, X, o, alloc);
+        const uint32_t k1 = effective_topk(m, o.only_topk);
+        reserve_outputs(m, X.rows, k1);
+        predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k1, m.stream, false);
+        download_rows(m, 0, X.rows, k1);
+        XRL_HIP(hipStreamSynchronize(m.stream));
         return;
     }
     // ---- batch boundaries: equal shares of the elements (CSR: of the nnz -- cost follows nnz, not rows)
@@ -229,8 +229,101 @@ void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, u
         throw;
     }
     for (auto& e : up) (void)hipEventDestroy(e);
+}
+
+// csr_t::create_pycsr over the row shards of several devices: ONE synchronous allocator call on the calling thread, then every
+// shard's fixed-stride rows are copied to their place
+struct ShardOut { uint32_t r0, r1; const uint32_t* idx; const float* val; const uint32_t* cnt; };
+void emit_csr_shards(uint32_t rows, uint32_t cols, uint32_t stride, const std::vector<ShardOut>& sh, py_sparse_allocator_t alloc) {
+    std::vector<uint64_t> ptr((size_t)rows + 1);
+    ptr[0] = 0;
+    for (const ShardOut& s : sh) for (uint32_t r = s.r0; r < s.r1; ++r) ptr[r + 1] = ptr[r] + std::min(s.cnt[r - s.r0], stride);
+    const uint64_t nnz = ptr[rows];
+    uint32_t* o_idx = nullptr; uint64_t* o_ptr = nullptr; float* o_val = nullptr;
+    alloc(false, rows, cols, nnz, &o_idx, &o_ptr, &o_val);
+    if (!o_ptr || (nnz && (!o_idx || !o_val))) fail("allocator callback returned null buffers");
+    parallel_ranges((size_t)rows + 1, 1u << 16, [&](size_t b, size_t e) { std::memcpy(o_ptr + b, ptr.data() + b, (e - b) * 8); });
+    for (const ShardOut& s : sh)
+        parallel_ranges(s.r1 - s.r0, 1u << 15, [&](size_t b, size_t e) {
+            for (size_t r = b; r < e; ++r) {
+                const size_t g = s.r0 + r, n = (size_t)(ptr[g + 1] - ptr[g]);
+                std::memcpy(o_idx + ptr[g], s.idx + r * stride, n * 4);
+                std::memcpy(o_val + ptr[g], s.val + r * stride, n * 4);
+            }
+        });
+}
+
+// c_xlinear_predict_{csr,drm}_f32.  With replicas behind the handle (xrl_set_option "devices"): the rows are cut into nnz-balanced
+// shards, one host thread per device runs the single-device pipeline above on its shard (its own stream, pinned staging and PCIe
+// link; no inter-GPU traffic), and the results of all shards go into the arrays of the one allocator call.
+template <class XT>
+void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, uint32_t topk,
+                  py_sparse_allocator_t alloc, bool is_csr) {
+    Model& m = *as_model(ptr);
+    if (!alloc) fail("null allocator callback");
+    if (!input_x) fail("null X");
+    std::lock_guard<std::mutex> g(m.mu);
+    PredictOpts o; o.beam_size = beam; o.only_topk = topk; o.post_processor = pp;
+    const ScipyCsrF32* Xs = is_csr ? reinterpret_cast<const ScipyCsrF32*>(input_x) : nullptr;
+    const ScipyDrmF32* Xd = is_csr ? nullptr : reinterpret_cast<const ScipyDrmF32*>(input_x);
+    const uint32_t rows = is_csr ? Xs->rows : Xd->rows;
     const Layer& last = *m.layers.back();
-    emit_csr(rows, last.reordered ? last.c_rows : last.w_cols, k, ws.h_idx.as<uint32_t>(), ws.h_val.as<float>(), ws.h_cnt.as<uint32_t>(), alloc);
+    const uint32_t out_cols = last.reordered ? last.c_rows : last.w_cols;
+    const uint32_t k = effective_topk(m, o.only_topk);
+    const size_t R = 1 + m.replicas.size();
+    if (R == 1 || rows < 2 * R) {
+        host_compute(m, input_x, o, is_csr);
+        Workspace& ws = *m.ws;
+        emit_csr(rows, out_cols, k, ws.h_idx.as<uint32_t>(), ws.h_val.as<float>(), ws.h_cnt.as<uint32_t>(), alloc);
+        return;
+    }
+    // ---- shard boundaries: equal shares of the nnz (+1 per row so that empty rows still count); dense X: equal rows
+    std::vector<uint32_t> sb(R + 1, rows);
+    sb[0] = 0;
+    for (size_t d = 1; d < R; ++d) {
+        if (is_csr) {
+            const uint64_t total = Xs->row_ptr[rows] + rows, want = total * d / R;
+            uint32_t lo = sb[d - 1], hi = rows;                          // first row r with row_ptr[r] + r >= want
+            while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (Xs->row_ptr[mid] + mid < want) lo = mid + 1; else hi = mid; }
+            sb[d] = lo;
+        } else sb[d] = (uint32_t)((uint64_t)rows * d / R);
+    }
+    std::vector<std::exception_ptr> errs(R);
+    std::vector<std::vector<uint64_t>> rebased(R);
+    auto work = [&](size_t d) {
+        try {
+            Model& md = d == 0 ? m : *m.replicas[d - 1];
+            std::unique_lock<std::mutex> lk(md.mu, std::defer_lock);
+            if (d != 0) lk.lock();
+            const uint32_t r0 = sb[d], r1 = sb[d + 1];
+            if (r1 <= r0) return;
+            if (is_csr) {
+                const uint64_t e0 = Xs->row_ptr[r0];
+                rebased[d].resize((size_t)(r1 - r0) + 1);
+                for (uint32_t r = r0; r <= r1; ++r) rebased[d][r - r0] = Xs->row_ptr[r] - e0;
+                ScipyCsrF32 v = *Xs;
+                v.rows = r1 - r0; v.row_ptr = rebased[d].data(); v.col_idx = Xs->col_idx + e0; v.val = Xs->val + e0;
+                host_compute(md, &v, o, true);
+            } else {
+                ScipyDrmF32 v = *Xd;
+                v.rows = r1 - r0; v.val = Xd->val + (size_t)r0 * Xd->cols;
+                host_compute(md, &v, o, false);
+            }
+        } catch (...) { errs[d] = std::current_exception(); }
+    };
+    std::vector<std::thread> th;
+    for (size_t d = 1; d < R; ++d) th.emplace_back(work, d);
+    work(0);
+    for (auto& t : th) t.join();
+    use_device(m.device);
+    for (auto& e : errs) if (e) std::rethrow_exception(e);
+    std::vector<ShardOut> sh;
+    for (size_t d = 0; d < R; ++d) {
+        if (sb[d + 1] <= sb[d]) continue;
+        Workspace& ws = *(d == 0 ? m : *m.replicas[d - 1]).ws;
+        sh.push_back(ShardOut{sb[d], sb[d + 1], ws.h_idx.as<uint32_t>(), ws.h_val.as<float>(), ws.h_cnt.as<uint32_t>()});
+    }
+    emit_csr_shards(rows, out_cols, k, sh, alloc);
 }
 
 HostCsc host_csc(const ScipyCscF32* M, const char* what) {
@@ -509,7 +602,7 @@ void* c_xlinear_load_model_from_disk_ext(const char* model_path, int weight_matr
         require_gpu();
         use_device(g_device);
         auto m = load_model_from_disk(model_path, weight_matrix_type);
-        m->device = g_device;
+        m->device = g_device; m->src_path = model_path; m->src_kind = 0;
         out = m.release();
     });
     return out;
@@ -527,7 +620,7 @@ void* c_xlinear_load_mmap_model_from_disk(const char* model_path, const bool laz
         require_gpu();
         use_device(g_device);
         auto m = load_mmap_model_from_disk(model_path);
-        m->device = g_device;
+        m->device = g_device; m->src_path = model_path; m->src_kind = 1;
         out = m.release();
     });
     return out;
@@ -572,6 +665,7 @@ uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
         else if (!std::strcmp(attr, "nr_dense_layers")) {    // additive: layers that also carry the dense row format (K1Q)
             for (auto& l : m.layers) v += l->dev.wd ? 1u : 0u;
         }
+        else if (!std::strcmp(attr, "nr_devices")) v = 1u + (uint32_t)m.replicas.size();   // additive: devices behind the handle (xrl_set_option "devices")
         else if (!std::strcmp(attr, "nr_k1r_layers")) {      // additive: layers that carry K1R tile images
             for (auto& l : m.layers) v += l->dev.img ? 1u : 0u;
         }
@@ -944,27 +1038,56 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
     return words;
 }
 
+static void set_option_one(Model& m, const char* key, int64_t value) {
+    if (!std::strcmp(key, "k1_group")) m.k1_group = (int)value;
+    else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
+    else if (!std::strcmp(key, "sort_min_tiles")) m.sort_min_tiles = (int)value;
+    else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;   // 0: the host ABI uploads X in one piece before computing
+    else if (!std::strcmp(key, "k1q_fuse")) m.k1q_fuse = (int)value;           // 0: one K1Q launch per dense-format layer
+    else if (!std::strcmp(key, "k1g_min_items")) m.k1g_min_items = (int)value;   // dense X: queries per parent from which a dense-format layer runs the tiled SGEMM K1G (0 = never)
+    else if (!std::strcmp(key, "dense_layers")) m.dense_layers = (int)value;   // 0: never run the fused dense-format kernel K1Q
+    else if (!std::strcmp(key, "k2_legacy")) m.k2_legacy = (int)value;        // debug / A-B: round-1 insertion top-k
+    else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
+    else if (!std::strcmp(key, "k1r_min_items")) m.k1r_min_items = (int)value;
+    else if (!std::strcmp(key, "k1r_items_per_block")) m.k1r_items_per_block = (int)value;
+    else if (!std::strcmp(key, "k1g_variant")) m.k1g_variant = (int)value;   // K1G tile-shape alternative (tuning; results identical)
+    else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
+    else if (!std::strcmp(key, "k1_lds_pad")) m.k1_lds_pad = (int)value;   // debug: occupancy experiments
+    else if (!std::strcmp(key, "k1_ablate")) m.k1_ablate = (int)value;     // debug: timing ablations only
+    else fail(std::string("unknown option ") + key);
+}
+
 int xrl_set_option(void* model, const char* key, int64_t value) {
     int rc = -1;
     guarded([&] {
         Model& m = *as_model(model);
         if (!key) fail("null key");
-        if (!std::strcmp(key, "k1_group")) m.k1_group = (int)value;
-        else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
-        else if (!std::strcmp(key, "sort_min_tiles")) m.sort_min_tiles = (int)value;
-        else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;   // 0: the host ABI uploads X in one piece before computing
-        else if (!std::strcmp(key, "k1q_fuse")) m.k1q_fuse = (int)value;           // 0: one K1Q launch per dense-format layer
-        else if (!std::strcmp(key, "k1g_min_items")) m.k1g_min_items = (int)value;   // dense X: queries per parent from which a dense-format layer runs the tiled SGEMM K1G (0 = never)
-        else if (!std::strcmp(key, "dense_layers")) m.dense_layers = (int)value;   // 0: never run the fused dense-format kernel K1Q
-        else if (!std::strcmp(key, "k2_legacy")) m.k2_legacy = (int)value;        // debug / A-B: round-1 insertion top-k
-        else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
-        else if (!std::strcmp(key, "k1r_min_items")) m.k1r_min_items = (int)value;
-        else if (!std::strcmp(key, "k1r_items_per_block")) m.k1r_items_per_block = (int)value;
-        else if (!std::strcmp(key, "k1g_variant")) m.k1g_variant = (int)value;   // K1G tile-shape alternative (tuning; results identical)
-        else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
-        else if (!std::strcmp(key, "k1_lds_pad")) m.k1_lds_pad = (int)value;   // debug: occupancy experiments
-        else if (!std::strcmp(key, "k1_ablate")) m.k1_ablate = (int)value;     // debug: timing ablations only
-        else fail(std::string("unknown option ") + key);
+        if (!std::strcmp(key, "devices")) {
+            // the handle serves c_xlinear_predict_* from `value` devices: this one plus value-1 replicas of the compiled model,
+            // placed on the following physical devices (wrapping around: with fewer GPUs than requested several replicas share one,
+            // which is how a one-GPU box tests the sharded path)
+            if (value < 1 || value > 64) fail("devices: expected 1..64");
+            if (m.src_kind < 0 && value > 1) fail("devices: only models loaded from a folder can be replicated");
+            std::lock_guard<std::mutex> g(m.mu);
+            int ndev = 0;
+            XRL_HIP(hipGetDeviceCount(&ndev));
+            m.replicas.clear();
+            for (int64_t i = 1; i < value; ++i) {
+                const int dev = (m.device + (int)i) % std::max(1, ndev);
+                use_device(dev);
+                std::unique_ptr<Model> r = m.src_kind == 0 ? load_model_from_disk(m.src_path, m.weight_matrix_type) : load_mmap_model_from_disk(m.src_path);
+                r->device = dev;
+                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->host_pipeline = m.host_pipeline;
+                r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers; r->k2_legacy = m.k2_legacy;
+                r->overlap_min_rows = m.overlap_min_rows; r->k1r_min_items = m.k1r_min_items; r->k1r_items_per_block = m.k1r_items_per_block;
+                r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;
+                m.replicas.push_back(std::move(r));
+            }
+            use_device(m.device);
+        } else {
+            set_option_one(m, key, value);
+            for (auto& r : m.replicas) set_option_one(*r, key, value);
+        }
         rc = 0;
     });
     return rc;

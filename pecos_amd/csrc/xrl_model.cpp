@@ -48,6 +48,8 @@ uint64_t Layer::cand_bound(uint32_t beam) const {
 
 Model::Model() {}
 Model::~Model() {
+    replicas.clear();                       // each replica releases its objects with ITS device current
+    (void)hipSetDevice(device);
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
     if (ws_done) (void)hipEventDestroy(ws_done);

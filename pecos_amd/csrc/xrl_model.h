@@ -176,6 +176,10 @@ struct Model {
     int k1g_min_items = 16;                 // dense X: run a dense-format layer as the tiled SGEMM K1G once a parent serves this many queries on average (0 = never)
     int k2_legacy = 0;                      // A/B and tests: 1 = round-1 insertion top-k kernels instead of the ballot-bisection K2
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
+    // multi-GPU behind the drop-in entry points (xrl_set_option "devices"): further copies of the compiled model on other devices; the
+    // host-ABI predict shards the rows over this handle's device and the replicas' (xrl_abi.cpp predict_host)
+    std::string src_path; int src_kind = -1;   // where the model came from: 0 = npz folder, 1 = mmap folder, -1 = arrays (no replicas)
+    std::vector<std::unique_ptr<Model>> replicas;
     bool profiling = false;
     std::vector<ProfileSlot> profile;
     std::vector<PendingEvent> pending;     // recorded, not yet resolved (no sync on the timed path)
