@@ -98,6 +98,43 @@ def test_device_concat_vs_reference_concat_features(manifest):
             assert np.array_equal(got.data[is_emb].view(np.uint32), z["data"][is_emb].view(np.uint32))
 
 
+def test_multi_device_behind_the_c_abi(oracle_mod, tmp_path):
+    # xrl_set_option(h, "devices", n): the SAME drop-in entry points (c_xlinear_predict_{csr,drm}_f32, here through XLinearModel.predict)
+    # then shard the rows over n copies of the compiled model, one host thread + stream + pinned staging per copy, and fill the arrays
+    # of the ONE allocator call.  On a one-GPU box the copies share the device ("virtual devices"), which exercises everything but the
+    # second PCIe link: results must equal the single-device ones bit for bit -- small X (direct upload), large X (pipelined staged
+    # upload per shard), dense X, fewer rows than devices, empty rows at the shard boundaries.
+    import xrl_synth
+    from pecos_amd import XLinearModel, clib
+    folder = str(tmp_path / "m")
+    ks, X, cfg = xrl_synth.make_config("eurlex-4k", folder, scale=0.5)
+    m = XLinearModel.load(folder)
+    h = m.model.model_chain
+    om = oracle_mod.OracleModel.load(folder)
+    kw = dict(beam_size=10, only_topk=10)
+    Xs = X[:600].tolil(); Xs[199] = 0; Xs[200] = 0; Xs[399] = 0; Xs = Xs.tocsr().astype(np.float32); Xs.eliminate_zeros(); Xs.sort_indices()
+    Xbig = smat.vstack([X] * 12).tocsr(); Xbig.sort_indices()             # > 32 MB per shard: the staged upload path
+    want_s, want_big = m.predict(Xs, **kw), m.predict(Xbig, **kw)
+    assert_same_topk(want_s, om.predict(Xs, **kw), exact_scores=True, what="single device vs oracle")
+    Xd = np.ascontiguousarray(X[:300].toarray())
+    want_d = m.predict(Xd, **kw)
+    for n in (3, 2):
+        clib.set_option(h, "devices", n)
+        assert clib.xlinear_get_int_attr(h, "nr_devices") == n
+        for trial in range(2):
+            assert_same_topk(m.predict(Xs, **kw), want_s, exact_scores=True, what=f"{n} devices, small X, trial {trial}")
+        assert_same_topk(m.predict(Xbig, **kw), want_big, exact_scores=True, what=f"{n} devices, staged upload")
+        assert_same_topk(m.predict(Xd, **kw), want_d, exact_scores=True, what=f"{n} devices, dense X")
+        assert_same_topk(m.predict(Xs[:n], **kw), want_s[:n], exact_scores=True, what=f"{n} devices, {n} rows")
+        assert_same_topk(m.predict(Xs[:1], **kw), want_s[:1], exact_scores=True, what=f"{n} devices, one row")
+        clib.set_option(h, "dense_layers", 0)                              # options reach the replicas
+        assert_same_topk(m.predict(Xs, **kw), want_s, exact_scores=True, what=f"{n} devices, tile format")
+        clib.set_option(h, "dense_layers", 1)
+    clib.set_option(h, "devices", 1)
+    assert clib.xlinear_get_int_attr(h, "nr_devices") == 1
+    assert_same_topk(m.predict(Xs, **kw), want_s, exact_scores=True, what="back to one device")
+
+
 def test_predict_device_rows_ranges_vs_oracle(oracle_mod):
     # xrl_predict_device_rows (what bench.py's timed step and the sharded path call): arbitrary row ranges with row_begin > 0,
     # results landing at the SAME rows of the caller's buffers (rows outside the range untouched), sparse and dense X, tile-format
