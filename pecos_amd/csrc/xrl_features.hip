@@ -1,0 +1,50 @@
+// Query-side featurizer kernels: what produces X stays on the device, so the beam search needs no H2D of X.
+//
+//   tfidf_weight_kernel   the WEIGHTING half of the reference's TF-IDF vectorizer -- BaseVectorizer::get_sorted_feature,
+//                         pecos/core/utils/tfidf.hpp:798-822 (c_tfidf_predict, libpecos.cpp:427-445): term counts of a document, in
+//                         ascending feature id, -> binary / sublinear tf -> x idf -> l1 / l2 normalisation.  Tokenisation and the
+//                         n-gram lookup (string work, :775-793) stay the reference's host code; their output -- a CSR of term
+//                         COUNTS -- is this kernel's input.
+//
+// Arithmetic follows the reference's float32 code operation by operation: the norm is accumulated SEQUENTIALLY in ascending
+// feature order (one thread per document), multiply and add rounded separately (-ffp-contract=off), sqrtf / division IEEE.
+// With sublinear_tf the reference calls glibc's logf, whose last bit the device's logf may not share: <= 1 ulp there.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "xrl_kernels.h"
+
+namespace xrl {
+
+__global__ void __launch_bounds__(256)
+tfidf_weight_kernel(const uint64_t* __restrict__ row_ptr, const uint32_t* __restrict__ col_idx, const float* __restrict__ count,
+                    const float* __restrict__ idf, uint32_t rows, uint32_t cols, int binary, int sublinear_tf, int norm_p,
+                    float* __restrict__ out) {
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= rows) return;
+    const uint64_t b = row_ptr[r], e = row_ptr[r + 1];
+    float denom = 0.0f;
+    for (uint64_t t = b; t < e; ++t) {
+        float v = binary ? 1.0f : count[t];                                    // tfidf.hpp:800
+        if (sublinear_tf) v = (float)((double)logf(v) + 1.0);                  // :801  (std::log(float) + 1.0)
+        if (idf) { const uint32_t f = col_idx[t]; v = __fmul_rn(v, idf[f < cols ? f : 0u]); }   // :802-804
+        out[t] = v;
+        denom = norm_p == 1 ? __fadd_rn(denom, fabsf(v)) : __fadd_rn(denom, __fmul_rn(v, v));   // :806-809
+    }
+    if (fabsf(denom) < FLT_EPSILON) denom = 1.0f;                              // :814-815
+    else if (norm_p == 2) denom = sqrtf(denom);                                // :816-817
+    for (uint64_t t = b; t < e; ++t) out[t] = __fdiv_rn(out[t], denom);        // :819-821
+}
+
+void launch_tfidf_weight(const uint64_t* row_ptr, const uint32_t* col_idx, const float* count, const float* idf, uint32_t rows, uint32_t cols,
+                         int binary, int sublinear_tf, int norm_p, float* out, hipStream_t s) {
+    if (rows == 0) return;
+    if (norm_p != 1 && norm_p != 2) fail("tfidf: invalid normalize option, norm_p: [ 1| 2]");
+    hipLaunchKernelGGL(tfidf_weight_kernel, dim3((rows + 255u) / 256u), dim3(256), 0, s, row_ptr, col_idx, count, idf, rows, cols, binary,
+                       sublinear_tf, norm_p, out);
+    XRL_HIP(hipGetLastError());
+}
+
+}  // namespace xrl

@@ -3,6 +3,9 @@
 * :func:`concat_features` -- host mirror of ``TransformerMatcher.concat_features``
   (pecos/xmc/xtransformer/matcher.py:864-890): [numerical features | (row-normalised) embeddings], the matrix
   XR-Transformer's ``concat_model`` predicts on (pecos/xmc/xtransformer/model.py:589-603).
+* :func:`tfidf_weight` / :func:`predict_tfidf_from_torch` -- the weighting half of the reference's TF-IDF vectorizer
+  (``BaseVectorizer::get_sorted_feature``, pecos/core/utils/tfidf.hpp:798-822): term counts -> tf -> x idf -> l1/l2 norm, as a host
+  mirror (numpy float32, sequential like the reference) and as a device kernel feeding the beam search without a host round trip.
 * :func:`predict_from_torch` -- X already in HBM as torch tensors (a GPU TF-IDF featurizer's CSR -- the reference's
   ``c_tfidf_predict`` produces that CSR on the host, pecos/core/libpecos.cpp:427-445 -- optionally with a dense embedding block to
   append on the device): no host round trip of X, results stay on the device.
@@ -69,6 +72,56 @@ def predict_from_torch(model, crow, col, val, n_cols, beam_size=None, only_topk=
         if rows:
             clib.predict_device(h, q, beam_size, post_processor, only_topk, idx.data_ptr(), sc.data_ptr(), cnt.data_ptr(), k,
                                 stream=s or None, sync=True)
+    finally:
+        clib.queries_free(q)
+    return idx, sc, cnt
+
+
+def tfidf_weight(counts, idf=None, binary=False, sublinear_tf=False, norm="l2"):
+    """Host mirror of tfidf.hpp:798-822 for a CSR of term counts (sorted column ids): float32, the norm accumulated
+    sequentially in ascending feature order, exactly the reference's operations (pinned on its outputs, tests/golden/tfidf/)."""
+    C = smat.csr_matrix(counts, dtype=np.float32)
+    C.sort_indices()
+    out = np.empty(C.nnz, dtype=np.float32)
+    f32 = np.float32
+    for r in range(C.shape[0]):
+        b, e = C.indptr[r], C.indptr[r + 1]
+        v = np.ones(e - b, f32) if binary else C.data[b:e].astype(f32)
+        if sublinear_tf:
+            v = (np.log(v).astype(f32).astype(np.float64) + 1.0).astype(f32)
+        if idf is not None:
+            v = (v * np.asarray(idf, f32)[C.indices[b:e]]).astype(f32)
+        denom = f32(0.0)
+        for x in v:
+            denom = f32(denom + (f32(abs(x)) if norm == "l1" else f32(x * x)))
+        if abs(denom) < np.finfo(np.float32).eps:
+            denom = f32(1.0)
+        elif norm == "l2":
+            denom = f32(np.sqrt(denom))
+        out[b:e] = (v / denom).astype(f32)
+    return smat.csr_matrix((out, C.indices.copy(), C.indptr.copy()), shape=C.shape)
+
+
+def predict_tfidf_from_torch(model, crow, col, count, n_cols, idf=None, binary=False, sublinear_tf=False, norm="l2", beam_size=None,
+                             only_topk=None, post_processor=None, stream=None):
+    """Term-count CSR already on the GPU (crow int64 [rows+1], col int32, count float32; idf float32 [n_cols] CUDA tensor or None)
+    -> tf-idf weighting on the device -> beam search; returns (labels, scores, counts) CUDA tensors like predict_from_torch."""
+    import torch
+    h = model.model.model_chain
+    assert crow.is_cuda and col.is_cuda and count.is_cuda and crow.dtype == torch.int64 and col.dtype == torch.int32 and count.dtype == torch.float32
+    crow, col, count = crow.contiguous(), col.contiguous(), count.contiguous()
+    rows = crow.numel() - 1
+    k = clib.effective_topk(h, only_topk)
+    idx = torch.zeros((rows, k), dtype=torch.int32, device=count.device)
+    sc = torch.zeros((rows, k), dtype=torch.float32, device=count.device)
+    cnt = torch.zeros((rows,), dtype=torch.int32, device=count.device)
+    torch.cuda.current_stream().synchronize()
+    q = clib.queries_tfidf_device(h, rows, n_cols, crow.data_ptr(), col.data_ptr(), count.data_ptr(), int(count.numel()),
+                                  idf.data_ptr() if idf is not None else None, binary, sublinear_tf, 1 if norm == "l1" else 2)
+    try:
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        if rows:
+            clib.predict_device(h, q, beam_size, post_processor, only_topk, idx.data_ptr(), sc.data_ptr(), cnt.data_ptr(), k, stream=s or None, sync=True)
     finally:
         clib.queries_free(q)
     return idx, sc, cnt

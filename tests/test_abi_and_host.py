@@ -338,3 +338,31 @@ def test_concat_features_vs_reference_goldens(manifest):
             got = got.tocsr()
             assert np.array_equal(got.indptr, z["indptr"]) and np.array_equal(got.indices, z["indices"]), c
             assert np.array_equal(got.data.view(np.uint32), z["data"].view(np.uint32)), c
+
+
+def _tfidf_case(c):
+    z = np.load(os.path.join(GOLDEN, "tfidf", c["file"]))
+    shape = tuple(int(v) for v in z["shape"])
+    counts = smat.csr_matrix((z["c_data"], z["c_indices"], z["c_indptr"]), shape=shape)
+    want = smat.csr_matrix((z["x_data"], z["c_indices"], z["c_indptr"]), shape=shape)
+    kw = dict(idf=z["idf"] if bool(z["use_idf"]) else None, binary=bool(z["binary"]), sublinear_tf=bool(z["sublinear_tf"]), norm=str(z["norm"]))
+    return counts, want, kw
+
+
+def test_tfidf_weighting_mirror_vs_reference_goldens(manifest):
+    # the weighting half of the reference's TF-IDF vectorizer (tfidf.hpp:798-822), restated in numpy float32 (pecos_amd.features.
+    # tfidf_weight), against outputs of the reference's own c_tfidf_predict on a saved-and-reloaded model (make_golden_r03.py):
+    # bit for bit, sublinear_tf included (numpy's float32 log is glibc's logf here)
+    from pecos_amd.features import tfidf_weight
+    assert len(manifest["tfidf"]) >= 5
+    empty_rows = 0
+    for c in manifest["tfidf"]:
+        counts, want, kw = _tfidf_case(c)
+        got = tfidf_weight(counts, **kw)
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices), c
+        if kw["sublinear_tf"]:
+            assert np.all(np.abs(got.data - want.data) <= 2e-7 * np.abs(want.data)), c
+        else:
+            assert np.array_equal(got.data.view(np.uint32), want.data.view(np.uint32)), c
+        empty_rows += int((np.diff(want.indptr) == 0).sum())
+    assert empty_rows > 0                                 # documents without any known feature are covered

@@ -225,3 +225,39 @@ def test_bench_step_under_rccl_one_rank(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+def test_device_tfidf_weighting_vs_reference(manifest):
+    # xrl_queries_tfidf_device: term counts on the device -> the reference's tf / idf / norm arithmetic -> query handle, read back and
+    # compared with the output of the reference's own c_tfidf_predict (tests/golden/tfidf/): bit-identical (sublinear_tf: the
+    # device's logf, <= 1 ulp); and a beam search fed from that handle equals the one fed with the reference's matrix
+    import torch
+    from pecos_amd import XLinearModel, clib
+    from pecos_amd.features import predict_tfidf_from_torch
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_abi_and_host import _tfidf_case
+    import xrl_synth
+    dev = torch.device("cuda", 0)
+    for c in manifest["tfidf"]:
+        counts, want, kw = _tfidf_case(c)
+        D = counts.shape[1]
+        import tempfile
+        with tempfile.TemporaryDirectory() as folder:
+            xrl_synth.make_model(folder, D, 300, [max(8, D // 6), max(6, D // 10), 12], seed=31, shape=[4, 24, 300])
+            m = XLinearModel.load(folder)
+            h = m.model.model_chain
+            crow = torch.from_numpy(counts.indptr.astype(np.int64)).to(dev); col = torch.from_numpy(counts.indices.astype(np.int32)).to(dev)
+            cnt = torch.from_numpy(counts.data.astype(np.float32)).to(dev)
+            idf = torch.from_numpy(kw["idf"]).to(dev) if kw["idf"] is not None else None
+            q = clib.queries_tfidf_device(h, counts.shape[0], D, crow.data_ptr(), col.data_ptr(), cnt.data_ptr(), int(counts.nnz),
+                                          idf.data_ptr() if idf is not None else None, kw["binary"], kw["sublinear_tf"], 1 if kw["norm"] == "l1" else 2)
+            got = clib.queries_download(q)
+            clib.queries_free(q)
+            assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices), c
+            if kw["sublinear_tf"]:
+                assert np.all(np.abs(got.data - want.data) <= 2.5e-7 * np.abs(want.data)), c
+            else:
+                assert np.array_equal(got.data.view(np.uint32), want.data.view(np.uint32)), c
+                pk = dict(beam_size=5, only_topk=7)
+                P = _rows_to_csr(*predict_tfidf_from_torch(m, crow, col, cnt, D, idf=idf, binary=kw["binary"], sublinear_tf=False, norm=kw["norm"], **pk), m.nr_pred_cols)
+                assert_same_topk(P, m.predict(want, **pk), exact_scores=True, what=f"beam search on device tf-idf queries, {c}")
