@@ -295,6 +295,32 @@ def main():
                                    ratio_to_device_resident=round(n_total / med / value, 3))
             log(f"host ABI: {med * 1e3:.2f} ms per call = {n_total / med / 1e6:.2f} M q/s ({n_total / med / value:.2f} x device-resident)")
 
+        # ---- what keeping the featurizer's output on the device buys.  The queries' values stand in for term counts:
+        #      the reference's tf-idf weighting + l2 normalisation runs as a kernel on the device CSR (xrl_queries_tfidf_device), and
+        #      the beam search reads its output in place -- against the host ABI, which receives X from the host.
+        if world == 1 and sparse and not args.include_upload and not args.no_host_abi:
+            try:
+                tx = torch.from_numpy(Xs.indptr.astype(np.int64)).to(dev), torch.from_numpy(Xs.indices.astype(np.int32)).to(dev), \
+                    torch.from_numpy(np.abs(Xs.data).astype(np.float32)).to(dev)
+                idf_t = torch.ones(Xs.shape[1], dtype=torch.float32, device=dev)
+                torch.cuda.synchronize()
+                ts = []
+                for it in range(4):
+                    t0 = time.perf_counter()
+                    qh = clib.queries_tfidf_device(h, rows, Xs.shape[1], tx[0].data_ptr(), tx[1].data_ptr(), tx[2].data_ptr(), int(Xs.nnz), idf_t.data_ptr(), False, False, 2)
+                    t1 = time.perf_counter() - t0
+                    clib.queries_free(qh)
+                    if it:
+                        ts.append(t1)
+                tf_ms = float(np.median(ts)) * 1e3
+                out["device_featurizer"] = dict(tfidf_weight_ms=round(tf_ms, 3), queries_per_s=round(n_total / ((tf_ms + ms_per_step) * 1e-3), 1),
+                                                vs_host_abi=round(out.get("value_host_abi", 0) and (n_total / ((tf_ms + ms_per_step) * 1e-3)) / out["value_host_abi"], 3),
+                                                note="tf-idf weighting + l2 norm of the whole batch on the device (term counts in HBM -> X in HBM, host-timed call incl. its "
+                                                     "sync) + one beam-search step on device-resident X, against value_host_abi (X arrives from pageable host memory)")
+                log(f"device featurizer: tf-idf weighting {tf_ms:.3f} ms; weighting + step = {n_total / ((tf_ms + ms_per_step) * 1e-3) / 1e6:.2f} M q/s")
+            except Exception as e:   # never let the extra line break the bench
+                log(f"device featurizer line skipped: {e}")
+
         # ---- CPU baseline + parity on a bounded sample (N=1 only)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(folder, Xs, model, beam, args.topk, args.cpu_seconds, log)
