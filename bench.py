@@ -303,11 +303,12 @@ def main():
                 tx = torch.from_numpy(Xs.indptr.astype(np.int64)).to(dev), torch.from_numpy(Xs.indices.astype(np.int32)).to(dev), \
                     torch.from_numpy(np.abs(Xs.data).astype(np.float32)).to(dev)
                 idf_t = torch.ones(Xs.shape[1], dtype=torch.float32, device=dev)
+                w_out = torch.empty(int(Xs.nnz), dtype=torch.float32, device=dev)
                 torch.cuda.synchronize()
                 ts = []
                 for it in range(4):
                     t0 = time.perf_counter()
-                    qh = clib.queries_tfidf_device(h, rows, Xs.shape[1], tx[0].data_ptr(), tx[1].data_ptr(), tx[2].data_ptr(), int(Xs.nnz), idf_t.data_ptr(), False, False, 2)
+                    qh = clib.queries_tfidf_device(h, rows, Xs.shape[1], tx[0].data_ptr(), tx[1].data_ptr(), tx[2].data_ptr(), int(Xs.nnz), idf_t.data_ptr(), False, False, 2, out_addr=w_out.data_ptr())
                     t1 = time.perf_counter() - t0
                     clib.queries_free(qh)
                     if it:

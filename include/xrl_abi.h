@@ -191,11 +191,12 @@ void* xrl_queries_from_device_drm(void* model, uint32_t rows, uint32_t cols, con
  * pecos/core/utils/tfidf.hpp:798-822; c_tfidf_predict, libpecos.cpp:427-445): a device CSR of term COUNTS (column ids ascending
  * inside every row, what the reference's tokenizer + n-gram lookup produce) -> binary / sublinear tf -> x idf (d_idf[cols], NULL =
  * use_idf false) -> l1 / l2 normalisation (norm_p 1 | 2), float32 operation by operation like the reference (bit-identical; with
- * sublinear_tf <= 1 ulp, the device's logf).  The returned query handle owns the weighted values and REFERENCES d_row_ptr /
- * d_col_idx (keep them alive); it feeds xrl_predict_device directly: the queries never visit the host. */
+ * sublinear_tf <= 1 ulp, the device's logf).  The weighted values go to d_out (nnz floats, caller-owned; may alias d_count) or, with
+ * d_out == NULL, into a buffer the returned query handle owns; the handle REFERENCES d_row_ptr / d_col_idx (and d_out): keep them
+ * alive.  It feeds xrl_predict_device directly: the queries never visit the host. */
 void* xrl_queries_tfidf_device(void* model, uint32_t rows, uint32_t cols, const uint64_t* d_row_ptr, const uint32_t* d_col_idx,
                                const float* d_count, uint64_t nnz, const float* d_idf, int binary, int sublinear_tf, int norm_p,
-                               void* hip_stream);
+                               float* d_out, void* hip_stream);
 /* The query form of XR-Transformer's concat_model (TransformerMatcher.concat_features + smat_util.hstack_csr,
  * pecos/xmc/xtransformer/matcher.py:864-890, model.py:589-603): [X_feat (device CSR, sparse_cols columns) | X_emb (device dense
  * rows x dense_cols)] assembled into one device CSR owned by the returned handle; every cell of the dense block becomes a stored

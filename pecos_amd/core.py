@@ -197,7 +197,7 @@ class corelib(object):
             "xrl_queries_from_device_csr": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64]),
             "xrl_queries_from_device_drm": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p]),
             "xrl_queries_concat_device": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_void_p]),
-            "xrl_queries_tfidf_device": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_int, c_void_p]),
+            "xrl_queries_tfidf_device": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
             "xrl_queries_concat_device_ex": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_int, c_void_p]),
             "xrl_queries_free": (None, [c_void_p]),
             "xrl_predict_device": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int]),
@@ -431,12 +431,12 @@ class corelib(object):
         return h
 
     def queries_tfidf_device(self, c_model, rows, cols, row_ptr_addr, col_idx_addr, count_addr, nnz, idf_addr=None, binary=False,
-                             sublinear_tf=False, norm_p=2, stream=None):
+                             sublinear_tf=False, norm_p=2, stream=None, out_addr=None):
         """Device CSR of term counts -> the reference's tf-idf weighting + normalisation on the device (tfidf.hpp:798-822);
-        the handle references row_ptr / col_idx (keep them alive) and owns the weighted values."""
+        the handle references row_ptr / col_idx (keep them alive); the weighted values go to out_addr (nnz floats) or a buffer it owns."""
         h = self.clib_float32.xrl_queries_tfidf_device(c_void_p(c_model), rows, cols, c_void_p(row_ptr_addr), c_void_p(col_idx_addr),
                                                        c_void_p(count_addr), nnz, c_void_p(idf_addr or 0), 1 if binary else 0,
-                                                       1 if sublinear_tf else 0, int(norm_p), c_void_p(stream or 0))
+                                                       1 if sublinear_tf else 0, int(norm_p), c_void_p(out_addr or 0), c_void_p(stream or 0))
         self._check()
         return h
 

@@ -844,7 +844,8 @@ void* xrl_queries_from_device_csr(void* model, uint32_t rows, uint32_t cols, con
 }
 
 void* xrl_queries_tfidf_device(void* model, uint32_t rows, uint32_t cols, const uint64_t* d_row_ptr, const uint32_t* d_col_idx,
-                               const float* d_count, uint64_t nnz, const float* d_idf, int binary, int sublinear_tf, int norm_p, void* hip_stream) {
+                               const float* d_count, uint64_t nnz, const float* d_idf, int binary, int sublinear_tf, int norm_p, float* d_out,
+                               void* hip_stream) {
     void* out = nullptr;
     guarded([&] {
         Model& m = *as_model(model);
@@ -852,11 +853,12 @@ void* xrl_queries_tfidf_device(void* model, uint32_t rows, uint32_t cols, const 
         use_device(m.device);
         auto q = std::make_unique<Queries>();
         q->device = m.device; q->nnz = nnz;
-        q->val.reserve(nnz * 4);                     // the handle owns the weighted values; row pointers and column ids stay the caller's
+        if (!d_out) q->val.reserve(nnz * 4);         // the handle owns the weighted values unless the caller supplies the buffer; row pointers and column ids stay the caller's
+        float* dst = d_out ? d_out : q->val.as<float>();
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m.stream;
-        launch_tfidf_weight(d_row_ptr, d_col_idx, d_count, d_idf, rows, cols, binary, sublinear_tf, norm_p, q->val.as<float>(), s);
+        launch_tfidf_weight(d_row_ptr, d_col_idx, d_count, d_idf, rows, cols, binary, sublinear_tf, norm_p, dst, s);
         XRL_HIP(hipStreamSynchronize(s));
-        q->dev.row_ptr = d_row_ptr; q->dev.col_idx = d_col_idx; q->dev.val = q->val.as<float>();
+        q->dev.row_ptr = d_row_ptr; q->dev.col_idx = d_col_idx; q->dev.val = dst;
         q->dev.rows = rows; q->dev.cols = cols; q->dev.dense = 0; q->dev.nnz = nnz;
         out = q.release();
     });
