@@ -269,6 +269,8 @@ int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char
  *   csrc/xrl_model.cpp) and returns its size in words, 0 when the tile does not fit cap_bytes (image may be NULL: size only). */
 uint32_t xrl_debug_split_chunk(const uint64_t* cum, uint32_t n, uint64_t limit);
 uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, uint32_t* ext_out);
+uint64_t xrl_debug_k1l_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, const uint32_t* rows, const uint32_t* rptr,
+                             const uint32_t* ent_col, const float* ent_val, uint64_t cap_bytes, uint32_t* image, uint64_t image_cap_words);   /* the K1L image (all rows in entry form) */
 uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, const uint32_t* rows, const uint32_t* rptr,
                              const uint32_t* ent_col, const float* ent_val, uint64_t cap_bytes, uint32_t* image, uint64_t image_cap_words);
 
@@ -285,7 +287,10 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *                         image in LDS, accumulators in registers) once a tile serves this many items on average
  *                         (0 = never, the default: profiles/r03_k1r_experiments.txt); needs the tile images (every tile of the layer fits in LDS; XRL_K1R=0
  *                         in the environment at load skips building them)
- *   "k1r_items_per_block" K1R: consecutive tile-sorted items per workgroup (default 1024)
+ *   "k1r_items_per_block" K1R / K1L: consecutive tile-sorted items per workgroup (default 1024)
+ *   "k1l_min_items"       sparse X: run a tile-format layer with the tile-resident kernel K1L (lane == entry, accumulators in LDS, four
+ *                         items per wavefront) once a tile serves this many items on average (0 = never); needs the K1L tile images
+ *                         (XRL_K1L=0 in the environment at load skips building them)
  *   "overlap_min_rows"    split predicts of at least this many rows into two batches on two streams (0 = never)
  *   "host_pipeline"       1 (default): c_xlinear_predict_* cut a large X into nnz-balanced row batches; batch b+1 is staged into
  *                         pinned memory and uploaded on a copy stream while batch b computes; 0: one synchronous upload

@@ -666,6 +666,7 @@ uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
             for (auto& l : m.layers) v += l->dev.wd ? 1u : 0u;
         }
         else if (!std::strcmp(attr, "nr_devices")) v = 1u + (uint32_t)m.replicas.size();   // additive: devices behind the handle (xrl_set_option "devices")
+        else if (!std::strcmp(attr, "nr_k1l_layers")) { for (auto& l : m.layers) v += l->dev.limg ? 1u : 0u; }   // additive: layers that carry K1L tile images
         else if (!std::strcmp(attr, "nr_k1r_layers")) {      // additive: layers that carry K1R tile images
             for (auto& l : m.layers) v += l->dev.img ? 1u : 0u;
         }
@@ -1072,11 +1073,28 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
     else if (!std::strcmp(key, "k1r_min_items")) m.k1r_min_items = (int)value;
     else if (!std::strcmp(key, "k1r_items_per_block")) m.k1r_items_per_block = (int)value;
+    else if (!std::strcmp(key, "k1l_min_items")) m.k1l_min_items = (int)value;
     else if (!std::strcmp(key, "k1g_variant")) m.k1g_variant = (int)value;   // K1G tile-shape alternative (tuning; results identical)
     else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
     else if (!std::strcmp(key, "k1_lds_pad")) m.k1_lds_pad = (int)value;   // debug: occupancy experiments
     else if (!std::strcmp(key, "k1_ablate")) m.k1_ablate = (int)value;     // debug: timing ablations only
     else fail(std::string("unknown option ") + key);
+}
+
+uint64_t xrl_debug_k1l_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, const uint32_t* rows, const uint32_t* rptr,
+                             const uint32_t* ent_col, const float* ent_val, uint64_t cap_bytes, uint32_t* image, uint64_t image_cap_words) {
+    uint64_t words = 0;
+    guarded([&] {
+        if (!rows || !rptr || !ent_col || !ent_val) fail("null argument");
+        words = k1l_image_words(rptr, nrows, ncols, w_rows, cap_bytes);
+        if (words == 0 || !image) return;
+        if (words > image_cap_words) fail("image buffer too small");
+        std::vector<Entry> ent(rptr[nrows]);
+        for (uint32_t e = 0; e < rptr[nrows]; ++e) ent[e] = Entry{ent_col[e], ent_val[e]};
+        std::memset(image, 0, words * 4);
+        k1l_build_image(rows, rptr, ent.data(), nrows, ncols, w_rows, words, image);
+    });
+    return words;
 }
 
 int xrl_set_option(void* model, const char* key, int64_t value) {
@@ -1101,7 +1119,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
                 r->device = dev;
                 r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->host_pipeline = m.host_pipeline;
                 r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers; r->k2_legacy = m.k2_legacy;
-                r->overlap_min_rows = m.overlap_min_rows; r->k1r_min_items = m.k1r_min_items; r->k1r_items_per_block = m.k1r_items_per_block;
+                r->overlap_min_rows = m.overlap_min_rows; r->k1r_min_items = m.k1r_min_items; r->k1r_items_per_block = m.k1r_items_per_block; r->k1l_min_items = m.k1l_min_items;
                 r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;
                 m.replicas.push_back(std::move(r));
             }

@@ -89,6 +89,10 @@ void launch_k1c_csc(const LayerDev& L, const uint64_t* col_ptr, const uint32_t* 
 // [X_feat | X_emb] -> one CSR on the device (concat_model's query form, matcher.py:864-890)
 void launch_concat_csr(const uint64_t* in_ptr, const uint32_t* in_idx, const float* in_val, const float* emb, uint32_t rows,
                        uint32_t sparse_cols, uint32_t dense_cols, int normalize_emb, uint64_t* out_ptr, uint32_t* out_idx, float* out_val, hipStream_t s);
+// K1L (xrl_k1l.hip): tile-resident, lane == entry, LDS accumulators, four items per wavefront
+bool k1l_eligible(const LayerDev& L);
+void launch_k1l(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
+                float* cand, uint32_t items_per_block, hipStream_t s);
 // xrl_features.hip: the weighting half of the reference's TF-IDF vectorizer (tfidf.hpp:798-822) on a device CSR of term counts
 void launch_tfidf_weight(const uint64_t* row_ptr, const uint32_t* col_idx, const float* count, const float* idf, uint32_t rows, uint32_t cols,
                          int binary, int sublinear_tf, int norm_p, float* out, hipStream_t s);

@@ -211,6 +211,44 @@ bool k1r_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* en
     return ok;
 }
 
+// ---- tile images of the tile-resident kernel K1L (xrl_k1l.hip): lane == entry, LDS accumulators -- every row stays in entry form.
+//      Layout (u32 words): [0] words [1] R [2] ncols [3] off_rank [4] off_rowext [5] off_bias [6] nw64 [7] off_entries [8..11] 0
+//        bits u64[nw64] | rank u16[nw64] | rowext u32[R] = first entry (20 bits) | (len - 1) << 20 | bias f32[ncols] |
+//        entries {column * 4, value bits}[E] (8-byte aligned, rows ascending, columns ascending inside a row) | 64 zero entries
+uint64_t k1l_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t cap_bytes) {
+    if (R >= 65536 || ncols > kMaxTileCols) return 0;
+    const uint64_t nw64 = ((uint64_t)w_rows + 63) / 64, E = rptr[R];
+    if (E >= (1u << 20)) return 0;
+    const uint64_t w = (12 + 2 * nw64 + (nw64 + 1) / 2 + R + ncols + 1 + 2 * (E + 64) + 3) & ~3ull;
+    return w * 4 <= cap_bytes ? w : 0;
+}
+void k1l_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* ent, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t words, uint32_t* b) {
+    const uint32_t nw64 = (uint32_t)(((uint64_t)w_rows + 63) / 64);
+    const uint32_t off_bits = 12, off_rank = off_bits + 2 * nw64, off_ext = off_rank + (nw64 + 1) / 2, off_bias = off_ext + R;
+    const uint32_t off_ent = (off_bias + ncols + 1u) & ~1u;
+    b[0] = (uint32_t)words; b[1] = R; b[2] = ncols; b[3] = off_rank; b[4] = off_ext; b[5] = off_bias; b[6] = nw64; b[7] = off_ent;
+    uint16_t* rank = reinterpret_cast<uint16_t*>(b + off_rank);
+    for (uint32_t r = 0; r < R; ++r) {
+        const uint32_t f = rows[r], len = rptr[r + 1] - rptr[r];
+        if (f >= w_rows) fail("layer: W row index out of range");
+        if (len == 0 || len > kMaxTileCols) fail("layer: internal error, tile row length");
+        b[off_bits + 2 * (f >> 6) + ((f >> 5) & 1u)] |= 1u << (f & 31u);
+        b[off_ext + r] = rptr[r] | ((len - 1u) << 20);
+    }
+    const uint32_t E = rptr[R];
+    for (uint32_t e = 0; e < E; ++e) { b[off_ent + 2 * e] = ent[e].col * 4u; std::memcpy(&b[off_ent + 2 * e + 1], &ent[e].val, 4); }
+    uint32_t run = 0;
+    for (uint32_t w = 0; w < nw64; ++w) {
+        rank[w] = (uint16_t)run;
+        run += (uint32_t)__builtin_popcount(b[off_bits + 2 * w]) + (uint32_t)__builtin_popcount(b[off_bits + 2 * w + 1]);
+    }
+    if ((uint64_t)off_ent + 2ull * (E + 64) > words) fail("layer: internal error, K1L tile image overflow");
+}
+
+static bool k1l_images_enabled() {   // XRL_K1L=0: do not build the K1L tile images
+    const char* e = std::getenv("XRL_K1L");
+    return !(e && e[0] == '0');
+}
 static bool k1r_images_enabled() {   // XRL_K1R=0: do not build the tile images of the tile-resident kernel (saves about the entries' size in HBM)
     const char* e = std::getenv("XRL_K1R");
     return !(e && e[0] == '0');
@@ -438,6 +476,33 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
         }
     }
 
+    // ---- K1L tile images (same policy: only when every tile fits)
+    std::vector<uint32_t> limg; std::vector<uint64_t> limg_off;
+    if (k1l_images_enabled() && T > 0 && !structure_only && L->max_tile_cols <= kMaxTileCols) {
+        std::vector<uint64_t> t_words(T, 0);
+        std::atomic<bool> all_fit{true};
+        parallel_for(T, [&](size_t t) {
+            t_words[t] = k1l_image_words(t_rptr[t].data(), tiles[t].nrows, tiles[t].ncols, W.rows, kMaxK1LImageBytes);
+            if (t_words[t] == 0) all_fit = false;
+        });
+        if (all_fit) {
+            uint64_t tot = 0; for (uint32_t t = 0; t < T; ++t) tot += t_words[t];
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && tot * 4 > free_b / 4) all_fit = false;
+        }
+        if (all_fit) {
+            limg_off.assign((size_t)T + 1, 0);
+            uint64_t max_words = 0;
+            for (uint32_t t = 0; t < T; ++t) { limg_off[t + 1] = limg_off[t] + t_words[t]; max_words = std::max(max_words, t_words[t]); }
+            limg.assign(limg_off[T] + 4, 0u);
+            parallel_for(T, [&](size_t t) {
+                k1l_build_image(t_rows[t].data(), t_rptr[t].data(), entries.data() + tiles[t].ent_base, tiles[t].nrows, tiles[t].ncols, W.rows,
+                                t_words[t], limg.data() + limg_off[t]);
+            });
+            L->max_tile_limg = max_words * 4;
+        }
+    }
+
     // algorithmic bytes of the REFERENCE chunk layout per parent:
     // 8*E_p (entries) + 4*R_p (row_idx) + 4*(R_p+1) (row_ptr as u32)
     std::vector<float> chunk_alg(P, 0.f);
@@ -472,6 +537,13 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
             std::memcpy(b + b[5], bias_prod.data() + tiles[t].col_begin, (size_t)tiles[t].ncols * 4);
         }
         L->d_img.upload(img); L->d_img_off.upload(img_off);
+    }
+    if (!limg.empty()) {
+        for (uint32_t t = 0; t < T; ++t) {
+            uint32_t* b = limg.data() + limg_off[t];
+            std::memcpy(b + b[5], bias_prod.data() + tiles[t].col_begin, (size_t)tiles[t].ncols * 4);
+        }
+        L->d_limg.upload(limg); L->d_limg_off.upload(limg_off);
     }
     // ---- device layout of rows: {start, length} per row, and the entries re-laid so that NO ROW TOUCHES MORE
     //      128-BYTE LINES THAN ITS LENGTH REQUIRES (a row that would straddle an extra line starts at the next
@@ -619,7 +691,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
                       L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap +
-                      L->d_img.cap + L->d_img_off.cap + L->d_bucket.cap + L->d_bitmap64.cap + L->d_wd.cap + L->d_dptile.cap + L->d_dtcol.cap;
+                      L->d_img.cap + L->d_img_off.cap + L->d_limg.cap + L->d_limg_off.cap + L->d_bucket.cap + L->d_bitmap64.cap + L->d_wd.cap + L->d_dptile.cap + L->d_dtcol.cap;
 
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
@@ -635,6 +707,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     d.max_tile_img = (uint32_t)std::min<uint64_t>(L->max_tile_img, 0xFFFFFFFFull);
     d.img = img.empty() ? nullptr : L->d_img.as<uint32_t>(); d.img_off = img.empty() ? nullptr : L->d_img_off.as<uint64_t>();
     d.img_max_short = L->img_max_short;
+    d.limg = limg.empty() ? nullptr : L->d_limg.as<uint32_t>(); d.limg_off = limg.empty() ? nullptr : L->d_limg_off.as<uint64_t>();
+    d.max_tile_limg = (uint32_t)std::min<uint64_t>(L->max_tile_limg, 0xFFFFFFFFull);
     d.bias = bias; d.has_bias = has_bias ? 1 : 0;
     d.wd = L->dense_bytes ? L->d_wd.as<uint32_t>() : nullptr; d.d_ld = d_ld; d.d_gp_log2 = d_gp_log2; d.d_max_tiles = d_max_tiles;
     d.d_ptile = L->dense_bytes ? L->d_dptile.as<uint32_t>() : nullptr; d.d_tcol = L->dense_bytes ? L->d_dtcol.as<uint32_t>() : nullptr;

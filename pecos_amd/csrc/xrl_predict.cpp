@@ -90,7 +90,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     uint64_t slots_max = 1;
     for (size_t l = 0; l < T; ++l) slots_max = std::max<uint64_t>(slots_max, nb * beam_in[l] * m.layers[l]->max_tiles_per_parent);
     for (int ln = 0; ln < lanes; ++ln) ws.lane[ln].items.reserve(slots_max * k0_item_bytes());
-    // per layer: 0 = K1 on the items in natural order, 1 = K1 on tile-sorted items, 2 = K1R (tile-resident:
+    // per layer: 0 = K1 on the items in natural order, 1 = K1 on tile-sorted items, 2 = K1R / 4 = K1L (tile-resident:
     // tile-sorted items, tile image in LDS) -- chosen when every tile image fits and a tile serves enough items
     auto layer_mode = [&](size_t l, uint64_t rows) -> int {
         const Layer& L = *m.layers[l];
@@ -99,6 +99,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         // 3 = K1G: dense queries against a dense-format layer as a tiled SGEMM over tile-sorted items
         if (X.dense && m.dense_layers && m.k1g_min_items > 0 && !csc && k1g_cols(L.dev) != 0 && k[l] <= k2_max_k() &&
             slots / std::max<uint32_t>(1, L.n_tiles) >= (uint64_t)m.k1g_min_items) return 3;
+        if (!X.dense && X.nnz > 0 && m.k1l_min_items > 0 && k1l_eligible(L.dev) && slots / L.n_tiles >= (uint64_t)m.k1l_min_items) return 4;
         if (!X.dense && X.nnz > 0 && m.k1r_min_items > 0 && k1r_eligible(L.dev) && slots / L.n_tiles >= (uint64_t)m.k1r_min_items) return 2;
         if (m.sort_min_tiles > 0 && L.n_tiles >= (uint32_t)m.sort_min_tiles) return 1;
         return 0;
@@ -229,7 +230,9 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             const uint64_t n_slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
             if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
             if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));   // K1 launches take turns across the lanes
-            if (mode == 2)
+            if (mode == 4)
+                timed("k1l_sparse", (uint32_t)l, [&] { launch_k1l(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.cand.as<float>(), (uint32_t)std::max(16, m.k1r_items_per_block), S); });
+            else if (mode == 2)
                 timed("k1r_sparse", (uint32_t)l, [&] { launch_k1r(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.cand.as<float>(), (uint32_t)std::max(16, m.k1r_items_per_block), S); });
             else
                 timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] {

@@ -287,6 +287,31 @@ def _k1r_walk(img, x_idx, x_val, w_rows):
     return acc[:ncols]
 
 
+def _k1l_walk(img, x_idx, x_val, w_rows):
+    """xrl_k1l.hip's traversal of its tile image: probe, row extent, the row's entries in stored order, LDS accumulators."""
+    R, ncols, off_rank, off_ext, off_bias, off_ent = (int(img[k]) for k in (1, 2, 3, 4, 5, 7))
+    assert off_ent % 2 == 0
+    rank16 = img[off_rank:].view(np.uint16)
+    acc = np.zeros(ncols, dtype=np.float32)
+    for f, v in zip(x_idx, x_val):
+        if f >= w_rows:
+            continue
+        w = int(f) >> 6
+        bits = int(img[12 + 2 * w]) | (int(img[12 + 2 * w + 1]) << 32)
+        b = int(f) & 63
+        if not (bits >> b) & 1:
+            continue
+        slot = int(rank16[w]) + bin(bits & ((1 << b) - 1)).count("1")
+        assert slot < R
+        ext = int(img[off_ext + slot])
+        start, n = ext & 0xFFFFF, (ext >> 20) + 1
+        for e in range(start, start + n):
+            c4 = int(img[off_ent + 2 * e]); wv = img[off_ent + 2 * e + 1:off_ent + 2 * e + 2].view(np.float32)[0]
+            assert c4 % 4 == 0 and c4 // 4 < ncols
+            acc[c4 // 4] = np.float32(acc[c4 // 4] + np.float32(np.float32(v) * wv))
+    return acc
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_k1r_tile_image_walk(seed):
     # the LDS image of the tile-resident kernel, built by the model compiler's host code, walked the way the kernel walks it
@@ -308,6 +333,8 @@ def test_k1r_tile_image_walk(seed):
     assert 2 <= img[7] <= 8
     # a tile that cannot fit is refused, not truncated
     assert clib.debug_k1r_image(w_rows, ncols, rows, rptr, ent_col, ent_val, cap_bytes=64) is None
+    limg = clib.debug_k1l_image(w_rows, ncols, rows, rptr, ent_col, ent_val, cap_bytes=512 * 1024)    # the same tile in K1L's form (every row as entries)
+    assert limg is not None and limg[0] == len(limg) and limg[1] == len(rows) and not limg[int(limg[7]) + 2 * len(ent_col):int(limg[7]) + 2 * len(ent_col) + 128].any()
     for _ in range(5):
         nx = int(rng.integers(0, min(w_rows, 200)))
         x_idx = np.sort(rng.choice(w_rows + 5, size=nx, replace=False))
@@ -319,6 +346,8 @@ def test_k1r_tile_image_walk(seed):
                     want[c] = np.float32(want[c] + np.float32(np.float32(v) * vals[f, c]))
         got = _k1r_walk(img, x_idx, x_val, w_rows)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        if limg is not None:
+            assert np.array_equal(_k1l_walk(limg, x_idx, x_val, w_rows).view(np.uint32), want.view(np.uint32))
 
 
 def test_concat_features_vs_reference_goldens(manifest):

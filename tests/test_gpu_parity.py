@@ -93,6 +93,13 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
             P = m.predict(X, **c["kwargs"])
             assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1R items_per_block={ipb}")
         clib.set_option(m.model.model_chain, "k1r_min_items", 0)
+        # tile-resident kernel K1L (lane == entry, LDS accumulators, four items per wavefront), short and long item runs
+        for ipb in (16, 1024):
+            clib.set_option(m.model.model_chain, "k1l_min_items", 1)
+            clib.set_option(m.model.model_chain, "k1r_items_per_block", ipb)
+            P = m.predict(X, **c["kwargs"])
+            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1L items_per_block={ipb}")
+        clib.set_option(m.model.model_chain, "k1l_min_items", 0)
         clib.set_option(m.model.model_chain, "dense_layers", 1)
 
 
@@ -136,6 +143,11 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         for pp in (None, "sigmoid"):
             kw = dict(beam_size=cfg["beam"], only_topk=10, **({"post_processor": pp} if pp else {}))
             assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} k1r_min_items={k1r} {pp}")
+    for pp in (None, "sigmoid"):
+        clib.set_option(m.model.model_chain, "k1l_min_items", 1)
+        kw = dict(beam_size=cfg["beam"], only_topk=10, **({"post_processor": pp} if pp else {}))
+        assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} K1L {pp}")
+        clib.set_option(m.model.model_chain, "k1l_min_items", 0)
     # the forced run really went through the tile-resident kernel
     clib.set_option(m.model.model_chain, "k1r_min_items", 1)
     clib.profile_enable(m.model.model_chain, True); clib.profile_reset(m.model.model_chain)
@@ -556,10 +568,10 @@ def test_hash_chunked_sparse_queries_bit_exact(manifest, XLM, clib, oracle_mod, 
         X = load_X(os.path.join(GOLDEN, "synth", c["model"] + "__X.npz"))
         G = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"]))
         ex = EXACT_PP(c["kwargs"].get("post_processor"))
-        for dl, k1r in ((1, 0), (2, 0), (0, 0), (0, 1)):
-            clib.set_option(h, "dense_layers", dl); clib.set_option(h, "k1r_min_items", k1r)
-            assert_same_topk(m.predict(X, **c["kwargs"]), G, exact_scores=ex, what=f"HASH_CHUNKED {c} dense_layers={dl} k1r={k1r}")
-        clib.set_option(h, "dense_layers", 1); clib.set_option(h, "k1r_min_items", 0)
+        for dl, k1r, k1l in ((1, 0, 0), (2, 0, 0), (0, 0, 0), (0, 1, 0), (0, 0, 1)):
+            clib.set_option(h, "dense_layers", dl); clib.set_option(h, "k1r_min_items", k1r); clib.set_option(h, "k1l_min_items", k1l)
+            assert_same_topk(m.predict(X, **c["kwargs"]), G, exact_scores=ex, what=f"HASH_CHUNKED {c} dense_layers={dl} k1r={k1r} k1l={k1l}")
+        clib.set_option(h, "dense_layers", 1); clib.set_option(h, "k1r_min_items", 0); clib.set_option(h, "k1l_min_items", 0)
     if oracle_mod.ref_available():
         import xrl_synth
         folder = str(tmp_path / "m")
@@ -623,6 +635,10 @@ def test_headline_config_full_size_all_rows_vs_reference(XLM, clib, oracle_mod):
         clib.set_option(h, "k1r_min_items", 1)
         assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, tile-resident leaf (K1R)")
         clib.set_option(h, "k1r_min_items", 0)
+    if clib.xlinear_get_int_attr(h, "nr_k1l_layers") > 0:
+        clib.set_option(h, "k1l_min_items", 1)
+        assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, tile-resident leaf (K1L)")
+        clib.set_option(h, "k1l_min_items", 0)
 
 
 @pytest.mark.timeout(2400)
