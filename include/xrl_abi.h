@@ -285,12 +285,12 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *                         Only for models loaded from a folder.  c_xlinear_get_int_attr "nr_devices" reads it back.
  *   "k1r_min_items"       sparse X: run a tile-format layer with the tile-RESIDENT kernel K1R (tile-sorted items, the tile's
  *                         image in LDS, accumulators in registers) once a tile serves this many items on average
- *                         (0 = never, the default: profiles/r03_k1r_experiments.txt); needs the tile images (every tile of the layer fits in LDS; XRL_K1R=0
- *                         in the environment at load skips building them)
+ *                         (0 = never, the default: profiles/r03_k1r_experiments.txt); needs the tile images (XRL_K1R=1 in the environment at load;
+ *                         built only when every tile of the layer fits in LDS)
  *   "k1r_items_per_block" K1R / K1L: consecutive tile-sorted items per workgroup (default 1024)
  *   "k1l_min_items"       sparse X: run a tile-format layer with the tile-resident kernel K1L (lane == entry, accumulators in LDS, four
  *                         items per wavefront) once a tile serves this many items on average (0 = never); needs the K1L tile images
- *                         (XRL_K1L=0 in the environment at load skips building them)
+ *                         (XRL_K1L=1 in the environment at load)
  *   "overlap_min_rows"    split predicts of at least this many rows into two batches on two streams (0 = never)
  *   "host_pipeline"       1 (default): c_xlinear_predict_* cut a large X into nnz-balanced row batches; batch b+1 is staged into
  *                         pinned memory and uploaded on a copy stream while batch b computes; 0: one synchronous upload
@@ -306,7 +306,7 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *   "k1g_variant"         1: the alternative register-tile / panel shapes of K1G (A/B, tests; results identical)
  *   "k2_legacy"           1: round-1 insertion top-k kernels instead of the ballot-bisection K2 (A/B, tests)
  *   "k1_wpb", "k1_lds_pad", "k1_ablate"   debug: wavefronts per K1 workgroup, extra LDS per wavefront, phase ablation
- * Environment read at model load: XRL_K1R=0 (do not build K1R tile images), XRL_LOOKUP=bitmap|bitmap64|bucket (force the row
+ * Environment read at model load: XRL_K1R=1 / XRL_K1L=1 (build the tile images of the optional tile-resident kernels), XRL_LOOKUP=bitmap|bitmap64|bucket (force the row
  * lookup structure; default per layer: bucket table if rank-bitmaps would take more than a quarter of the free HBM, else
  * 64-feature words carrying the first row's extent on sparse tiles, else 32-feature words),
  * XRL_ROW_ALIGN=0 (keep tile rows packed instead of line-aligned), XRL_MAX_TILE_ENTRIES (lower the tile splitter's

@@ -245,13 +245,13 @@ void k1l_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* en
     if ((uint64_t)off_ent + 2ull * (E + 64) > words) fail("layer: internal error, K1L tile image overflow");
 }
 
-static bool k1l_images_enabled() {   // XRL_K1L=0: do not build the K1L tile images
+static bool k1l_images_enabled() {   // XRL_K1L=1: build the K1L tile images (the kernel is an option, default off: profiles/r03_k1r_experiments.txt)
     const char* e = std::getenv("XRL_K1L");
-    return !(e && e[0] == '0');
+    return e && e[0] && e[0] != '0';
 }
-static bool k1r_images_enabled() {   // XRL_K1R=0: do not build the tile images of the tile-resident kernel (saves about the entries' size in HBM)
+static bool k1r_images_enabled() {   // XRL_K1R=1: build the K1R tile images (about the entries' size in HBM; the kernel is an option, default off)
     const char* e = std::getenv("XRL_K1R");
-    return !(e && e[0] == '0');
+    return e && e[0] && e[0] != '0';
 }
 
 std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, float bias, uint32_t only_topk,
