@@ -278,6 +278,8 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *   "k1_group"            lanes per (query, tile) item in K1: 0 = auto, else a power of two <= 64
  *   "max_batch_rows"      rows of X per internal batch (0 = auto: candidate buffer <= 6 GiB)
  *   "sort_min_tiles"      tile-sort the items of layers with at least this many tiles (0 = never)
+ *   "host_register"       host ABI: 1 = page-lock the caller's X arrays in place for the duration of the call (hipHostRegister) and let
+ *                         the copy engine read them directly, instead of staging them through two pinned buffers with host threads
  *   "devices"             MULTI-GPU BEHIND THE DROP-IN ENTRY POINTS: the handle serves c_xlinear_predict_{csr,drm}_f32 from this many
  *                         devices -- its own plus value-1 replicas of the compiled model on the following devices (wrapping around when
  *                         the box has fewer).  A predict then cuts X into nnz-balanced row shards, one host thread + stream + pinned

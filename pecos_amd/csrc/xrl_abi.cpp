@@ -194,6 +194,25 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     for (auto& e : up) XRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const uint32_t k = effective_topk(m, o.only_topk);
     reserve_outputs(m, rows, k);
+    // option host_register: page-lock the caller's arrays in place for the duration of the call and let the copy engine read them
+    // directly (no staging memcpy); falls back to staging when the registration fails
+    bool reg_idx = false, reg_val = false;
+    if (m.host_register) {
+        if (is_csr) {
+            reg_idx = hipHostRegister(const_cast<uint32_t*>(Xs->col_idx), elems * 4, hipHostRegisterDefault) == hipSuccess;
+            reg_val = reg_idx && hipHostRegister(const_cast<float*>(Xs->val), elems * 4, hipHostRegisterDefault) == hipSuccess;
+            if (reg_idx && !reg_val) { (void)hipHostUnregister(const_cast<uint32_t*>(Xs->col_idx)); reg_idx = false; }
+        } else {
+            reg_val = hipHostRegister(const_cast<float*>(Xd->val), elems * 4, hipHostRegisterDefault) == hipSuccess;
+        }
+        (void)hipGetLastError();
+    }
+    const bool direct = reg_val;
+    auto unregister = [&] {
+        if (reg_idx) (void)hipHostUnregister(const_cast<uint32_t*>(Xs->col_idx));
+        if (reg_val) (void)hipHostUnregister(const_cast<float*>(is_csr ? Xs->val : Xd->val));
+        reg_idx = reg_val = false;
+    };
     try {
         uint64_t chunk = 0;                                                 // staged chunks so far: slot = chunk & 1
         for (uint32_t b = 0; b < n_batch; ++b) {
@@ -202,6 +221,17 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
             for (uint64_t c0 = e0; c0 < e1; c0 += chunk_elems, ++chunk) {
                 const int slot = (int)(chunk & 1u);
                 const uint64_t n = std::min(chunk_elems, e1 - c0);
+                if (direct) {
+                    if (is_csr) {
+                        XRL_HIP(hipMemcpyAsync(ws.x_idx.as<uint32_t>() + c0, Xs->col_idx + c0, n * 4, hipMemcpyHostToDevice, m.copy_stream));
+                        XRL_HIP(hipMemcpyAsync(ws.x_val.as<float>() + c0, Xs->val + c0, n * 4, hipMemcpyHostToDevice, m.copy_stream));
+                    } else {
+                        XRL_HIP(hipMemcpyAsync(ws.x_val.as<float>() + c0, Xd->val + c0, n * 4, hipMemcpyHostToDevice, m.copy_stream));
+                    }
+                    XRL_HIP(hipEventRecord(up[slot], m.copy_stream));
+                    last_slot = slot;
+                    continue;
+                }
                 if (chunk >= 2) XRL_HIP(hipEventSynchronize(up[slot]));    // the slot's previous upload has left the staging buffer
                 char* st = ws.stage[slot].as<char>();
                 if (is_csr) {
@@ -226,9 +256,11 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     } catch (...) {
         (void)hipStreamSynchronize(m.copy_stream); (void)hipStreamSynchronize(m.stream);
         for (auto& e : up) (void)hipEventDestroy(e);
+        unregister();
         throw;
     }
     for (auto& e : up) (void)hipEventDestroy(e);
+    unregister();
 }
 
 // csr_t::create_pycsr over the row shards of several devices: ONE synchronous allocator call on the calling thread, then every
@@ -1065,7 +1097,8 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     if (!std::strcmp(key, "k1_group")) m.k1_group = (int)value;
     else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
     else if (!std::strcmp(key, "sort_min_tiles")) m.sort_min_tiles = (int)value;
-    else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;   // 0: the host ABI uploads X in one piece before computing
+    else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;
+    else if (!std::strcmp(key, "host_register")) m.host_register = (int)value;   // 1: page-lock the caller's X in place (hipHostRegister) instead of staging it through pinned buffers   // 0: the host ABI uploads X in one piece before computing
     else if (!std::strcmp(key, "k1q_fuse")) m.k1q_fuse = (int)value;           // 0: one K1Q launch per dense-format layer
     else if (!std::strcmp(key, "k1g_min_items")) m.k1g_min_items = (int)value;   // dense X: queries per parent from which a dense-format layer runs the tiled SGEMM K1G (0 = never)
     else if (!std::strcmp(key, "dense_layers")) m.dense_layers = (int)value;   // 0: never run the fused dense-format kernel K1Q
@@ -1117,7 +1150,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
                 use_device(dev);
                 std::unique_ptr<Model> r = m.src_kind == 0 ? load_model_from_disk(m.src_path, m.weight_matrix_type) : load_mmap_model_from_disk(m.src_path);
                 r->device = dev;
-                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->host_pipeline = m.host_pipeline;
+                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->host_pipeline = m.host_pipeline; r->host_register = m.host_register;
                 r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers; r->k2_legacy = m.k2_legacy;
                 r->overlap_min_rows = m.overlap_min_rows; r->k1r_min_items = m.k1r_min_items; r->k1r_items_per_block = m.k1r_items_per_block; r->k1l_min_items = m.k1l_min_items;
                 r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;
