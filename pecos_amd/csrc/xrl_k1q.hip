@@ -64,7 +64,9 @@ template <int NS> struct K1QCfg {
 };
 
 // One layer for one query (one wavefront): beam in s_bidx / s_bval[0..cnt) -> beam out in the same arrays; returns the new count.
-template <int NS, int PPC, bool DENSEX>
+// BIASF: the accumulators start at the bias product (dense X; sparse X under HASH_CHUNKED, inference.hpp:716-722) instead of receiving it
+// last -- a compile-time switch: as a run-time one it cost the widest kernel 8 VGPRs and a wavefront per SIMD
+template <int NS, int PPC, bool DENSEX, bool BIASF>
 __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesDev& X, uint64_t xrow, uint32_t cnt_in,
                                                uint32_t* s_bidx, float* s_bval, uint2* sc, int lane) {
     constexpr int U = K1QCfg<NS>::U;
@@ -92,7 +94,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         child[r] = v ? cb + col : 0u;
         ps[r] = pscore; valid[r] = v;
         // dense queries: bias FIRST (inference.hpp:824-830); bias_prod holds fl32(bias * w) or +0.0
-        acc[r] = ((DENSEX || Ly.bias_first) && Ly.has_bias) ? Ly.bias_prod[child[r]] : 0.0f;
+        acc[r] = (BIASF && Ly.has_bias) ? Ly.bias_prod[child[r]] : 0.0f;
     }
     wave_sync_lds();                                                   // the beam has been read: the arrays may be overwritten below
 
@@ -162,7 +164,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
         float s = acc[r];
-        if (!DENSEX && !Ly.bias_first && Ly.has_bias) s = __fadd_rn(s, Ly.bias_prod[child[r]]);
+        if (!BIASF && Ly.has_bias) s = __fadd_rn(s, Ly.bias_prod[child[r]]);
         float v = pp_transform<PPC>(Ly.pp_kind, Ly.pp_p, s);
         if (!Ly.first_layer) v = pp_combine(Ly.pp_kind, v, ps[r]);
         sbits[r] = __float_as_uint(v);
@@ -184,7 +186,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
 // The fused kernel of narrow layers is compiled for 7 wavefronts per SIMD (72 VGPRs instead of the 74 the compiler settles on,
 // no spills; the exp-family post-processors would spill and keep the default): measured 6.57 vs 6.73 ms on Amazon-670K's levels 0-3; 8 (64 VGPRs, 8 spilled) loses, and so does any target
 // on the wide single-layer kernels.
-template <int NSMAX, int PPC, bool DENSEX, bool MULTI>
+template <int NSMAX, int PPC, bool DENSEX, bool MULTI, bool BIASF>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI && NSMAX <= 3 && PPC == 0) ? 7 : 1, 8))) k1q_kernel(K1QArgs a) {
     __shared__ uint2 sc_all[4 * 64];
     __shared__ uint32_t bidx_all[4 * 64];
@@ -208,14 +210,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
-        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
     }
     if ((uint32_t)lane < cnt) {
         const size_t o = (size_t)q * a.out_stride + (uint32_t)lane;
@@ -263,9 +265,11 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     a.out_idx = out_idx; a.out_val = out_val; a.out_cnt = out_cnt; a.out_stride = out_stride;
     a.row0 = Ps[0].row0; a.nrows = Ps[0].nrows;
     const dim3 grid((a.nrows + 3u) / 4u), block(256);
+    const bool bias_first = Ps[0].bias_first != 0;
 #define XRL_K1Q_M(NN, MM) do { \
-        if (X.dense) { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, true, MM>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, true, MM>), grid, block, 0, s, a); } \
-        else { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, false, MM>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, false, MM>), grid, block, 0, s, a); } } while (0)
+        if (X.dense) { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, true, MM, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, true, MM, true>), grid, block, 0, s, a); } \
+        else if (bias_first) { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, false, MM, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, false, MM, true>), grid, block, 0, s, a); } \
+        else { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, false, MM, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, false, MM, false>), grid, block, 0, s, a); } } while (0)
 #define XRL_K1Q(NN) do { if (n > 1) XRL_K1Q_M(NN, true); else XRL_K1Q_M(NN, false); } while (0)
     switch (k1q_kernel_bucket(nsmax)) {
     case 1: XRL_K1Q(1); break;
