@@ -344,6 +344,8 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
 
     def matched_bytes(name, layer):
         s, li = st[layer], linfo[layer]
+        if name.endswith("_rest") or name.startswith("k0b"):     # second phase of a bound-pruned layer: its (few) items are counted with the first phase's kernel
+            return 0.0
         if name.startswith("k1q_fused"):                          # several dense-format layers in one launch: "k1q_fused[_x]_<first>_<last>"
             l0, l1 = (int(v) for v in name.split("_")[-2:])
             return x_bytes_q + sum(4.0 * st[ll]["x_cols"] for ll in range(l0, l1 + 1)) + 16.0 * k * rows

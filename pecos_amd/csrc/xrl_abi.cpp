@@ -1107,6 +1107,7 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     else if (!std::strcmp(key, "k1r_min_items")) m.k1r_min_items = (int)value;
     else if (!std::strcmp(key, "k1r_items_per_block")) m.k1r_items_per_block = (int)value;
     else if (!std::strcmp(key, "k1l_min_items")) m.k1l_min_items = (int)value;
+    else if (!std::strcmp(key, "prune")) m.prune = (int)value;            // 0: evaluate every candidate of every beam parent (no exact bound pruning)
     else if (!std::strcmp(key, "k1g_variant")) m.k1g_variant = (int)value;   // K1G tile-shape alternative (tuning; results identical)
     else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
     else if (!std::strcmp(key, "k1_lds_pad")) m.k1_lds_pad = (int)value;   // debug: occupancy experiments
@@ -1152,7 +1153,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
                 r->device = dev;
                 r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->host_pipeline = m.host_pipeline; r->host_register = m.host_register;
                 r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers; r->k2_legacy = m.k2_legacy;
-                r->overlap_min_rows = m.overlap_min_rows; r->k1r_min_items = m.k1r_min_items; r->k1r_items_per_block = m.k1r_items_per_block; r->k1l_min_items = m.k1l_min_items;
+                r->overlap_min_rows = m.overlap_min_rows; r->k1r_min_items = m.k1r_min_items; r->k1r_items_per_block = m.k1r_items_per_block; r->k1l_min_items = m.k1l_min_items; r->prune = m.prune;
                 r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;
                 m.replicas.push_back(std::move(r));
             }

@@ -42,7 +42,11 @@ struct LayerPlan {
 // K0  prolongate: per query, offsets of every beam parent's child block + candidate count, and one
 //     16-byte item descriptor per (query, beam slot, tile-in-parent) for K1.
 void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, uint32_t* cand_off,
-                          uint32_t* ncand, void* items, hipStream_t s);
+                          uint32_t* ncand, void* items, hipStream_t s, uint32_t item_ranks = 0xFFFFFFFFu /* beam slots that get item descriptors */);
+// bound-pruned layers, second phase: items of the beam slots >= first_rank of the queries with done[q] == 0, compact; *n_items = their number
+void launch_k0b_remaining(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* done,
+                          uint32_t first_rank, void* items, uint32_t* n_items, hipStream_t s);
+bool k2_wave_path(const LayerPlan& P, bool legacy);   // the register top-k kernel serves this layer (what bound pruning needs)
 size_t k0_item_bytes();
 // K1  (query, tile) inner products + bias + post-processor + combine, one item per G lanes.
 void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, const uint32_t* n_items,
@@ -59,12 +63,14 @@ size_t sort_hist_bytes(uint64_t n_slots, uint32_t n_tiles);
 // K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
-                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, bool legacy = false /* round-1 insertion kernels (A/B) */);
+                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, bool legacy = false /* round-1 insertion kernels (A/B) */,
+                    uint32_t rank_limit = 0 /* > 0: only the candidates of the first rank_limit beam slots */, uint32_t limited_cands = 0 /* their maximum number */,
+                    uint32_t* done = nullptr /* out: that selection is final (exact bound, see K2Args) */, const uint32_t* skip_done = nullptr /* queries to skip */);
 // stats: sum over (query, parent) of the reference chunk's algorithmic bytes, and of candidates
 constexpr int kStatsPerLayer = 8;   // [0] reference-chunk bytes, [1] candidates, [2] items, [3] probes, [4] matched rows, [5] their entries,
                                     // [6] tile columns over the items, [7] query features x tile columns over the items
 void launch_stats(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, const uint32_t* ncand, const void* items,
-                  double* out8, hipStream_t s);
+                  double* out8, hipStream_t s, uint64_t item_slots = 0 /* slots of `items` (0: rows x beam x tiles per parent) */);
 // K3  sparse_inner_products (pecos/core/utils/matrix.hpp:1049-1060), 4 layout combos
 void launch_k3_inner_products(const uint64_t* x_ptr, const uint32_t* x_idx, const float* x_val, int x_dense,
                               const uint64_t* w_ptr, const uint32_t* w_idx, const float* w_val, int w_dense,

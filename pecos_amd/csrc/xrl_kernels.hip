@@ -47,7 +47,7 @@ namespace xrl {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k0_prolongate(const uint32_t* __restrict__ chunk_col, const uint32_t* __restrict__ ptile,
-              const TileDesc* __restrict__ tiles, uint32_t nrows, uint32_t beam_in, uint32_t TT, uint32_t cand_stride,
+              const TileDesc* __restrict__ tiles, uint32_t nrows, uint32_t beam_in, uint32_t item_ranks, uint32_t TT, uint32_t cand_stride,
               int implicit_root, const uint32_t* __restrict__ p_idx, const float* __restrict__ p_val,
               const uint32_t* __restrict__ p_cnt, uint32_t p_stride, uint32_t* __restrict__ cand_off,
               uint32_t* __restrict__ ncand, ItemDesc* __restrict__ items, const uint64_t* __restrict__ x_row_ptr) {
@@ -57,8 +57,10 @@ k0_prolongate(const uint32_t* __restrict__ chunk_col, const uint32_t* __restrict
     if (x_row_ptr) { xb = x_row_ptr[q]; xl = (uint32_t)(x_row_ptr[q + 1] - xb); }
     const uint32_t cnt = implicit_root ? 1u : min(p_cnt[q], beam_in);
     uint32_t off = 0;
+    // item descriptors are written for the first `item_ranks` beam slots only (all of them unless the layer runs the bound-pruned
+    // two-phase scheme, where the later slots' items are laid out by k0b_remaining for the queries that still need them)
     for (uint32_t j = 0; j < beam_in; ++j) {
-        ItemDesc* it = items + ((size_t)q * beam_in + j) * TT;
+        ItemDesc* it = items + ((size_t)q * item_ranks + j) * TT;
         uint32_t nt = 0;
         if (j < cnt) {
             const uint32_t parent = implicit_root ? 0u : p_idx[(size_t)q * p_stride + j];
@@ -66,26 +68,71 @@ k0_prolongate(const uint32_t* __restrict__ chunk_col, const uint32_t* __restrict
             const uint32_t cb = chunk_col[parent], t0 = ptile[parent];
             nt = ptile[parent + 1] - t0;
             cand_off[(size_t)q * beam_in + j] = off;
-            for (uint32_t tt = 0; tt < nt; ++tt)
-                it[tt] = make_item(q, t0 + tt, q * cand_stride + off + (tiles[t0 + tt].col_begin - cb), ps, xb, xl);
+            if (j < item_ranks)
+                for (uint32_t tt = 0; tt < nt; ++tt)
+                    it[tt] = make_item(q, t0 + tt, q * cand_stride + off + (tiles[t0 + tt].col_begin - cb), ps, xb, xl);
             off += chunk_col[parent + 1] - cb;
         }
-        for (uint32_t tt = nt; tt < TT; ++tt) it[tt] = make_item(q, kNoTile, 0u, 0.f, 0, 0u);
+        if (j < item_ranks) for (uint32_t tt = nt; tt < TT; ++tt) it[tt] = make_item(q, kNoTile, 0u, 0.f, 0, 0u);
     }
     ncand[q] = off;
 }
 
 void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, uint32_t* cand_off,
-                          uint32_t* ncand, void* items, hipStream_t s) {
+                          uint32_t* ncand, void* items, hipStream_t s, uint32_t item_ranks) {
     if (P.nrows == 0) return;
     if ((uint64_t)P.nrows * P.cand_stride > 0xFFFFFFFFull) fail("k0: candidate buffer exceeds 2^32 floats; lower max_batch_rows");
     hipLaunchKernelGGL(k0_prolongate, dim3((P.nrows + 255) / 256), dim3(256), 0, s, L.chunk_col, L.ptile, L.tiles,
-                       P.nrows, P.beam_in, L.max_tiles_per_parent, P.cand_stride, P.implicit_root, prev.idx, prev.val,
+                       P.nrows, P.beam_in, std::min(item_ranks, P.beam_in), L.max_tiles_per_parent, P.cand_stride, P.implicit_root, prev.idx, prev.val,
                        prev.cnt, prev.stride, cand_off, ncand, static_cast<ItemDesc*>(items),
                        X.dense ? nullptr : X.row_ptr + P.row0);
     XRL_LAUNCH_CHECK();
 }
 size_t k0_item_bytes() { return sizeof(ItemDesc); }
+
+// Bound-pruned layers, second phase: the items of beam slots >= first_rank, for the queries whose first phase did NOT already
+// prove its top-k final (done[q] == 0), appended to a compact list (one atomicAdd per wavefront).
+__global__ void __launch_bounds__(256)
+k0b_remaining(const uint32_t* __restrict__ chunk_col, const uint32_t* __restrict__ ptile, const TileDesc* __restrict__ tiles,
+              uint32_t nrows, uint32_t beam_in, uint32_t first_rank, uint32_t cand_stride, const uint32_t* __restrict__ p_idx,
+              const float* __restrict__ p_val, const uint32_t* __restrict__ p_cnt, uint32_t p_stride, const uint32_t* __restrict__ cand_off,
+              const uint32_t* __restrict__ done, ItemDesc* __restrict__ items, uint32_t* __restrict__ n_items,
+              const uint64_t* __restrict__ x_row_ptr) {
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = q < nrows && !done[q];
+    const uint32_t cnt = live ? min(p_cnt[q], beam_in) : 0u;
+    uint32_t n = 0;
+    for (uint32_t j = first_rank; j < cnt; ++j) { const uint32_t parent = p_idx[(size_t)q * p_stride + j]; n += ptile[parent + 1] - ptile[parent]; }
+    uint32_t incl = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += y; }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(n_items, total);
+    base = (uint32_t)__shfl((int)base, 63, 64) + incl - n;
+    if (n == 0) return;
+    uint64_t xb = 0; uint32_t xl = 0;
+    if (x_row_ptr) { xb = x_row_ptr[q]; xl = (uint32_t)(x_row_ptr[q + 1] - xb); }
+    for (uint32_t j = first_rank; j < cnt; ++j) {
+        const uint32_t parent = p_idx[(size_t)q * p_stride + j];
+        const float ps = p_val[(size_t)q * p_stride + j];
+        const uint32_t cb = chunk_col[parent], t0 = ptile[parent], nt = ptile[parent + 1] - t0;
+        const uint32_t off = cand_off[(size_t)q * beam_in + j];
+        for (uint32_t tt = 0; tt < nt; ++tt)
+            items[base++] = make_item(q, t0 + tt, q * cand_stride + off + (tiles[t0 + tt].col_begin - cb), ps, xb, xl);
+    }
+}
+
+void launch_k0b_remaining(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* done,
+                          uint32_t first_rank, void* items, uint32_t* n_items, hipStream_t s) {
+    if (P.nrows == 0) return;
+    XRL_HIP(hipMemsetAsync(n_items, 0, 4, s));
+    hipLaunchKernelGGL(k0b_remaining, dim3((P.nrows + 255) / 256), dim3(256), 0, s, L.chunk_col, L.ptile, L.tiles, P.nrows, P.beam_in, first_rank,
+                       P.cand_stride, prev.idx, prev.val, prev.cnt, prev.stride, cand_off, done, static_cast<ItemDesc*>(items), n_items,
+                       X.dense ? nullptr : X.row_ptr + P.row0);
+    XRL_LAUNCH_CHECK();
+}
 
 // ---------------------------------------------------------------------------------------------
 // Item ordering: counting sort of the layer's item descriptors by tile id, so that the wavefronts
@@ -630,6 +677,14 @@ struct K2Args {
     uint32_t* out_idx; float* out_val; uint32_t* out_cnt;
     uint32_t nrows, beam_in, cand_stride, k, out_stride;
     int implicit_root;
+    // exact bound pruning (k2_topk_wave only): rank_limit > 0 restricts the selection to the candidates of the first rank_limit beam
+    // slots and reports in done[q] whether that selection is already FINAL -- every candidate of a later slot scores at most its
+    // parent's score (transform <= 1 times / <= 0 plus the parent's score) and would lose a tie by position, so once k selected
+    // candidates score >= the next parent's score nothing can change.  skip_done: queries to leave untouched (second phase).
+    const float* p_val;
+    uint32_t rank_limit;
+    uint32_t* done;
+    const uint32_t* skip_done;
 };
 
 __device__ __forceinline__ uint32_t k2_child_id(const K2Args& a, uint64_t q, uint32_t pos) {
@@ -750,7 +805,11 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     const uint32_t q32 = blockIdx.x * 4u + wave;
     if (q32 >= a.nrows) return;
     const uint64_t q = q32;
-    const uint32_t n = min(a.ncand[q], (uint32_t)(64 * NS));
+    if (a.skip_done && a.skip_done[q]) return;
+    uint32_t n = min(a.ncand[q], (uint32_t)(64 * NS));
+    const uint32_t bcnt0 = a.implicit_root ? 1u : min(a.p_cnt[q], a.beam_in);
+    const bool limited = a.rank_limit != 0u && bcnt0 > a.rank_limit;
+    if (limited) n = min(n, a.cand_off[q * a.beam_in + a.rank_limit]);
     const float* __restrict__ cv = a.cand + q * a.cand_stride;
     const uint32_t nlast = n ? n - 1 : 0;
     // the beam's block offsets and parents, one per lane (beams of up to 64 parents): in flight while the candidates are ranked,
@@ -769,6 +828,11 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     }
     uint32_t rank, sb, pp;
     const uint32_t kk = wave_topk<NS>(key, sbits, pos, a.k, sc_all + wave * 64u, lane, rank, sb, pp);
+    if (a.done) {
+        bool d = true;
+        if (limited) d = wave_count_ge<NS>(key, score_key(a.p_val[q * a.p_stride + a.rank_limit])) >= a.k;   // the k-th best >= the best any later slot can reach
+        if (lane == 0) a.done[q] = d ? 1u : 0u;
+    }
     uint32_t child;
     if (lane_beam) {
         uint32_t jj = 0;                                            // last beam slot whose block starts at or before the position
@@ -788,11 +852,16 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
 
 size_t k2_max_k() { return (160 * 1024) / 8; }
 
+bool k2_wave_path(const LayerPlan& P, bool legacy) { return P.k <= 64 && P.cand_stride <= 64u * 32u && !legacy; }
+
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
-                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, bool legacy) {
+                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, bool legacy, uint32_t rank_limit, uint32_t limited_cands,
+                    uint32_t* done, const uint32_t* skip_done) {
     if (P.nrows == 0) return;
     K2Args a;
+    a.p_val = prev.val; a.rank_limit = rank_limit; a.done = done; a.skip_done = skip_done;
+    if ((rank_limit || done || skip_done) && !k2_wave_path(P, legacy)) fail("k2: bound pruning needs the register top-k path");
     a.chunk_col = L.chunk_col; a.perm_inv = L.perm_inv;
     a.p_idx = prev.idx; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
     a.cand_off = cand_off; a.ncand = ncand; a.cand = cand;
@@ -800,8 +869,9 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
     a.nrows = P.nrows; a.beam_in = P.beam_in; a.cand_stride = P.cand_stride; a.k = P.k; a.out_stride = out_stride;
     a.implicit_root = P.implicit_root;
     if (P.k == 0) fail("k2: only_topk / beam_size resolved to 0");
-    if (P.k <= 64 && P.cand_stride <= 64u * 32u && !legacy) {
-        const uint32_t ns = (P.cand_stride + 63u) / 64u;
+    if (k2_wave_path(P, legacy)) {
+        // (a rank-limited selection looks at the first slots' candidates only: registers for that many)
+        const uint32_t ns = ((rank_limit ? std::min(P.cand_stride, std::max(1u, limited_cands)) : P.cand_stride) + 63u) / 64u;
         const dim3 grid((P.nrows + 3u) / 4u), block(256);
         if (ns <= 1) hipLaunchKernelGGL(k2_topk_wave<1>, grid, block, 0, s, a);
         else if (ns <= 2) hipLaunchKernelGGL(k2_topk_wave<2>, grid, block, 0, s, a);
@@ -932,11 +1002,13 @@ stats_items_kernel(LayerDev L, QueriesDev X, const ItemDesc* __restrict__ items,
 }
 
 void launch_stats(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, const uint32_t* ncand, const void* items,
-                  double* out8, hipStream_t s) {
+                  double* out8, hipStream_t s, uint64_t item_slots) {
     if (P.nrows == 0) return;
-    hipLaunchKernelGGL(stats_kernel, dim3((P.nrows + 255) / 256), dim3(256), 0, s, L.chunk_alg_bytes, P.nrows,
-                       P.beam_in, P.implicit_root, prev.idx, prev.cnt, prev.stride, ncand, out8);
-    const uint64_t n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
+    if (ncand)   // (nullptr: only the items of a further item list of the same layer are added)
+        hipLaunchKernelGGL(stats_kernel, dim3((P.nrows + 255) / 256), dim3(256), 0, s, L.chunk_alg_bytes, P.nrows,
+                           P.beam_in, P.implicit_root, prev.idx, prev.cnt, prev.stride, ncand, out8);
+    const uint64_t n_slots = item_slots ? item_slots : (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;
+    if (n_slots == 0) return;
     hipLaunchKernelGGL(stats_items_kernel, dim3((uint32_t)((n_slots + 255) / 256)), dim3(256), 0, s, L, X,
                        static_cast<const ItemDesc*>(items), n_slots, P.row0, out8 + 2);
     XRL_LAUNCH_CHECK();

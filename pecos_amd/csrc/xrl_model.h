@@ -136,6 +136,7 @@ struct LaneWs {      // scratch of one row batch in flight
     DevBuf cand_off, ncand, cand;
     DevBuf items, items_sorted, sort_hist, sort_start;   // item descriptors (K0) and their tile-sorted copy
     DevBuf blk_start, x_ok;                              // K1G: first workgroup of every tile; per-row "all x finite" flags
+    DevBuf prune_done, prune_cnt;                        // bound-pruned layers: per-query "first phase was final" flags; item count of the second phase
 };
 struct Workspace {
     LaneWs lane[2];      // two row batches are in flight on two streams (xrl_predict.cpp)
@@ -174,6 +175,8 @@ struct Model {
     int k1r_min_items = 0;                  // sparse X: run a tile-format layer tile-RESIDENT (K1R: tile-sorted items, the tile's image in LDS) once a tile serves
                                             // at least this many items on average; 0 = never (default: measured slower than K1, profiles/r03_k1r_experiments.txt)
     int k1r_items_per_block = 1024;         // K1R / K1L: consecutive tile-sorted items per workgroup
+    int prune = 1;                          // exact bound pruning (xrl_predict.cpp): 1 = a layer first scores the children of the best beam parent(s) only and
+                                            // skips the rest for every query whose k-th best already reaches the next parent's score; 0 = score every candidate
     int k1l_min_items = 0;                  // sparse X: run a tile-format layer with the tile-resident kernel K1L (lane == entry, LDS accumulators, 4 items per
                                             // wavefront) once a tile serves at least this many items on average (0 = never)
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)

@@ -225,8 +225,36 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 continue;
             }
             int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
-            timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
             const int mode = layer_mode(l, nrows);
+            // ---- exact bound pruning, tile format: score the children of the best beam parent first (K0 -> K1 -> K2 on one slot), then
+            //      only the remaining slots of the queries whose top-k is not final yet (see K2Args).  Needs a combiner (a child's score
+            //      is then <= its parent's) and the register top-k kernel.
+            if (m.prune && mode == 0 && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P, m.k2_legacy != 0)) {
+                const uint32_t J = 1;
+                const uint64_t slots_b = (uint64_t)nrows * (beam_in[l] - J) * L.max_tiles_per_parent;
+                lw.prune_done.reserve((size_t)nb * 4); lw.prune_cnt.reserve(256);
+                lw.items_sorted.reserve(slots_max * k0_item_bytes());
+                LayerPlan PA = P; PA.beam_in = J;                  // (K1 sizes its grid from beam_in x tiles per parent)
+                LayerPlan PB = P; PB.beam_in = beam_in[l] - J;
+                timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S, J); });
+                if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));
+                timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] { launch_k1(L.dev, PA, X, lw.items.p, nullptr, lw.cand.as<float>(), g, S); });
+                timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, false,
+                                                                   J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr); });
+                if (o.stats_out) XRL_HIP(hipMemsetAsync(lw.items_sorted.p, 0xFF, slots_b * k0_item_bytes(), S));   // the stats pass walks the whole list: unused slots read as "no tile"
+                timed("k0b_remaining", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), J, lw.items_sorted.p,
+                                                                               lw.prune_cnt.as<uint32_t>(), S); });
+                timed(X.dense ? "k1_dense_rest" : "k1_sparse_rest", (uint32_t)l, [&] { launch_k1(L.dev, PB, X, lw.items_sorted.p, lw.prune_cnt.as<uint32_t>(), lw.cand.as<float>(), g, S); });
+                if (lanes == 2) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
+                timed("k2_topk_rest", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, false,
+                                                                        0, 0, nullptr, lw.prune_done.as<uint32_t>()); });
+                if (o.stats_out) {
+                    launch_stats(L.dev, P, X, prev, lw.ncand.as<uint32_t>(), lw.items.p, ws.stats.as<double>() + kStatsPerLayer * l, S, (uint64_t)nrows * J * L.max_tiles_per_parent);
+                    launch_stats(L.dev, PB, X, prev, nullptr, lw.items_sorted.p, ws.stats.as<double>() + kStatsPerLayer * l, S, slots_b);
+                }
+                continue;
+            }
+            timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
             const uint64_t n_slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
             if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
             if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));   // K1 launches take turns across the lanes

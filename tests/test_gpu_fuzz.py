@@ -103,7 +103,8 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         # tile-resident kernel (K1R): off / forced for every layer whose tile images fit in LDS, short and long item runs
         clib.set_option(m.model.model_chain, "k1r_min_items", int(rng.choice([0, 1, 1])))
         clib.set_option(m.model.model_chain, "k1r_items_per_block", int(rng.choice([16, 100, 1024])))
-        clib.set_option(m.model.model_chain, "k1l_min_items", int(rng.choice([0, 0, 1])))          # K1L takes precedence over K1R when both are forced
+        clib.set_option(m.model.model_chain, "k1l_min_items", int(rng.choice([0, 0, 1])))
+        clib.set_option(m.model.model_chain, "prune", int(rng.choice([0, 1, 1])))                  # exact bound pruning on / off: same bits          # K1L takes precedence over K1R when both are forced
         # one or two row batches in flight (two streams), whole or ragged batches
         clib.set_option(m.model.model_chain, "overlap_min_rows", int(rng.choice([0, 2])))
         clib.set_option(m.model.model_chain, "max_batch_rows", int(rng.choice([0, 0, 7, 32])))
@@ -119,6 +120,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
     clib.set_option(m.model.model_chain, "dense_layers", 1)
     clib.set_option(m.model.model_chain, "k1r_min_items", 1)
     clib.set_option(m.model.model_chain, "k1l_min_items", 0)
+    clib.set_option(m.model.model_chain, "prune", 1)
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)
     # model defaults (per-layer only_topk / post-processor from param.json)
     assert_same_topk(m.predict(X), om.predict(X), exact_scores=True, what=f"seed={seed} defaults")

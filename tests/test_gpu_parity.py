@@ -129,6 +129,21 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         clib.set_option(m.model.model_chain, "dense_layers", 1)
         assert_same_topk(a, b, exact_scores=True, what=f"{name} dense vs tile format {kw}")
         assert_same_topk(a2, b, exact_scores=True, what=f"{name} dense (forced) vs tile format {kw}")
+    # exact bound pruning off / on (default on): the same bits on every kernel family, and the profile shows both phases of a pruned layer
+    for kw in (dict(beam_size=cfg["beam"], only_topk=10), dict(beam_size=cfg["beam"], only_topk=10, post_processor="log-sigmoid"),
+               dict(beam_size=4, only_topk=40), dict(beam_size=cfg["beam"], only_topk=3, post_processor="noop")):
+        for dl in (1, 0):
+            clib.set_option(m.model.model_chain, "dense_layers", dl)
+            clib.set_option(m.model.model_chain, "prune", 0)
+            a0 = m.predict(X, **kw)
+            clib.set_option(m.model.model_chain, "prune", 1)
+            assert_same_topk(m.predict(X, **kw), a0, exact_scores=True, what=f"{name} prune on vs off {kw} dense_layers={dl}")
+    clib.set_option(m.model.model_chain, "dense_layers", 0)
+    clib.profile_enable(m.model.model_chain, True); clib.profile_reset(m.model.model_chain)
+    m.predict(X, beam_size=cfg["beam"], only_topk=10)
+    pnames = {r["name"] for r in clib.profile_get(m.model.model_chain)}
+    clib.profile_enable(m.model.model_chain, False)
+    assert {"k0b_remaining", "k1_sparse_rest", "k2_topk_rest"} <= pnames, pnames
     clib.set_option(m.model.model_chain, "dense_layers", 0)     # the remaining checks are about the tile-format kernels
     # two row batches in flight on two streams (default only for large X): same results, also with a ragged tail batch
     for rows in (2, 150):
@@ -631,6 +646,9 @@ def test_headline_config_full_size_all_rows_vs_reference(XLM, clib, oracle_mod):
     clib.set_option(h, "dense_layers", 0)
     assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, tile format everywhere")
     clib.set_option(h, "dense_layers", 1)
+    clib.set_option(h, "prune", 0)                    # every candidate of every beam parent scored (no exact bound pruning)
+    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, prune=0")
+    clib.set_option(h, "prune", 1)
     if clib.xlinear_get_int_attr(h, "nr_k1r_layers") > 0:
         clib.set_option(h, "k1r_min_items", 1)
         assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, tile-resident leaf (K1R)")
