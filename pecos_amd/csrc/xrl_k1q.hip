@@ -25,6 +25,8 @@
 // order (beam rank major, child order minor), which is what ties are broken by.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "xrl_device.h"
 #include "xrl_kernels.h"
 
@@ -39,6 +41,7 @@ struct K1QLayer {
     uint32_t d_gp_log2, d_max_tiles, n_parents, w_rows;
     uint32_t beam_in, k, ns;          // ns: candidate registers per lane this layer needs
     int has_bias, pp_kind, pp_p, first_layer, implicit_root;
+    int prune;                        // exact bound pruning: score the first candidate register before requesting the others' weights
     int bias_first;                   // sparse X, HASH_CHUNKED arithmetic (inference.hpp:705-735): bias before the features, like dense X
 };
 constexpr int kK1QMaxLayers = 8;
@@ -69,7 +72,6 @@ template <int NS> struct K1QCfg {
 template <int NS, int PPC, bool DENSEX, bool BIASF>
 __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesDev& X, uint64_t xrow, uint32_t cnt_in,
                                                uint32_t* s_bidx, float* s_bval, uint2* sc, int lane) {
-    constexpr int U = K1QCfg<NS>::U;
     // ---- prolongate: which (parent, dense tile, column) does each of this lane's candidates stand for
     const uint32_t gl = Ly.d_gp_log2, gmask = (1u << gl) - 1u, TT = Ly.d_max_tiles;
     const uint32_t cnt = Ly.implicit_root ? 1u : min(cnt_in, Ly.beam_in);
@@ -96,79 +98,110 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         // dense queries: bias FIRST (inference.hpp:824-830); bias_prod holds fl32(bias * w) or +0.0
         acc[r] = (BIASF && Ly.has_bias) ? Ly.bias_prod[child[r]] : 0.0f;
     }
+    // bound pruning: score of the first beam parent that has no candidate in register 0 (the beam is sorted best first)
+    const uint32_t j_next = (64u >> gl) / TT;
+    const bool prune_next_ok = Ly.prune && !Ly.first_layer && !Ly.implicit_root && Ly.pp_kind != PP_NOOP;
+    const bool prune_all_in_first = j_next >= cnt;                    // every parent's candidates sit in register 0 already
+    const float ps_next = (prune_next_ok && !prune_all_in_first) ? s_bval[j_next] : 0.0f;
     wave_sync_lds();                                                   // the beam has been read: the arrays may be overwritten below
 
     const uint32_t* __restrict__ wd = Ly.wd;
     const uint64_t ld = Ly.d_ld;
     const uint32_t w_rows = Ly.w_rows;
 
-    // U features per batch: their U*NS weight loads are issued together (addresses depend only on the
-    // feature ids: scalar row base + this lane's column offset), then applied in feature order
-    auto batch = [&](uint32_t fv, uint32_t vbits, uint32_t t, uint32_t f_end) {
-        uint32_t wb[U][NS]; float xs[U];
+    // One pass over the query's features for the candidate registers [RB, RE): U features per batch, their U*(RE-RB) weight loads issued
+    // together (addresses depend only on the feature ids: scalar row base + this lane's column offset), then applied in feature order
+    auto pass = [&](auto rb_tag, auto re_tag) {
+        constexpr int RB = decltype(rb_tag)::value, RE = decltype(re_tag)::value, NR = RE - RB;
+        constexpr int UU = K1QCfg<NR>::U;
+        auto batch = [&](uint32_t fv, uint32_t vbits, uint32_t t, uint32_t f_end) {
+            uint32_t wb[UU][NR]; float xs[UU];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)(t + (uint32_t)u));
-            xs[u] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)vbits, (int)(t + (uint32_t)u)));
-            // features outside the layer (and the padding lanes, f = 0xFFFFFFFF) read the all-kMissing row the model compiler
-            // appends after the last feature row: no separate "skip" state to carry
-            const char* __restrict__ row = reinterpret_cast<const char*>(wd + (uint64_t)min(f, f_end) * ld);
+            for (int u = 0; u < UU; ++u) {
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)(t + (uint32_t)u));
+                xs[u] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)vbits, (int)(t + (uint32_t)u)));
+                // features outside the layer (and the padding lanes, f = 0xFFFFFFFF) read the all-kMissing row the model compiler
+                // appends after the last feature row: no separate "skip" state to carry
+                const char* __restrict__ row = reinterpret_cast<const char*>(wd + (uint64_t)min(f, f_end) * ld);
 #pragma unroll
-            for (int r = 0; r < NS; ++r) wb[u][r] = *reinterpret_cast<const uint32_t*>(row + woff[r]);   // scalar base + 32-bit lane offset
-        }
+                for (int r = 0; r < NR; ++r) wb[u][r] = *reinterpret_cast<const uint32_t*>(row + woff[RB + r]);   // scalar base + 32-bit lane offset
+            }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < UU; ++u) {
 #pragma unroll
-            for (int r = 0; r < NS; ++r) {
-                // scalar * val, then add: no fma (inference.hpp:512-517); no entry -> no operation
-                const float s = __fadd_rn(acc[r], __fmul_rn(xs[u], __uint_as_float(wb[u][r])));
-                acc[r] = (wb[u][r] == kMissing) ? acc[r] : s;
+                for (int r = 0; r < NR; ++r) {
+                    // scalar * val, then add: no fma (inference.hpp:512-517); no entry -> no operation
+                    const float sm = __fadd_rn(acc[RB + r], __fmul_rn(xs[u], __uint_as_float(wb[u][r])));
+                    acc[RB + r] = (wb[u][r] == kMissing) ? acc[RB + r] : sm;
+                }
+            }
+        };
+        if (DENSEX) {
+            // chunk_ops<drm, bin_search> (inference.hpp:815-839): every chunk row except the bias row, x gathered by row id
+            const float* __restrict__ xd = X.val + xrow * X.cols;
+            const uint32_t n_feat = Ly.has_bias ? w_rows - 1u : w_rows;
+            for (uint32_t t0 = 0; t0 < n_feat; t0 += 64u) {
+                const uint32_t f = t0 + (uint32_t)lane;
+                const float xv = f < X.cols ? xd[f] : 0.0f;
+                const uint32_t fv = f < n_feat ? f : 0xFFFFFFFFu;
+                const uint32_t n = min(64u, n_feat - t0);
+                for (uint32_t t = 0; t < n; t += (uint32_t)UU) batch(fv, __float_as_uint(xv), t, w_rows);   // fv >= n_feat only on padding lanes (0xFFFFFFFF)
+            }
+        } else {
+            // chunk_ops<csr, bin_search> (inference.hpp:769-813): the query's features in ascending order
+            const uint64_t xb = X.row_ptr[xrow];
+            const uint32_t xl = (uint32_t)(X.row_ptr[xrow + 1] - xb);
+            const uint32_t* __restrict__ xi = X.col_idx + xb;
+            const float* __restrict__ xv = X.val + xb;
+            uint32_t fv = 0xFFFFFFFFu, vb = 0u;
+            if (xl) { const bool ok = (uint32_t)lane < xl; const uint32_t t = ok ? (uint32_t)lane : 0u; fv = ok ? xi[t] : 0xFFFFFFFFu; vb = __float_as_uint(xv[t]); }
+            for (uint32_t t0 = 0; t0 < xl; t0 += 64u) {
+                uint32_t fn = 0xFFFFFFFFu, vn = 0u;                          // next 64 features: in flight while this chunk is applied
+                if (t0 + 64u < xl) {
+                    const uint32_t tn = t0 + 64u + (uint32_t)lane;
+                    const bool ok = tn < xl; const uint32_t tc = ok ? tn : t0;
+                    fn = ok ? xi[tc] : 0xFFFFFFFFu; vn = __float_as_uint(xv[tc]);
+                }
+                const uint32_t n = min(64u, xl - t0);
+                for (uint32_t t = 0; t < n; t += (uint32_t)UU) batch(fv, vb, t, w_rows);
+                fv = fn; vb = vn;
             }
         }
     };
-
-    if (DENSEX) {
-        // chunk_ops<drm, bin_search> (inference.hpp:815-839): every chunk row except the bias row, x gathered by row id
-        const float* __restrict__ xd = X.val + xrow * X.cols;
-        const uint32_t n_feat = Ly.has_bias ? w_rows - 1u : w_rows;
-        for (uint32_t t0 = 0; t0 < n_feat; t0 += 64u) {
-            const uint32_t f = t0 + (uint32_t)lane;
-            const float xv = f < X.cols ? xd[f] : 0.0f;
-            const uint32_t fv = f < n_feat ? f : 0xFFFFFFFFu;
-            const uint32_t n = min(64u, n_feat - t0);
-            for (uint32_t t = 0; t < n; t += (uint32_t)U) batch(fv, __float_as_uint(xv), t, w_rows);   // fv >= n_feat only on padding lanes (0xFFFFFFFF)
-        }
-    } else {
-        // chunk_ops<csr, bin_search> (inference.hpp:769-813): the query's features in ascending order
-        const uint64_t xb = X.row_ptr[xrow];
-        const uint32_t xl = (uint32_t)(X.row_ptr[xrow + 1] - xb);
-        const uint32_t* __restrict__ xi = X.col_idx + xb;
-        const float* __restrict__ xv = X.val + xb;
-        uint32_t fv = 0xFFFFFFFFu, vb = 0u;
-        if (xl) { const bool ok = (uint32_t)lane < xl; const uint32_t t = ok ? (uint32_t)lane : 0u; fv = ok ? xi[t] : 0xFFFFFFFFu; vb = __float_as_uint(xv[t]); }
-        for (uint32_t t0 = 0; t0 < xl; t0 += 64u) {
-            uint32_t fn = 0xFFFFFFFFu, vn = 0u;                          // next 64 features: in flight while this chunk is applied
-            if (t0 + 64u < xl) {
-                const uint32_t tn = t0 + 64u + (uint32_t)lane;
-                const bool ok = tn < xl; const uint32_t tc = ok ? tn : t0;
-                fn = ok ? xi[tc] : 0xFFFFFFFFu; vn = __float_as_uint(xv[tc]);
-            }
-            const uint32_t n = min(64u, xl - t0);
-            for (uint32_t t = 0; t < n; t += (uint32_t)U) batch(fv, vb, t, w_rows);
-            fv = fn; vb = vn;
-        }
-    }
-
-    // ---- bias last (sparse X, inference.hpp:806-811), transform in fp64, combine with the parent's score
+    // bias last (sparse X, inference.hpp:806-811), transform in fp64, combine with the parent's score
     uint32_t key[NS], sbits[NS];
-#pragma unroll
-    for (int r = 0; r < NS; ++r) {
-        float s = acc[r];
-        if (!BIASF && Ly.has_bias) s = __fadd_rn(s, Ly.bias_prod[child[r]]);
-        float v = pp_transform<PPC>(Ly.pp_kind, Ly.pp_p, s);
+    auto finish = [&](int r) -> float {
+        float sm = acc[r];
+        if (!BIASF && Ly.has_bias) sm = __fadd_rn(sm, Ly.bias_prod[child[r]]);
+        float v = pp_transform<PPC>(Ly.pp_kind, Ly.pp_p, sm);
         if (!Ly.first_layer) v = pp_combine(Ly.pp_kind, v, ps[r]);
         sbits[r] = __float_as_uint(v);
         key[r] = valid[r] ? score_key(v) : 0u;
+        return v;
+    };
+    // EXACT bound pruning (option prune): with a combiner a child's score is <= its parent's (transform <= 1 times, or <= 0 plus, the
+    // parent's score) and a later candidate loses ties by position -- so when k candidates of the FIRST register (the best beam
+    // parents) already score >= the score of the first parent outside it, no candidate of the other registers can enter the top-k:
+    // their weight rows are never requested.  Otherwise a second pass scores them; either way the selection below is the reference's.
+    bool staged = false;
+    if (NS > 1 && prune_next_ok) {
+        staged = true;
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+        const float v0 = finish(0);
+        const uint32_t cge = (uint32_t)__popcll(__ballot(valid[0] && v0 >= ps_next));
+        if (!prune_all_in_first && cge < Ly.k) {
+            pass(std::integral_constant<int, (NS > 1 ? 1 : 0)>{}, std::integral_constant<int, NS>{});
+#pragma unroll
+            for (int r = 1; r < NS; ++r) finish(r);
+        } else {
+#pragma unroll
+            for (int r = 1; r < NS; ++r) { key[r] = 0u; sbits[r] = 0u; }
+        }
+    }
+    if (!staged) {
+        pass(std::integral_constant<int, 0>{}, std::integral_constant<int, NS>{});
+#pragma unroll
+        for (int r = 0; r < NS; ++r) finish(r);
     }
     // ---- top-k (value desc, position asc) and reorder_prediction: the next beam, best first
     uint32_t rank, sb, ch;
@@ -257,7 +290,7 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
         y.wd = L.wd; y.d_ld = L.d_ld; y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
         y.d_gp_log2 = L.d_gp_log2; y.d_max_tiles = L.d_max_tiles; y.n_parents = L.n_parents; y.w_rows = L.w_rows;
         y.beam_in = P.beam_in; y.k = P.k; y.ns = k1q_bucket(ns);
-        y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root; y.bias_first = P.bias_first;
+        y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root; y.bias_first = P.bias_first; y.prune = P.prune;
         nsmax = std::max(nsmax, y.ns); ppc |= pp_class(P.pp);
     }
     a.n_layers = n; a.X = X;

@@ -33,6 +33,7 @@ struct LayerPlan {
     PostProc pp;
     int first_layer;            // no combine (no_prev_pred)
     int implicit_root;          // previous beam is the implicit all-ones root
+    int prune;                  // exact bound pruning allowed (Model::prune)
     int bias_first;             // sparse X under weight_matrix_type HASH_CHUNKED: the bias row is applied BEFORE the query's features
                                 // (chunk_ops<csr, hash>, inference.hpp:705-735); dense X is bias-first in every layout
     int layer;                  // index in the chain (profiling only)

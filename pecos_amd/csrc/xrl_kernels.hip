@@ -808,8 +808,12 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     if (a.skip_done && a.skip_done[q]) return;
     uint32_t n = min(a.ncand[q], (uint32_t)(64 * NS));
     const uint32_t bcnt0 = a.implicit_root ? 1u : min(a.p_cnt[q], a.beam_in);
+    // (both loads are issued up front, whether or not the query has that many parents: no dependent round trips later)
+    const uint32_t rl = min(a.rank_limit, a.beam_in - 1u);
+    const uint32_t lim_off = a.rank_limit ? a.cand_off[q * a.beam_in + rl] : 0u;
+    const float ps_next = a.rank_limit ? a.p_val[q * a.p_stride + rl] : 0.0f;
     const bool limited = a.rank_limit != 0u && bcnt0 > a.rank_limit;
-    if (limited) n = min(n, a.cand_off[q * a.beam_in + a.rank_limit]);
+    if (limited) n = min(n, lim_off);
     const float* __restrict__ cv = a.cand + q * a.cand_stride;
     const uint32_t nlast = n ? n - 1 : 0;
     // the beam's block offsets and parents, one per lane (beams of up to 64 parents): in flight while the candidates are ranked,
@@ -830,7 +834,7 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     const uint32_t kk = wave_topk<NS>(key, sbits, pos, a.k, sc_all + wave * 64u, lane, rank, sb, pp);
     if (a.done) {
         bool d = true;
-        if (limited) d = wave_count_ge<NS>(key, score_key(a.p_val[q * a.p_stride + a.rank_limit])) >= a.k;   // the k-th best >= the best any later slot can reach
+        if (limited) d = wave_count_ge<NS>(key, score_key(ps_next)) >= a.k;   // the k-th best >= the best any later slot can reach
         if (lane == 0) a.done[q] = d ? 1u : 0u;
     }
     uint32_t child;

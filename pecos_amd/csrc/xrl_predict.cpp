@@ -164,6 +164,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             P.first_layer = (l == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;   // no_prev_pred
             P.implicit_root = (l == 0 && !has_init) ? 1 : 0;
             P.bias_first = (m.weight_matrix_type == 1 && !X.dense) ? 1 : 0;
+            P.prune = m.prune ? 1 : 0;
             BeamDev prev{};
             if (l == 0 && has_init) {
                 prev = *o.initial;
@@ -236,6 +237,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 lw.items_sorted.reserve(slots_max * k0_item_bytes());
                 LayerPlan PA = P; PA.beam_in = J;                  // (K1 sizes its grid from beam_in x tiles per parent)
                 LayerPlan PB = P; PB.beam_in = beam_in[l] - J;
+                PB.tune.wpb = 4;                                   // the second phase's grid is sized for "nothing pruned": mostly empty wavefronts, 4 per workgroup to dispatch fewer groups
                 timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S, J); });
                 if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));
                 timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] { launch_k1(L.dev, PA, X, lw.items.p, nullptr, lw.cand.as<float>(), g, S); });
