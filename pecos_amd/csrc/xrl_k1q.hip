@@ -102,7 +102,11 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     const uint32_t j_next = (64u >> gl) / TT;
     const bool prune_next_ok = Ly.prune && !Ly.first_layer && !Ly.implicit_root && Ly.pp_kind != PP_NOOP;
     const bool prune_all_in_first = j_next >= cnt;                    // every parent's candidates sit in register 0 already
-    const float ps_next = (prune_next_ok && !prune_all_in_first) ? s_bval[j_next] : 0.0f;
+    // (a multiplying combiner keeps a child of a parent with a NEGATIVE score -- possible when an earlier layer used another
+    //  post-processor -- inside [score, 0]: the bound is then max(score, 0); the adding ones add a transform <= 0)
+    float ps_next = (prune_next_ok && !prune_all_in_first) ? s_bval[j_next] : 0.0f;
+    if (Ly.pp_kind == PP_SIGMOID || Ly.pp_kind == PP_LP_HINGE) ps_next = fmaxf(ps_next, 0.0f);
+    if (!(ps_next == ps_next)) ps_next = INFINITY;                    // a NaN parent score proves nothing: no pruning
     wave_sync_lds();                                                   // the beam has been read: the arrays may be overwritten below
 
     const uint32_t* __restrict__ wd = Ly.wd;

@@ -682,6 +682,9 @@ struct K2Args {
     // parent's score (transform <= 1 times / <= 0 plus the parent's score) and would lose a tie by position, so once k selected
     // candidates score >= the next parent's score nothing can change.  skip_done: queries to leave untouched (second phase).
     const float* p_val;
+    int mult;                    // the combiner multiplies (sigmoid, l{p}-hinge): a child of a parent with a NEGATIVE score (possible when an
+                                 // earlier layer used another post-processor) lies in [score, 0], so the bound is max(score, 0); additive
+                                 // combiners (log-*) add a transform <= 0: the bound is the score itself
     uint32_t rank_limit;
     uint32_t* done;
     const uint32_t* skip_done;
@@ -834,7 +837,8 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     const uint32_t kk = wave_topk<NS>(key, sbits, pos, a.k, sc_all + wave * 64u, lane, rank, sb, pp);
     if (a.done) {
         bool d = true;
-        if (limited) d = wave_count_ge<NS>(key, score_key(ps_next)) >= a.k;   // the k-th best >= the best any later slot can reach
+        // the k-th best >= the best any later slot can reach (a NaN parent score proves nothing: no pruning)
+        if (limited) d = ps_next == ps_next && wave_count_ge<NS>(key, score_key(a.mult ? fmaxf(ps_next, 0.0f) : ps_next)) >= a.k;
         if (lane == 0) a.done[q] = d ? 1u : 0u;
     }
     uint32_t child;
@@ -865,6 +869,7 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
     if (P.nrows == 0) return;
     K2Args a;
     a.p_val = prev.val; a.rank_limit = rank_limit; a.done = done; a.skip_done = skip_done;
+    a.mult = (P.pp.kind == PP_SIGMOID || P.pp.kind == PP_LP_HINGE) ? 1 : 0;
     if ((rank_limit || done || skip_done) && !k2_wave_path(P, legacy)) fail("k2: bound pruning needs the register top-k path");
     a.chunk_col = L.chunk_col; a.perm_inv = L.perm_inv;
     a.p_idx = prev.idx; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
