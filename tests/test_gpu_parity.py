@@ -604,6 +604,46 @@ def test_hash_chunked_sparse_queries_bit_exact(manifest, XLM, clib, oracle_mod, 
             assert not np.array_equal(other.data.view(np.uint32), want.data.view(np.uint32))     # the two layouts do differ in the last bits
 
 
+@pytest.mark.parametrize("variant", ["all_saturated", "bias_only", "descending"])
+def test_bound_pruning_with_massive_ties(variant, XLM, clib, oracle_mod, tmp_path):
+    # exact bound pruning at its boundary conditions.  all_saturated: every weight is +2 and x >= 0, so every accumulator is >= 1 wherever a
+    # feature matches and l3-hinge returns exactly 1.0 -- parents tie, children tie with their parents, and the whole top-k is decided by
+    # candidate POSITION; bias_only: no query feature matches anything (empty rows), scores come from the bias alone and tie within a
+    # layer; descending: weights shrink with the child id so that scores strictly decrease and the k-th best sits just above / below the
+    # next parent's score.  Pruning on must equal pruning off and the oracle for every beam / top-k, every kernel family, sparse and dense X.
+    import xrl_synth
+    folder = str(tmp_path / "m")
+    D = 120
+    xrl_synth.make_model(folder, D, 700, [60, 40, 12], seed=41, shape=[5, 40, 700], permute_leaf=True)
+    rng = np.random.default_rng(7)
+    for d in range(3):
+        f = os.path.join(folder, "ranker", f"{d}.model", "W.npz")
+        W = smat.load_npz(f).tocsc().astype(np.float32)
+        if variant == "descending":
+            col = np.repeat(np.arange(W.shape[1]), np.diff(W.indptr))
+            W.data[:] = (1.5 / (1.0 + 0.01 * col)).astype(np.float32)
+        else:
+            W.data[:] = 2.0
+        smat.save_npz(f, W, compressed=False)
+    X = xrl_synth.make_queries(50, D, 12, seed=43, relabel_seed=41)
+    if variant == "bias_only":
+        X = smat.csr_matrix(X.shape, dtype=np.float32)
+    m = XLM.load(folder)
+    h = m.model.model_chain
+    om = oracle_mod.OracleModel.load(folder)
+    for Xq in (X, np.ascontiguousarray(X.toarray())):
+        for kw in (dict(beam_size=10, only_topk=10), dict(beam_size=3, only_topk=30), dict(beam_size=2, only_topk=1), dict(beam_size=25, only_topk=64),
+                   dict(beam_size=10, only_topk=10, post_processor="log-l2-hinge"), dict(beam_size=7, only_topk=12, post_processor="sigmoid")):
+            want = om.predict(Xq, **kw)
+            for dl in (1, 2, 0):
+                clib.set_option(h, "dense_layers", dl)
+                for pr in (1, 0):
+                    clib.set_option(h, "prune", pr)
+                    assert_same_topk(m.predict(Xq, **kw), want, exact_scores=EXACT_PP(kw.get("post_processor")),
+                                     what=f"{variant} {kw} dense_layers={dl} prune={pr} dense_x={not smat.issparse(Xq)}")
+    clib.set_option(h, "dense_layers", 1); clib.set_option(h, "prune", 1)
+
+
 def _bench_workload(name, cache=None):
     """The folder bench.py generates / re-uses for a workload at scale 1.0 (so that the driver's pytest and bench runs build it once)."""
     import json
