@@ -25,6 +25,7 @@
 // order (beam rank major, child order minor), which is what ties are broken by.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "xrl_device.h"
@@ -49,6 +50,7 @@ constexpr int kK1QMaxLayers = 8;
 struct K1QArgs {
     K1QLayer layer[kK1QMaxLayers];
     int n_layers;                     // consecutive dense-format layers run back to back by the same wavefront: the beam stays in LDS
+    int fuse01;                       // layers 0 and 1 share one walk over the query's features (k1q_layer01)
     QueriesDev X;
     const uint32_t* p_idx; const float* p_val; const uint32_t* p_cnt; uint32_t p_stride;
     uint32_t* out_idx; float* out_val; uint32_t* out_cnt; uint32_t out_stride;
@@ -218,6 +220,114 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     return kk;
 }
 
+// Levels 0 and 1 in ONE pass over the query's features (sparse X, fused launches).  When the root layer keeps every one of its K0
+// children (K0 <= its k), the next layer always evaluates ALL of their children: which weight columns level 1 reads does not depend
+// on level 0's scores, only the ORDER of the parents (= candidate positions, the tie-break) and the parents' scores do.  So both
+// layers' accumulators are filled by the same feature walk -- lanes [0, K0) hold level 0's columns, every lane holds one level-1
+// candidate of the parents taken in column order -- and afterwards level 0 is ranked, the level-1 scores are combined with their
+// parent's score and moved to the lane their reference position names (parents in rank order), where the usual top-k runs.
+// Saves one of the two latency-bound feature walks of the narrow top levels.
+template <int PPC, bool BIASF>
+__device__ __forceinline__ uint32_t k1q_layer01(const K1QLayer& L0, const K1QLayer& L1, const QueriesDev& X, uint64_t xrow,
+                                                 uint32_t* s_bidx, float* s_bval, uint2* sc, int lane) {
+    constexpr int UU = 8;
+    // ---- level 0: lane c < K0 <-> child c of the root (one dense tile at offset 0)
+    const uint32_t K0 = L0.d_tcol[1] - L0.d_tcol[0];
+    const bool v0 = (uint32_t)lane < K0;
+    const uint32_t woff0 = v0 ? (uint32_t)lane * 4u : 0u;
+    const uint32_t child0 = v0 ? L0.d_tcol[0] + (uint32_t)lane : 0u;
+    const uint32_t orig0 = v0 ? (L0.perm_inv ? L0.perm_inv[child0] : child0) : 0xFFFFFFFFu;
+    float acc0 = (BIASF && L0.has_bias && v0) ? L0.bias_prod[child0] : 0.0f;
+    // ---- level 1: candidate u = lane of the parents in COLUMN order (virtual beam slot j = level-0 column j)
+    const uint32_t gl = L1.d_gp_log2, gmask = (1u << gl) - 1u, TT = L1.d_max_tiles;
+    const uint32_t slot = (uint32_t)lane >> gl, col = (uint32_t)lane & gmask;
+    const uint32_t j = TT == 1u ? slot : slot / TT, tt = TT == 1u ? 0u : slot - j * TT;
+    bool v1 = j < K0;
+    uint32_t parent = (uint32_t)__shfl((int)orig0, (int)(v1 ? j : 0u), 64);
+    v1 = v1 && parent < L1.n_parents;
+    if (!v1) parent = 0;
+    const uint32_t dt = L1.d_ptile[parent] + tt;
+    v1 = v1 && dt < L1.d_ptile[parent + 1];
+    const uint32_t dtc = v1 ? dt : 0u;
+    const uint32_t cb = L1.d_tcol[dtc], ce = L1.d_tcol[dtc + 1];
+    v1 = v1 && col < ce - cb;
+    const uint32_t woff1 = v1 ? ((dtc << gl) + col) * 4u : 0u;
+    const uint32_t child1 = v1 ? cb + col : 0u;
+    float acc1 = (BIASF && L1.has_bias && v1) ? L1.bias_prod[child1] : 0.0f;
+
+    // ---- one walk over the query's features, UU at a time: 2 * UU loads in flight
+    const uint32_t* __restrict__ wd0 = L0.wd; const uint32_t* __restrict__ wd1 = L1.wd;
+    const uint64_t ld0 = L0.d_ld, ld1 = L1.d_ld;
+    const uint32_t wr0 = L0.w_rows, wr1 = L1.w_rows;
+    const uint64_t xb = X.row_ptr[xrow];
+    const uint32_t xl = (uint32_t)(X.row_ptr[xrow + 1] - xb);
+    const uint32_t* __restrict__ xi = X.col_idx + xb;
+    const float* __restrict__ xv = X.val + xb;
+    uint32_t fv = 0xFFFFFFFFu, vb = 0u;
+    if (xl) { const bool ok = (uint32_t)lane < xl; const uint32_t t = ok ? (uint32_t)lane : 0u; fv = ok ? xi[t] : 0xFFFFFFFFu; vb = __float_as_uint(xv[t]); }
+    for (uint32_t t0 = 0; t0 < xl; t0 += 64u) {
+        uint32_t fn = 0xFFFFFFFFu, vn = 0u;
+        if (t0 + 64u < xl) {
+            const uint32_t tn = t0 + 64u + (uint32_t)lane;
+            const bool ok = tn < xl; const uint32_t tc = ok ? tn : t0;
+            fn = ok ? xi[tc] : 0xFFFFFFFFu; vn = __float_as_uint(xv[tc]);
+        }
+        const uint32_t n = min(64u, xl - t0);
+        for (uint32_t t = 0; t < n; t += (uint32_t)UU) {
+            uint32_t w0[UU], w1[UU]; float xs[UU];
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)(t + (uint32_t)u));
+                xs[u] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)vb, (int)(t + (uint32_t)u)));
+                w0[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(wd0 + (uint64_t)min(f, wr0) * ld0) + woff0);
+                w1[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(wd1 + (uint64_t)min(f, wr1) * ld1) + woff1);
+            }
+#pragma unroll
+            for (int u = 0; u < UU; ++u) {
+                const float s0 = __fadd_rn(acc0, __fmul_rn(xs[u], __uint_as_float(w0[u])));
+                acc0 = (w0[u] == kMissing) ? acc0 : s0;
+                const float s1 = __fadd_rn(acc1, __fmul_rn(xs[u], __uint_as_float(w1[u])));
+                acc1 = (w1[u] == kMissing) ? acc1 : s1;
+            }
+        }
+        fv = fn; vb = vn;
+    }
+    // ---- level 0: bias, transform (first layer: no combine), rank of every node in (value desc, position asc) order
+    if (!BIASF && L0.has_bias && v0) acc0 = __fadd_rn(acc0, L0.bias_prod[child0]);
+    const float s0v = pp_transform<PPC>(L0.pp_kind, L0.pp_p, acc0);
+    const uint32_t k0key = v0 ? score_key(s0v) : 0u;
+    uint32_t rank0 = 0;
+    for (uint32_t c = 0; c < K0; ++c) {
+        const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)k0key, (int)c);
+        rank0 += (kc > k0key || (kc == k0key && c < (uint32_t)lane)) ? 1u : 0u;
+    }
+    // ---- level 1: bias, transform, combine with the parent's score; candidate position = (rank of the parent, tile, column)
+    if (!BIASF && L1.has_bias && v1) acc1 = __fadd_rn(acc1, L1.bias_prod[child1]);
+    float s1v = pp_transform<PPC>(L1.pp_kind, L1.pp_p, acc1);
+    const float psv = __shfl(s0v, (int)(j < K0 ? j : 0u), 64);
+    if (!L1.first_layer) s1v = pp_combine(L1.pp_kind, s1v, psv);
+    const uint32_t prank = (uint32_t)__shfl((int)rank0, (int)(j < K0 ? j : 0u), 64);
+    const uint32_t position = (((prank * TT) + tt) << gl) + col;       // < 64: one candidate register
+    // move every candidate to the lane its position names (slots no candidate names stay marked empty)
+    sc[lane] = make_uint2(0u, 0xFFFFFFFFu);
+    wave_sync_lds();
+    if (v1) sc[position] = make_uint2(__float_as_uint(s1v), child1);
+    wave_sync_lds();
+    const uint2 mine = sc[lane];
+    wave_sync_lds();
+    uint32_t key[1], sbits[1], payload[1];
+    sbits[0] = mine.x; payload[0] = mine.y;
+    key[0] = mine.y != 0xFFFFFFFFu ? score_key(__uint_as_float(mine.x)) : 0u;
+    uint32_t rank, sb, ch;
+    const uint32_t kk = wave_topk<1>(key, sbits, payload, L1.k, sc, lane, rank, sb, ch);
+    if ((uint32_t)lane < kk) {
+        s_bidx[rank] = L1.perm_inv ? L1.perm_inv[ch] : ch;
+        s_bval[rank] = __uint_as_float(sb);
+    }
+    wave_sync_lds();
+    return kk;
+}
+
 // MULTI = false: exactly one layer (layer[0]); the layer loop and its run-time descriptor indexing cost ~20 VGPRs, which the
 // single-layer launches (wide layers, k1q_fuse = 0) do not pay.
 // The fused kernel of narrow layers is compiled for 7 wavefronts per SIMD (72 VGPRs instead of the 74 the compiler settles on,
@@ -243,7 +353,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI
     }
     wave_sync_lds();
     const uint64_t xrow = (uint64_t)a.row0 + q;
-    for (int l = 0; l < (MULTI ? a.n_layers : 1); ++l) {
+    int l_first = 0;
+    if (MULTI && !DENSEX && a.fuse01) { cnt = k1q_layer01<PPC, BIASF>(a.layer[0], a.layer[1], a.X, xrow, s_bidx, s_bval, sc, lane); l_first = 2; }
+    for (int l = l_first; l < (MULTI ? a.n_layers : 1); ++l) {
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
@@ -275,6 +387,10 @@ uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k, bool dense_x)
     return ns <= 16 ? (uint32_t)std::max<uint64_t>(1, ns) : 0u;
 }
 
+static bool k1q_fuse01_enabled() {   // XRL_K1Q_FUSE01=0: levels 0 and 1 take separate feature walks (A/B, tests)
+    const char* e = std::getenv("XRL_K1Q_FUSE01");
+    return !(e && e[0] == '0');
+}
 static uint32_t k1q_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 3 ? 3 : ns <= 4 ? 4 : ns <= 6 ? 6 : ns <= 8 ? 8 : ns <= 12 ? 12 : 16; }
 static uint32_t k1q_kernel_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 3 ? 3 : ns <= 6 ? 6 : 16; }   // kernels are compiled for these maxima
 
@@ -298,6 +414,14 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
         nsmax = std::max(nsmax, y.ns); ppc |= pp_class(P.pp);
     }
     a.n_layers = n; a.X = X;
+    // root + next level in one feature walk: the root keeps all of its children (so level 1 always evaluates all of theirs), both sit
+    // in one candidate register, sparse X
+    a.fuse01 = 0;
+    if (n >= 2 && !X.dense && Ps[0].implicit_root && Ps[0].first_layer && Ls[0]->n_parents == 1 && Ls[0]->d_max_tiles == 1 && Ps[0].tune.ablate == 0) {
+        const uint32_t K0 = Ls[0]->n_children;
+        const uint64_t c1 = ((uint64_t)K0 * Ls[1]->d_max_tiles) << Ls[1]->d_gp_log2;
+        if (K0 >= 1 && K0 <= 64 && K0 <= Ps[0].k && Ps[1].beam_in >= K0 && c1 <= 64 && a.layer[0].ns == 1 && a.layer[1].ns == 1 && Ps[1].k <= 64) a.fuse01 = k1q_fuse01_enabled() ? 1 : 0;
+    }
     a.p_idx = prev.idx; a.p_val = prev.val; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
     a.out_idx = out_idx; a.out_val = out_val; a.out_cnt = out_cnt; a.out_stride = out_stride;
     a.row0 = Ps[0].row0; a.nrows = Ps[0].nrows;

@@ -818,18 +818,18 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     const bool limited = a.rank_limit != 0u && bcnt0 > a.rank_limit;
     if (limited) n = min(n, lim_off);
     const float* __restrict__ cv = a.cand + q * a.cand_stride;
-    const uint32_t nlast = n ? n - 1 : 0;
+    const uint32_t slast = a.cand_stride - 1u;                  // last float of the query's candidate row (the loads below do not wait for n)
     // the beam's block offsets and parents, one per lane (beams of up to 64 parents): in flight while the candidates are ranked,
     // so that mapping a winner's position back to its child needs no dependent loads afterwards
     const uint32_t bcnt = a.implicit_root ? 1u : min(a.p_cnt[q], a.beam_in);
     const bool lane_beam = !a.implicit_root && bcnt <= 64u;
-    uint32_t b_off = 0xFFFFFFFFu, b_par = 0u;
-    if (lane_beam && (uint32_t)lane < bcnt) { b_off = a.cand_off[q * a.beam_in + lane]; b_par = a.p_idx[q * a.p_stride + lane]; }
+    uint32_t b_off = 0xFFFFFFFFu, b_par = 0u, b_cc = 0u;
+    if (lane_beam && (uint32_t)lane < bcnt) { b_off = a.cand_off[q * a.beam_in + lane]; b_par = a.p_idx[q * a.p_stride + lane]; b_cc = a.chunk_col[b_par]; }
     uint32_t key[NS], sbits[NS], pos[NS];
 #pragma unroll
     for (int r = 0; r < NS; ++r) {
         const uint32_t p = (uint32_t)r * 64u + (uint32_t)lane;
-        const float v = cv[p < n ? p : nlast];                     // unconditional, clamped
+        const float v = cv[min(p, slast)];                         // unconditional, clamped to the row (positions >= n are masked below)
         sbits[r] = __float_as_uint(v); pos[r] = p;
         key[r] = p < n ? score_key(v) : 0u;
     }
@@ -845,8 +845,8 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     if (lane_beam) {
         uint32_t jj = 0;                                            // last beam slot whose block starts at or before the position
         for (uint32_t j = 1; j < bcnt; ++j) jj = ((uint32_t)__builtin_amdgcn_readlane((int)b_off, (int)j) <= pp) ? j : jj;
-        const uint32_t off = (uint32_t)__shfl((int)b_off, (int)jj, 64), parent = (uint32_t)__shfl((int)b_par, (int)jj, 64);
-        child = a.chunk_col[(uint32_t)lane < kk ? parent : 0u] + (pp - off);
+        const uint32_t off = (uint32_t)__shfl((int)b_off, (int)jj, 64), cc = (uint32_t)__shfl((int)b_cc, (int)jj, 64);
+        child = cc + (pp - off);
         if ((uint32_t)lane < kk && a.perm_inv) child = a.perm_inv[child];
     } else {
         child = (uint32_t)lane < kk ? k2_child_id(a, q, pp) : 0u;

@@ -104,6 +104,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         clib.set_option(m.model.model_chain, "k1r_min_items", int(rng.choice([0, 1, 1])))
         clib.set_option(m.model.model_chain, "k1r_items_per_block", int(rng.choice([16, 100, 1024])))
         clib.set_option(m.model.model_chain, "k1l_min_items", int(rng.choice([0, 0, 1])))
+        os.environ["XRL_K1Q_FUSE01"] = str(int(rng.choice([0, 1, 1])))                          # levels 0 + 1 in one feature walk (K1Q) / separately
         clib.set_option(m.model.model_chain, "prune", int(rng.choice([0, 1, 1])))                  # exact bound pruning on / off: same bits          # K1L takes precedence over K1R when both are forced
         # one or two row batches in flight (two streams), whole or ragged batches
         clib.set_option(m.model.model_chain, "overlap_min_rows", int(rng.choice([0, 2])))
@@ -121,6 +122,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
     clib.set_option(m.model.model_chain, "k1r_min_items", 1)
     clib.set_option(m.model.model_chain, "k1l_min_items", 0)
     clib.set_option(m.model.model_chain, "prune", 1)
+    os.environ.pop("XRL_K1Q_FUSE01", None)
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)
     # model defaults (per-layer only_topk / post-processor from param.json)
     assert_same_topk(m.predict(X), om.predict(X), exact_scores=True, what=f"seed={seed} defaults")

@@ -129,6 +129,13 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
         clib.set_option(m.model.model_chain, "dense_layers", 1)
         assert_same_topk(a, b, exact_scores=True, what=f"{name} dense vs tile format {kw}")
         assert_same_topk(a2, b, exact_scores=True, what=f"{name} dense (forced) vs tile format {kw}")
+    # K1Q: levels 0 and 1 in one walk over the query's features (default where the root keeps all its children) vs separate walks
+    for kw in (dict(beam_size=cfg["beam"], only_topk=10), dict(beam_size=64, only_topk=64, post_processor="log-l3-hinge"), dict(beam_size=2, only_topk=5, post_processor="sigmoid")):
+        os.environ["XRL_K1Q_FUSE01"] = "0"
+        a0 = m.predict(X, **kw)
+        os.environ.pop("XRL_K1Q_FUSE01")
+        assert_same_topk(m.predict(X, **kw), a0, exact_scores=True, what=f"{name} levels 0+1 fused vs separate {kw}")
+        assert_same_topk(a0, ref.predict(X, **kw), exact_scores=EXACT_PP(kw.get("post_processor")), what=f"{name} separate walks vs reference {kw}")
     # exact bound pruning off / on (default on): the same bits on every kernel family, and the profile shows both phases of a pruned layer
     for kw in (dict(beam_size=cfg["beam"], only_topk=10), dict(beam_size=cfg["beam"], only_topk=10, post_processor="log-sigmoid"),
                dict(beam_size=4, only_topk=40), dict(beam_size=cfg["beam"], only_topk=3, post_processor="noop")):
