@@ -338,7 +338,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
     ItemDesc it = make_item(0u, kNoTile, 0u, 0.f, 0, 0u);
     if (a.n_items) {   // tile-sorted list: every XCD takes a contiguous run of tiles
         const uint32_t n = *a.n_items, nb = (n + W - 1) / W;
-        if (vblock < nb) { const uint64_t slot = (uint64_t)xcd_remap(vblock, nb) * W + grp; if (slot < n) it = a.items[slot]; }
+        if (vblock >= nb) return;   // a compacted list (second phase of a pruned layer) usually fills a small part of the grid
+        { const uint64_t slot = (uint64_t)xcd_remap(vblock, nb) * W + grp; if (slot < n) it = a.items[slot]; }
     } else {
         const uint64_t slot = (uint64_t)vblock * W + grp;
         if (slot < a.n_slots) it = a.items[slot];
