@@ -134,11 +134,63 @@ __device__ __forceinline__ uint32_t wave_bisect_kth(const uint32_t (&key)[N], ui
     return lo;
 }
 
+// Maximum of x over the wavefront, as a scalar: four DPP steps leave every lane with its 16-lane row's maximum (max is idempotent,
+// so mirrored / overlapping exchanges are fine), the four rows meet in SGPRs.  All 64 lanes must be active.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    x = max(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true));   // row_mirror
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)x, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)x, 48);
+    return max(max(a, b), max(c, d));
+}
+
+// Small k: take the best remaining candidate k times.  The bisection below costs ~15 scalar instructions per step and needs all 32
+// steps when the k-th score is tied (saturated post-processor outputs are the rule on deep trees) -- about 1000 scalar instructions
+// per selection, which made the query-stationary kernels scalar-issue bound (one scalar unit per CU; profiles/r03_topk.md).  One
+// extraction is a wavefront maximum (DPP), a ballot per candidate register to find the FIRST holder of that maximum -- lowest
+// register, then lowest lane = lowest position, the reference's tie-break -- two readlanes and three selects: ~19 vector and ~12
+// scalar instructions, and the winners come out already ranked (lane i receives the i-th best).
+template <int NS>
+__device__ __forceinline__ uint32_t wave_topk_extract(uint32_t (&kx)[NS], const uint32_t (&sbits)[NS], const uint32_t (&payload)[NS],
+                                                      uint32_t k, int lane, uint32_t& o_rank, uint32_t& o_sbits, uint32_t& o_payload) {
+    uint32_t osb = 0, opl = 0, i = 0;
+    for (; i < k; ++i) {
+        uint32_t m = kx[0];
+#pragma unroll
+        for (int r = 1; r < NS; ++r) m = max(m, kx[r]);
+        const uint32_t mx = wave_max_u32(m);
+        if (mx == 0u) break;                                         // no candidate left
+        bool found = false;
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            if (!found) {
+                const unsigned long long b = __ballot(kx[r] == mx);
+                if (b != 0ull) {
+                    const int wl = __builtin_ctzll(b);
+                    const int sb = __builtin_amdgcn_readlane((int)sbits[r], wl), pl = __builtin_amdgcn_readlane((int)payload[r], wl);
+                    const bool dst = (uint32_t)lane == i;
+                    osb = dst ? (uint32_t)sb : osb;
+                    opl = dst ? (uint32_t)pl : opl;
+                    kx[r] = lane == wl ? 0u : kx[r];
+                    found = true;
+                }
+            }
+        }
+    }
+    o_rank = (uint32_t)lane; o_sbits = osb; o_payload = opl;
+    return i;
+}
+constexpr uint32_t kTopkExtractMaxK = 20;   // above: the bisection's fixed cost is the smaller one
+
 // Returns kk = min(k, #candidates).  Lanes [0, kk) receive one selected candidate each: its final rank in
 // (value desc, position asc) order, its score bits and its payload.  sc: 64 uint2 of wavefront-private LDS.  k <= 64.
+// The keys are CONSUMED (the extraction clears the winners in place: no second copy in registers).
 template <int NS>
-__device__ __forceinline__ uint32_t wave_topk(const uint32_t (&key)[NS], const uint32_t (&sbits)[NS], const uint32_t (&payload)[NS],
+__device__ __forceinline__ uint32_t wave_topk(uint32_t (&key)[NS], const uint32_t (&sbits)[NS], const uint32_t (&payload)[NS],
                                               uint32_t k, uint2* sc, int lane, uint32_t& o_rank, uint32_t& o_sbits, uint32_t& o_payload) {
+    if (k <= kTopkExtractMaxK) return wave_topk_extract<NS>(key, sbits, payload, k, lane, o_rank, o_sbits, o_payload);
     o_rank = 0; o_sbits = 0; o_payload = 0;
     const uint32_t n_valid = wave_count_ge<NS>(key, 1u);
     const uint32_t kk = min(k, n_valid);

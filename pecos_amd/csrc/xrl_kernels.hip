@@ -834,14 +834,14 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
         sbits[r] = __float_as_uint(v); pos[r] = p;
         key[r] = p < n ? score_key(v) : 0u;
     }
-    uint32_t rank, sb, pp;
-    const uint32_t kk = wave_topk<NS>(key, sbits, pos, a.k, sc_all + wave * 64u, lane, rank, sb, pp);
-    if (a.done) {
+    if (a.done) {   // (before the selection: it consumes the keys)
         bool d = true;
         // the k-th best >= the best any later slot can reach (a NaN parent score proves nothing: no pruning)
         if (limited) d = ps_next == ps_next && wave_count_ge<NS>(key, score_key(a.mult ? fmaxf(ps_next, 0.0f) : ps_next)) >= a.k;
         if (lane == 0) a.done[q] = d ? 1u : 0u;
     }
+    uint32_t rank, sb, pp;
+    const uint32_t kk = wave_topk<NS>(key, sbits, pos, a.k, sc_all + wave * 64u, lane, rank, sb, pp);
     uint32_t child;
     if (lane_beam) {
         uint32_t jj = 0;                                            // last beam slot whose block starts at or before the position
