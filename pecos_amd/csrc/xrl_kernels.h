@@ -54,7 +54,8 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
                float* cand, int group, hipStream_t s);
 // counting sort of the item descriptors by tile (LDS histograms, no global atomics); start[n_tiles] = #items
 void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, void* sorted, uint32_t* H,
-                       uint32_t* start, hipStream_t s);
+                       uint32_t* start, hipStream_t s,
+                       const uint32_t* n_dev = nullptr);   // n_dev: device count of a compacted list (<= n_slots)
 uint32_t sort_max_tiles();
 // K1R (xrl_k1r.hip): tile-resident K1 (sparse queries, tile-sorted items, tile image held in LDS, accumulators in registers)
 bool k1r_eligible(const LayerDev& L);   // the layer carries tile images (every tile fits in LDS)

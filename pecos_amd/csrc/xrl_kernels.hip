@@ -145,8 +145,10 @@ void launch_k0b_remaining(const LayerDev& L, const LayerPlan& P, const QueriesDe
 constexpr uint32_t kSortChunk = 8192;    // item slots per block
 
 __global__ void __launch_bounds__(256)
-sort_hist_kernel(const ItemDesc* __restrict__ items, uint64_t n_slots, uint32_t T, uint32_t* __restrict__ H) {
+sort_hist_kernel(const ItemDesc* __restrict__ items, uint64_t n_slots, const uint32_t* __restrict__ n_dev, uint32_t T, uint32_t* __restrict__ H) {
     extern __shared__ uint32_t hist[];
+    if (n_dev) n_slots = min(n_slots, (uint64_t)*n_dev);          // compacted list: only its first *n_dev slots are items
+    if ((uint64_t)blockIdx.x * kSortChunk >= n_slots) return;      // (the later kernels skip this block's histogram as well)
     for (uint32_t t = threadIdx.x; t < T; t += 256) hist[t] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
@@ -160,9 +162,10 @@ sort_hist_kernel(const ItemDesc* __restrict__ items, uint64_t n_slots, uint32_t 
 
 // per tile: exclusive running sum over blocks (in place), total per tile
 __global__ void __launch_bounds__(256)
-sort_colsum_kernel(uint32_t* __restrict__ H, uint32_t B, uint32_t T, uint32_t* __restrict__ total) {
+sort_colsum_kernel(uint32_t* __restrict__ H, uint32_t B, const uint32_t* __restrict__ n_dev, uint32_t T, uint32_t* __restrict__ total) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= T) return;
+    if (n_dev) B = min(B, (uint32_t)(((uint64_t)*n_dev + kSortChunk - 1) / kSortChunk));
     uint32_t run = 0;
     for (uint32_t b = 0; b < B; ++b) { const uint32_t c = H[(size_t)b * T + t]; H[(size_t)b * T + t] = run; run += c; }
     total[t] = run;
@@ -194,9 +197,11 @@ __global__ void __launch_bounds__(1024) sort_scan_kernel(uint32_t* __restrict__ 
 }
 
 __global__ void __launch_bounds__(256)
-sort_scatter_kernel(const ItemDesc* __restrict__ items, uint64_t n_slots, uint32_t T, const uint32_t* __restrict__ H,
+sort_scatter_kernel(const ItemDesc* __restrict__ items, uint64_t n_slots, const uint32_t* __restrict__ n_dev, uint32_t T, const uint32_t* __restrict__ H,
                     const uint32_t* __restrict__ start, ItemDesc* __restrict__ sorted) {
     extern __shared__ uint32_t pos[];
+    if (n_dev) n_slots = min(n_slots, (uint64_t)*n_dev);
+    if ((uint64_t)blockIdx.x * kSortChunk >= n_slots) return;
     for (uint32_t t = threadIdx.x; t < T; t += 256) pos[t] = start[t] + H[(size_t)blockIdx.x * T + t];
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * kSortChunk;
@@ -210,7 +215,7 @@ uint32_t sort_max_tiles() { return 36864; }   // LDS histogram: 4 B per tile, <=
 size_t sort_hist_bytes(uint64_t n_slots, uint32_t T) { return ((n_slots + kSortChunk - 1) / kSortChunk) * (size_t)T * 4; }
 
 void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, void* sorted, uint32_t* H,
-                       uint32_t* start /*[n_tiles+1]*/, hipStream_t s) {
+                       uint32_t* start /*[n_tiles+1]*/, hipStream_t s, const uint32_t* n_dev) {
     if (n_slots == 0) return;
     const uint32_t T = L.n_tiles;
     if (T > sort_max_tiles()) fail("sort_items: too many tiles for the LDS histogram");
@@ -220,10 +225,10 @@ void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, v
         XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         XRL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(B), dim3(256), lds, s, static_cast<const ItemDesc*>(items), n_slots, T, H);
-    hipLaunchKernelGGL(sort_colsum_kernel, dim3((T + 255) / 256), dim3(256), 0, s, H, B, T, start);
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(B), dim3(256), lds, s, static_cast<const ItemDesc*>(items), n_slots, n_dev, T, H);
+    hipLaunchKernelGGL(sort_colsum_kernel, dim3((T + 255) / 256), dim3(256), 0, s, H, B, n_dev, T, start);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, start, T);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(B), dim3(256), lds, s, static_cast<const ItemDesc*>(items), n_slots, T, H,
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(B), dim3(256), lds, s, static_cast<const ItemDesc*>(items), n_slots, n_dev, T, H,
                        start, static_cast<ItemDesc*>(sorted));
     XRL_LAUNCH_CHECK();
 }

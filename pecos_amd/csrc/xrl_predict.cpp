@@ -189,14 +189,37 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 continue;
             }
             if (!o.stats_out && layer_mode(l, nrows) == 3) {
-                timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
-                const uint64_t n_slots3 = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
-                timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots3, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
                 if (!x_ok_done) {   // once per row batch: which dense query rows are finite (K1G's fast loop needs it on layers with missing cells)
                     lw.x_ok.reserve((size_t)nb * 4);
                     launch_xfinite(X, (uint32_t)row0, nrows, lw.x_ok.as<uint32_t>(), S);
                     x_ok_done = true;
                 }
+                // ---- exact bound pruning (see the tile-format path below): the GEMM over the children of the J best beam parents first,
+                //      then a second, tile-sorted GEMM over the remaining slots of the queries whose top-k is not final yet.  J covers about
+                //      one candidate register (64 candidates), like K1Q's first stage.
+                if (m.prune && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P, m.k2_legacy != 0)) {
+                    const uint32_t J = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(beam_in[l] - 1, 64 / std::max<uint64_t>(1, L.cand_bound(1))));
+                    const uint64_t slots_a = (uint64_t)nrows * J * L.max_tiles_per_parent, slots_b = (uint64_t)nrows * (beam_in[l] - J) * L.max_tiles_per_parent;
+                    lw.prune_done.reserve((size_t)nb * 4); lw.prune_cnt.reserve(256);
+                    LayerPlan PA = P; PA.beam_in = J;
+                    LayerPlan PB = P; PB.beam_in = beam_in[l] - J;
+                    timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S, J); });
+                    timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, slots_a, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
+                    timed("k1g_dense_x", (uint32_t)l, [&] { launch_k1g(L.dev, PA, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.x_ok.as<uint32_t>(), lw.cand.as<float>(), S); });
+                    timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, false,
+                                                                       J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr); });
+                    timed("k0b_remaining", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), J, lw.items.p,
+                                                                                   lw.prune_cnt.as<uint32_t>(), S); });
+                    timed("k1_sort_items_rest", (uint32_t)l, [&] { launch_sort_items(L.dev, slots_b, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S,
+                                                                                     lw.prune_cnt.as<uint32_t>()); });
+                    timed("k1g_dense_x_rest", (uint32_t)l, [&] { launch_k1g(L.dev, PB, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.x_ok.as<uint32_t>(), lw.cand.as<float>(), S); });
+                    timed("k2_topk_rest", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, false,
+                                                                            0, 0, nullptr, lw.prune_done.as<uint32_t>()); });
+                    continue;
+                }
+                timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
+                const uint64_t n_slots3 = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
+                timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots3, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
                 timed("k1g_dense_x", (uint32_t)l, [&] { launch_k1g(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.x_ok.as<uint32_t>(), lw.cand.as<float>(), S); });
                 timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
                 continue;
