@@ -3,6 +3,8 @@
 #include "../../include/xrl_abi.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -59,7 +61,7 @@ void upload_drm(const ScipyDrmF32* X, DevBuf& val, QueriesDev& d) {
 // Host-side worker threads for the bulk copies of the host ABI (staging X into pinned memory, writing the result CSR):
 // one thread moves ~6-10 GB/s, which would make a 300 MB X the slowest stage of the pipeline below.
 template <class F> void parallel_ranges(size_t n, size_t min_per_thread, F&& fn) {
-    unsigned nt = (unsigned)std::min<size_t>(8, std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
+    unsigned nt = (unsigned)std::min<size_t>(16, std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
     nt = std::min(nt, std::max(1u, std::thread::hardware_concurrency()));
     if (nt <= 1) { fn((size_t)0, n); return; }
     std::vector<std::thread> th;
@@ -73,22 +75,39 @@ template <class F> void parallel_ranges(size_t n, size_t min_per_thread, F&& fn)
     if (err) std::rethrow_exception(err);
 }
 void parallel_copy(void* dst, const void* src, size_t bytes) {
-    parallel_ranges(bytes, 4u << 20, [&](size_t b, size_t e) { std::memcpy((char*)dst + b, (const char*)src + b, e - b); });
+    parallel_ranges(bytes, 1u << 20, [&](size_t b, size_t e) { std::memcpy((char*)dst + b, (const char*)src + b, e - b); });
 }
+// two equally long arrays at once (labels + scores, column ids + values): one set of threads, each takes its share of both
+void parallel_copy2(void* dst0, const void* src0, void* dst1, const void* src1, size_t bytes_each) {
+    parallel_ranges(bytes_each, 512u << 10, [&](size_t b, size_t e) {
+        std::memcpy((char*)dst0 + b, (const char*)src0 + b, e - b);
+        std::memcpy((char*)dst1 + b, (const char*)src1 + b, e - b);
+    });
+}
+
+// XRL_HOST_TIMING=1: one stderr line per host-ABI call with the wall time of every stage of the pipeline (diagnostics only)
+struct HostTimes { double prep = 0, stage = 0, slot_wait = 0, enqueue = 0, final_sync = 0, prefix = 0, alloc = 0, copy_out = 0; };
+static thread_local HostTimes g_ht;
+static bool host_timing() { static const bool on = [] { const char* e = std::getenv("XRL_HOST_TIMING"); return e && e[0] == '1'; }(); return on; }
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // csr_t::create_pycsr, pecos/core/utils/matrix.hpp:300-316: one synchronous allocator call, then copy.
 void emit_csr(uint32_t rows, uint32_t cols, uint32_t stride, const uint32_t* idx, const float* val,
               const uint32_t* cnt, py_sparse_allocator_t alloc) {
+    double t0 = now_ms();
     std::vector<uint64_t> ptr((size_t)rows + 1);
     ptr[0] = 0;
     for (uint32_t r = 0; r < rows; ++r) ptr[r + 1] = ptr[r] + std::min(cnt[r], stride);
     const uint64_t nnz = ptr[rows];
     uint32_t* o_idx = nullptr; uint64_t* o_ptr = nullptr; float* o_val = nullptr;
+    g_ht.prefix += now_ms() - t0; t0 = now_ms();
     alloc(false, rows, cols, nnz, &o_idx, &o_ptr, &o_val);
+    g_ht.alloc += now_ms() - t0; t0 = now_ms();
     if (!o_ptr || (nnz && (!o_idx || !o_val))) fail("allocator callback returned null buffers");
     parallel_ranges((size_t)rows + 1, 1u << 16, [&](size_t b, size_t e) { std::memcpy(o_ptr + b, ptr.data() + b, (e - b) * 8); });
     if (nnz == (uint64_t)rows * stride) {          // every row full: the fixed-stride buffers ARE the CSR arrays
-        parallel_copy(o_idx, idx, nnz * 4); parallel_copy(o_val, val, nnz * 4);
+        parallel_copy2(o_idx, idx, o_val, val, nnz * 4);
+        g_ht.copy_out += now_ms() - t0;
         return;
     }
     parallel_ranges(rows, 1u << 15, [&](size_t b, size_t e) {
@@ -107,13 +126,27 @@ void reserve_outputs(Model& m, uint32_t rows, uint32_t k) {
     ws.h_idx.reserve(cells * 4); ws.h_val.reserve(cells * 4); ws.h_cnt.reserve((size_t)rows * 4);
 }
 
-void download_rows(Model& m, uint32_t r0, uint32_t r1, uint32_t k) {
+// `batch` >= 0: the copies run on the handle's D2H stream behind an event recorded on the compute stream, so that they do not
+// hold up the next batch's kernels (callers finish with sync_downloads); -1: on the compute stream itself.
+void download_rows(Model& m, uint32_t r0, uint32_t r1, uint32_t k, int batch = -1) {
     Workspace& ws = *m.ws;
     if (r1 <= r0) return;
+    hipStream_t s = m.stream;
+    if (batch >= 0) {
+        if (!m.d2h_stream) XRL_HIP(hipStreamCreateWithFlags(&m.d2h_stream, hipStreamNonBlocking));
+        while (m.d2h_events.size() <= (size_t)batch) { hipEvent_t e; XRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m.d2h_events.push_back(e); }
+        XRL_HIP(hipEventRecord(m.d2h_events[batch], m.stream));
+        XRL_HIP(hipStreamWaitEvent(m.d2h_stream, m.d2h_events[batch], 0));
+        s = m.d2h_stream;
+    }
     const size_t o = (size_t)r0 * k, n = (size_t)(r1 - r0) * k;
-    XRL_HIP(hipMemcpyAsync(ws.h_idx.as<uint32_t>() + o, ws.out_idx.as<uint32_t>() + o, n * 4, hipMemcpyDeviceToHost, m.stream));
-    XRL_HIP(hipMemcpyAsync(ws.h_val.as<float>() + o, ws.out_val.as<float>() + o, n * 4, hipMemcpyDeviceToHost, m.stream));
-    XRL_HIP(hipMemcpyAsync(ws.h_cnt.as<uint32_t>() + r0, ws.out_cnt.as<uint32_t>() + r0, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, m.stream));
+    XRL_HIP(hipMemcpyAsync(ws.h_idx.as<uint32_t>() + o, ws.out_idx.as<uint32_t>() + o, n * 4, hipMemcpyDeviceToHost, s));
+    XRL_HIP(hipMemcpyAsync(ws.h_val.as<float>() + o, ws.out_val.as<float>() + o, n * 4, hipMemcpyDeviceToHost, s));
+    XRL_HIP(hipMemcpyAsync(ws.h_cnt.as<uint32_t>() + r0, ws.out_cnt.as<uint32_t>() + r0, (size_t)(r1 - r0) * 4, hipMemcpyDeviceToHost, s));
+}
+void sync_downloads(Model& m) {
+    XRL_HIP(hipStreamSynchronize(m.stream));
+    if (m.d2h_stream) XRL_HIP(hipStreamSynchronize(m.d2h_stream));
 }
 
 void run_and_emit(Model& m, const QueriesDev& X, const PredictOpts& o, py_sparse_allocator_t alloc) {
@@ -140,6 +173,7 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     use_device(m.device);
     if (!m.ws) m.ws = std::make_unique<Workspace>();
     Workspace& ws = *m.ws;
+    double t_ph = now_ms();
     const ScipyCsrF32* Xs = is_csr ? reinterpret_cast<const ScipyCsrF32*>(input_x) : nullptr;
     const ScipyDrmF32* Xd = is_csr ? nullptr : reinterpret_cast<const ScipyDrmF32*>(input_x);
     const uint32_t rows = is_csr ? Xs->rows : Xd->rows;
@@ -152,7 +186,7 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     const bool staged = m.host_pipeline && bytes >= (32ull << 20);
     uint32_t n_batch = 1;
     if (staged && rows >= 8192)
-        n_batch = is_csr ? (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, bytes / (24ull << 20)))
+        n_batch = is_csr ? (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, bytes / ((uint64_t)std::max(1, m.host_batch_mb) << 20)))
                          : (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, rows / 65536u));
     QueriesDev X{};
     if (!staged) {
@@ -213,6 +247,7 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
         if (reg_val) (void)hipHostUnregister(const_cast<float*>(is_csr ? Xs->val : Xd->val));
         reg_idx = reg_val = false;
     };
+    g_ht.prep += now_ms() - t_ph;
     try {
         uint64_t chunk = 0;                                                 // staged chunks so far: slot = chunk & 1
         for (uint32_t b = 0; b < n_batch; ++b) {
@@ -232,10 +267,12 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
                     last_slot = slot;
                     continue;
                 }
+                t_ph = now_ms();
                 if (chunk >= 2) XRL_HIP(hipEventSynchronize(up[slot]));    // the slot's previous upload has left the staging buffer
+                g_ht.slot_wait += now_ms() - t_ph; t_ph = now_ms();
                 char* st = ws.stage[slot].as<char>();
                 if (is_csr) {
-                    parallel_copy(st, Xs->col_idx + c0, n * 4); parallel_copy(st + n * 4, Xs->val + c0, n * 4);
+                    parallel_copy2(st, Xs->col_idx + c0, st + n * 4, Xs->val + c0, n * 4);
                     XRL_HIP(hipMemcpyAsync(ws.x_idx.as<uint32_t>() + c0, st, n * 4, hipMemcpyHostToDevice, m.copy_stream));
                     XRL_HIP(hipMemcpyAsync(ws.x_val.as<float>() + c0, st + n * 4, n * 4, hipMemcpyHostToDevice, m.copy_stream));
                 } else {
@@ -244,17 +281,23 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
                 }
                 XRL_HIP(hipEventRecord(up[slot], m.copy_stream));
                 last_slot = slot;
+                g_ht.stage += now_ms() - t_ph;
             }
+            t_ph = now_ms();
             if (last_slot >= 0) XRL_HIP(hipStreamWaitEvent(m.stream, up[last_slot], 0));   // batch b's kernels start when its rows have arrived (the copy stream is in order)
             if (rb[b + 1] > rb[b]) {
                 predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, false,
                                rb[b], rb[b + 1] - rb[b]);
-                download_rows(m, rb[b], rb[b + 1], k);
+                download_rows(m, rb[b], rb[b + 1], k, (int)b);
             }
+            g_ht.enqueue += now_ms() - t_ph;
         }
-        XRL_HIP(hipStreamSynchronize(m.stream));
+        t_ph = now_ms();
+        sync_downloads(m);
+        g_ht.final_sync += now_ms() - t_ph;
     } catch (...) {
         (void)hipStreamSynchronize(m.copy_stream); (void)hipStreamSynchronize(m.stream);
+        if (m.d2h_stream) (void)hipStreamSynchronize(m.d2h_stream);
         for (auto& e : up) (void)hipEventDestroy(e);
         unregister();
         throw;
@@ -304,9 +347,15 @@ void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, u
     const uint32_t k = effective_topk(m, o.only_topk);
     const size_t R = 1 + m.replicas.size();
     if (R == 1 || rows < 2 * R) {
+        const double t_call = now_ms();
+        g_ht = HostTimes{};
         host_compute(m, input_x, o, is_csr);
         Workspace& ws = *m.ws;
         emit_csr(rows, out_cols, k, ws.h_idx.as<uint32_t>(), ws.h_val.as<float>(), ws.h_cnt.as<uint32_t>(), alloc);
+        if (host_timing())
+            std::fprintf(stderr, "[xrl host] rows=%u total=%.2f ms: prep %.2f | stage-memcpy+h2d-enqueue %.2f | wait for a staging slot %.2f | kernel+d2h enqueue %.2f | "
+                                 "final sync %.2f | row-pointer prefix %.2f | allocator callback %.2f | copy out %.2f\n",
+                         rows, now_ms() - t_call, g_ht.prep, g_ht.stage, g_ht.slot_wait, g_ht.enqueue, g_ht.final_sync, g_ht.prefix, g_ht.alloc, g_ht.copy_out);
         return;
     }
     // ---- shard boundaries: equal shares of the nnz (+1 per row so that empty rows still count); dense X: equal rows
@@ -1098,6 +1147,7 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
     else if (!std::strcmp(key, "sort_min_tiles")) m.sort_min_tiles = (int)value;
     else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;
+    else if (!std::strcmp(key, "host_batch_mb")) m.host_batch_mb = (int)value;
     else if (!std::strcmp(key, "host_register")) m.host_register = (int)value;   // 1: page-lock the caller's X in place (hipHostRegister) instead of staging it through pinned buffers   // 0: the host ABI uploads X in one piece before computing
     else if (!std::strcmp(key, "k1q_fuse")) m.k1q_fuse = (int)value;           // 0: one K1Q launch per dense-format layer
     else if (!std::strcmp(key, "k1g_min_items")) m.k1g_min_items = (int)value;   // dense X: queries per parent from which a dense-format layer runs the tiled SGEMM K1G (0 = never)
@@ -1151,7 +1201,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
                 use_device(dev);
                 std::unique_ptr<Model> r = m.src_kind == 0 ? load_model_from_disk(m.src_path, m.weight_matrix_type) : load_mmap_model_from_disk(m.src_path);
                 r->device = dev;
-                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->host_pipeline = m.host_pipeline; r->host_register = m.host_register;
+                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->host_pipeline = m.host_pipeline; r->host_batch_mb = m.host_batch_mb; r->host_register = m.host_register;
                 r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers; r->k2_legacy = m.k2_legacy;
                 r->overlap_min_rows = m.overlap_min_rows; r->k1r_min_items = m.k1r_min_items; r->k1r_items_per_block = m.k1r_items_per_block; r->k1l_min_items = m.k1l_min_items; r->prune = m.prune;
                 r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;

@@ -54,6 +54,8 @@ Model::~Model() {
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
     if (ws_done) (void)hipEventDestroy(ws_done);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    if (d2h_stream) (void)hipStreamDestroy(d2h_stream);
+    for (hipEvent_t e : d2h_events) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
 }
 uint64_t Model::device_bytes() const {

@@ -18,7 +18,7 @@ for st in "$@"; do
     tests) timeout 1500 python -m pytest tests -m gpu -q -x $args 2>&1 | tail -15 > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
     bench) n=$((n+1)); echo "== bench $args"; timeout 1200 python bench.py $args > $O/bench_$n.json 2> $O/bench_$n.err; echo "$args" > $O/bench_$n.args
-           grep -E "per-launch|host ABI|cpu reference|Error|error" $O/bench_$n.err | cut -c1-1500; python -c "
+           grep -E "per-launch|host ABI|xrl host|cpu reference|Error|error" $O/bench_$n.err | cut -c1-1500; python -c "
 import json,sys
 try:
     d=json.load(open('$O/bench_$n.json')); print({k:d.get(k) for k in ('value','ms_per_step','value_host_abi','parity')}); print(d['roofline'].get('per_kernel_ms_per_step'))
