@@ -6,6 +6,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -60,10 +62,74 @@ void upload_drm(const ScipyDrmF32* X, DevBuf& val, QueriesDev& d) {
 
 // Host-side worker threads for the bulk copies of the host ABI (staging X into pinned memory, writing the result CSR):
 // one thread moves ~6-10 GB/s, which would make a 300 MB X the slowest stage of the pipeline below.
+// The workers are persistent (creating 16 threads per 32 MB chunk cost as much as the copy itself): a process-wide pool, never
+// destroyed (its threads sleep on a condition variable until the process exits).  One job at a time owns the pool; a caller that
+// finds it busy (the per-device host threads of a multi-device handle) spawns its own threads as before.
+class CopyPool {
+public:
+    static CopyPool& get() { static CopyPool* p = new CopyPool(); return *p; }
+    unsigned size() const { return (unsigned)workers_.size() + 1u; }      // + the calling thread
+    // runs fn(n*i/parts, n*(i+1)/parts) for i in [0, parts) on the workers and the caller; false: the pool is busy, nothing was run
+    bool try_run(size_t n, unsigned parts, const std::function<void(size_t, size_t)>& fn) {
+        std::unique_lock<std::mutex> owner(owner_, std::try_to_lock);
+        if (!owner.owns_lock()) return false;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            fn_ = &fn; n_ = n; parts_ = parts; next_ = 0; pending_ = parts; err_ = nullptr; ++gen_;
+        }
+        cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(mu_);
+        done_.wait(g, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+        if (err_) std::rethrow_exception(err_);
+        return true;
+    }
+private:
+    CopyPool() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned nw = std::min(15u, hw > 1 ? hw - 1 : 0u);
+        for (unsigned i = 0; i < nw; ++i) workers_.emplace_back([this] { loop(); });
+        for (auto& t : workers_) t.detach();
+    }
+    void work() {
+        for (;;) {
+            unsigned i; const std::function<void(size_t, size_t)>* f; size_t n; unsigned parts;
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (!fn_ || next_ >= parts_) return;
+                i = next_++; f = fn_; n = n_; parts = parts_;
+            }
+            std::exception_ptr e;
+            try { (*f)(n * i / parts, n * (i + 1) / parts); } catch (...) { e = std::current_exception(); }
+            std::lock_guard<std::mutex> g(mu_);
+            if (e && !err_) err_ = e;
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> g(mu_); cv_.wait(g, [&] { return gen_ != seen; }); seen = gen_; }
+            work();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex owner_, mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t, size_t)>* fn_ = nullptr;
+    size_t n_ = 0; unsigned parts_ = 0, next_ = 0, pending_ = 0; uint64_t gen_ = 0;
+    std::exception_ptr err_;
+};
+
 template <class F> void parallel_ranges(size_t n, size_t min_per_thread, F&& fn) {
     unsigned nt = (unsigned)std::min<size_t>(16, std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
     nt = std::min(nt, std::max(1u, std::thread::hardware_concurrency()));
     if (nt <= 1) { fn((size_t)0, n); return; }
+    {
+        const std::function<void(size_t, size_t)> f = [&](size_t b, size_t e) { fn(b, e); };
+        if (CopyPool::get().try_run(n, nt, f)) return;
+    }
     std::vector<std::thread> th;
     std::exception_ptr err; std::mutex emu;
     for (unsigned t = 0; t < nt; ++t)
@@ -95,16 +161,31 @@ static double now_ms() { return std::chrono::duration<double, std::milli>(std::c
 void emit_csr(uint32_t rows, uint32_t cols, uint32_t stride, const uint32_t* idx, const float* val,
               const uint32_t* cnt, py_sparse_allocator_t alloc) {
     double t0 = now_ms();
-    std::vector<uint64_t> ptr((size_t)rows + 1);
-    ptr[0] = 0;
-    for (uint32_t r = 0; r < rows; ++r) ptr[r + 1] = ptr[r] + std::min(cnt[r], stride);
-    const uint64_t nnz = ptr[rows];
+    // row lengths -> nnz in P partial sums (the allocator needs nnz first), then the row pointers are written straight into the
+    // allocator's array, every part continuing from its partial sum
+    constexpr size_t P = 16;
+    uint64_t part[P + 1] = {0};
+    parallel_ranges(P, 1, [&](size_t pb, size_t pe) {
+        for (size_t p = pb; p < pe; ++p) {
+            uint64_t s = 0;
+            for (size_t r = (size_t)rows * p / P, re = (size_t)rows * (p + 1) / P; r < re; ++r) s += std::min(cnt[r], stride);
+            part[p + 1] = s;
+        }
+    });
+    for (size_t p = 0; p < P; ++p) part[p + 1] += part[p];
+    const uint64_t nnz = part[P];
     uint32_t* o_idx = nullptr; uint64_t* o_ptr = nullptr; float* o_val = nullptr;
     g_ht.prefix += now_ms() - t0; t0 = now_ms();
     alloc(false, rows, cols, nnz, &o_idx, &o_ptr, &o_val);
     g_ht.alloc += now_ms() - t0; t0 = now_ms();
     if (!o_ptr || (nnz && (!o_idx || !o_val))) fail("allocator callback returned null buffers");
-    parallel_ranges((size_t)rows + 1, 1u << 16, [&](size_t b, size_t e) { std::memcpy(o_ptr + b, ptr.data() + b, (e - b) * 8); });
+    o_ptr[0] = 0;
+    parallel_ranges(P, 1, [&](size_t pb, size_t pe) {
+        for (size_t p = pb; p < pe; ++p) {
+            uint64_t run = part[p];
+            for (size_t r = (size_t)rows * p / P, re = (size_t)rows * (p + 1) / P; r < re; ++r) { run += std::min(cnt[r], stride); o_ptr[r + 1] = run; }
+        }
+    });
     if (nnz == (uint64_t)rows * stride) {          // every row full: the fixed-stride buffers ARE the CSR arrays
         parallel_copy2(o_idx, idx, o_val, val, nnz * 4);
         g_ht.copy_out += now_ms() - t0;
@@ -112,11 +193,12 @@ void emit_csr(uint32_t rows, uint32_t cols, uint32_t stride, const uint32_t* idx
     }
     parallel_ranges(rows, 1u << 15, [&](size_t b, size_t e) {
         for (size_t r = b; r < e; ++r) {
-            const size_t n = (size_t)(ptr[r + 1] - ptr[r]);
-            std::memcpy(o_idx + ptr[r], idx + r * stride, n * 4);
-            std::memcpy(o_val + ptr[r], val + r * stride, n * 4);
+            const size_t n = (size_t)(o_ptr[r + 1] - o_ptr[r]);
+            std::memcpy(o_idx + o_ptr[r], idx + r * stride, n * 4);
+            std::memcpy(o_val + o_ptr[r], val + r * stride, n * 4);
         }
     });
+    g_ht.copy_out += now_ms() - t0;
 }
 
 void reserve_outputs(Model& m, uint32_t rows, uint32_t k) {
@@ -168,6 +250,7 @@ void run_and_emit(Model& m, const QueriesDev& X, const PredictOpts& o, py_sparse
 // (pecos/core/base.py:431-464 discipline).  Small inputs take the single-batch path.
 // Runs the whole host-ABI pipeline of ONE device for the rows of `input_x` and leaves the fixed-stride results in the handle's
 // pinned host buffers (ws.h_idx / h_val / h_cnt, stride k); the caller holds m.mu and emits the CSR afterwards.
+constexpr int kStageSlots = 3;   // == the length of Workspace::stage
 template <class XT>
 void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     use_device(m.device);
@@ -222,9 +305,9 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     }
     for (uint32_t b = 0; b < n_batch; ++b) o.reserve_rows = std::max(o.reserve_rows, rb[b + 1] - rb[b]);
     const uint64_t chunk_elems = (32ull << 20) / (is_csr ? 8u : 4u);      // elements per staged upload chunk
-    for (int s2 = 0; s2 < 2; ++s2) ws.stage[s2].reserve(std::min(max_elems, chunk_elems) * (is_csr ? 8u : 4u));
+    for (int s2 = 0; s2 < kStageSlots; ++s2) ws.stage[s2].reserve(std::min(max_elems, chunk_elems) * (is_csr ? 8u : 4u));
     if (!m.copy_stream) XRL_HIP(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
-    hipEvent_t up[2];
+    hipEvent_t up[kStageSlots];
     for (auto& e : up) XRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const uint32_t k = effective_topk(m, o.only_topk);
     reserve_outputs(m, rows, k);
@@ -254,7 +337,7 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
             const uint64_t e0 = elem_at(rb[b]), e1 = elem_at(rb[b + 1]);
             int last_slot = -1;
             for (uint64_t c0 = e0; c0 < e1; c0 += chunk_elems, ++chunk) {
-                const int slot = (int)(chunk & 1u);
+                const int slot = (int)(chunk % (uint64_t)kStageSlots);
                 const uint64_t n = std::min(chunk_elems, e1 - c0);
                 if (direct) {
                     if (is_csr) {
@@ -268,7 +351,7 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
                     continue;
                 }
                 t_ph = now_ms();
-                if (chunk >= 2) XRL_HIP(hipEventSynchronize(up[slot]));    // the slot's previous upload has left the staging buffer
+                if (chunk >= (uint64_t)kStageSlots) XRL_HIP(hipEventSynchronize(up[slot]));    // the slot's previous upload has left the staging buffer
                 g_ht.slot_wait += now_ms() - t_ph; t_ph = now_ms();
                 char* st = ws.stage[slot].as<char>();
                 if (is_csr) {

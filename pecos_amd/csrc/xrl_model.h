@@ -145,7 +145,7 @@ struct Workspace {
     DevBuf x_ptr, x_idx, x_val;
     DevBuf out_idx, out_val, out_cnt;
     PinnedBuf h_idx, h_val, h_cnt;
-    PinnedBuf stage[2];   // double-buffered pinned staging of the pipelined host-ABI upload
+    PinnedBuf stage[3];   // pinned staging ring of the pipelined host-ABI upload (kStageSlots, xrl_abi.cpp)
     // initial beam for the single-layer API
     DevBuf init_idx, init_val, init_cnt;
 };
