@@ -267,10 +267,24 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     // back to the query-stationary kernel, 5x slower).  The upload itself always moves in <= 32 MB chunks through two pinned
     // staging buffers, whatever the batch size.
     const bool staged = m.host_pipeline && bytes >= (32ull << 20);
-    uint32_t n_batch = 1;
-    if (staged && rows >= 8192)
-        n_batch = is_csr ? (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(4, bytes / ((uint64_t)std::max(1, m.host_batch_mb) << 20)))
-                         : (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, rows / 65536u));
+    // CSR: batches GROW (x1.6 from a third of host_batch_mb up to 3x host_batch_mb): the first kernels start after a few megabytes have
+    // arrived, the later launches are large enough to fill the chip (a 40 k-row launch of the query-stationary kernel runs at 0.7x
+    // the per-row rate of a 490 k-row one: measured with rocprofv3's copy + kernel trace, profiles/r03_host_abi.md)
+    std::vector<uint64_t> share;                                        // cumulative element targets of the batch ends
+    if (staged && rows >= 8192) {
+        if (is_csr) {
+            const double mb = (double)(1u << 20) / 8.0;                    // elements per megabyte of (id, value) pairs
+            double cur = std::max(1, m.host_batch_mb) / 3.0, pos = 0.0;
+            const double cap = 3.0 * std::max(1, m.host_batch_mb);
+            while (pos + cur * mb < (double)elems && share.size() < 31) { pos += cur * mb; share.push_back((uint64_t)pos); cur = std::min(cap, cur * 1.6); }
+            // a short last batch joins the previous one (the tail after the upload ends is one launch either way)
+            if (!share.empty() && (double)elems - (double)share.back() < 0.25 * cur * mb) share.pop_back();
+        } else {
+            const uint32_t nb = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, rows / 65536u));
+            for (uint32_t b = 1; b < nb; ++b) share.push_back(elems * b / nb);
+        }
+    }
+    const uint32_t n_batch = (uint32_t)share.size() + 1;
     QueriesDev X{};
     if (!staged) {
         if (is_csr) upload_csr(Xs, ws.x_ptr, ws.x_idx, ws.x_val, X);
@@ -286,7 +300,7 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     std::vector<uint32_t> rb(n_batch + 1, rows);
     rb[0] = 0;
     for (uint32_t b = 1; b < n_batch; ++b) {
-        if (is_csr) rb[b] = (uint32_t)(std::lower_bound(Xs->row_ptr, Xs->row_ptr + rows + 1, elems * b / n_batch) - Xs->row_ptr);
+        if (is_csr) rb[b] = (uint32_t)(std::lower_bound(Xs->row_ptr, Xs->row_ptr + rows + 1, share[b - 1]) - Xs->row_ptr);
         else rb[b] = (uint32_t)((uint64_t)rows * b / n_batch);
         rb[b] = std::min(std::max(rb[b], rb[b - 1]), rows);
     }
@@ -368,11 +382,14 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
             }
             t_ph = now_ms();
             if (last_slot >= 0) XRL_HIP(hipStreamWaitEvent(m.stream, up[last_slot], 0));   // batch b's kernels start when its rows have arrived (the copy stream is in order)
-            if (rb[b + 1] > rb[b]) {
+            if (rb[b + 1] > rb[b])
                 predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, false,
                                rb[b], rb[b + 1] - rb[b]);
-                download_rows(m, rb[b], rb[b + 1], k, (int)b);
-            }
+            // results: everything but the last batch goes back in ONE set of copies on the D2H stream, queued before the last batch's
+            // kernels (per-batch copies are blit kernels that held up the next batch's launch: 12 x 0.15 ms); the last batch follows
+            // on the compute stream
+            if (b + 2 == n_batch) download_rows(m, 0, rb[b + 1], k, 0);
+            else if (b + 1 == n_batch) download_rows(m, n_batch > 1 ? rb[b] : 0, rb[b + 1], k, -1);
             g_ht.enqueue += now_ms() - t_ph;
         }
         t_ph = now_ms();
