@@ -298,8 +298,9 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *                         items per wavefront) once a tile serves this many items on average (0 = never); needs the K1L tile images
  *                         (XRL_K1L=1 in the environment at load)
  *   "overlap_min_rows"    split predicts of at least this many rows into two batches on two streams (0 = never)
- *   "host_batch_mb"       24 (default): CSR input of the pipelined host ABI is computed in batches of about this many megabytes of
- *                         (column id, value) pairs (4..32 batches per call)
+ *   "host_batch_mb"       12 (default): CSR input of the pipelined host ABI is computed in batches that grow x1.6 from a third of this
+ *                         many megabytes of (column id, value) pairs up to three times it (measured on Amazon-670K: 12 -> 10.4 ms per
+ *                         call, 24 -> 12.1, 36 -> 13.0)
  *   "host_pipeline"       1 (default): c_xlinear_predict_* cut a large X into nnz-balanced row batches; batch b+1 is staged into
  *                         pinned memory and uploaded on a copy stream while batch b computes; 0: one synchronous upload
  *   "dense_layers"        1 (default): layers that carry the dense row format run the fused query-stationary kernel K1Q

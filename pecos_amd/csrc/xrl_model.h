@@ -163,7 +163,7 @@ struct Model {
     hipStream_t d2h_stream = nullptr;       // D2H of its results: a batch's rows travel back under the next batch's kernels
     std::vector<hipEvent_t> d2h_events;     // "batch b's kernels are queued" (grow-only, reused)
     int host_register = 0;                  // host ABI: 1 = hipHostRegister the caller's arrays for the call and DMA from them directly (no staging copy)
-    int host_batch_mb = 24;                 // host ABI, CSR input: megabytes of (column id, value) pairs per compute batch
+    int host_batch_mb = 12;                 // host ABI, CSR input: megabytes of (column id, value) pairs per compute batch
     int host_pipeline = 1;                  // host ABI: cut large X into row batches whose upload overlaps the previous batch's kernels
     std::vector<hipEvent_t> events;         // cross-stream ordering (timing disabled), reused across predicts
     std::mutex mu;                          // one predict at a time per handle
