@@ -169,14 +169,19 @@ def main():
     tstream = torch.cuda.Stream(device=dev)
     stream = tstream.cuda_stream
     use_dist = dist.is_initialized()
-    # packed rows [idx(k) | val(k) | cnt].  With a process group the shard is computed in two halves: the all-gather of the
-    # first half runs on a second stream under the second half's kernels, the gather of the second half closes the step.
-    # (decided from the GLOBAL bounds: every rank must issue the same collectives)
-    parts = 2 if (use_dist and int(np.diff(bounds).min()) >= 1024) else 1
-    cstream = torch.cuda.Stream(device=dev) if parts == 2 else None
-    ev_half = torch.cuda.Event() if parts == 2 else None
+    # packed rows [idx(k) | val(k) | cnt].  With a process group the all-gather of step s runs on a second stream under the kernels
+    # of step s+1 (two result buffers take turns): a rank's launches are latency-bound at a shard's size (61 k rows take 0.96 ms,
+    # two halves of it 2 x 0.70 ms -- profiles/r03_batch_size.md), so the shard is NOT cut to hide the gather inside its own step.
+    # Every step's gathered result is complete before the closing barrier; the last step's is what the parity check reads.
+    parts = 1
+    n_buf = 2 if use_dist else 1
+    cstream = torch.cuda.Stream(device=dev) if use_dist else None
+    ev_done = [torch.cuda.Event() for _ in range(n_buf)]        # step's kernels queued (compute stream)
+    ev_free = [torch.cuda.Event() for _ in range(n_buf)]        # step's gather finished (gather stream): the buffer may be overwritten
     with torch.cuda.stream(tstream):
-        pk = PackedTopk(bounds, rank, k, dev, parts=parts)
+        pks = [PackedTopk(bounds, rank, k, dev, parts=parts) for _ in range(n_buf)]
+    pk = pks[0]
+    step_no = [0]
 
     view = (ScipyCsrF32.init_from(Xs) if sparse else ScipyDrmF32.init_from(Xs)) if args.include_upload else None
     last_host = [None]
@@ -189,22 +194,23 @@ def main():
             last_host[0] = alloc
 
     def step_resident():
-        for p in range(parts):
-            with torch.cuda.stream(tstream):
-                b, e = pk.rows(p)
-                p_idx, p_val, p_cnt, p_stride = pk.pointers(p)
-                if e > b:
-                    clib.predict_device_rows(h, q, beam, None, args.topk, p_idx, p_val, p_cnt, p_stride, b, e - b, stream=stream, sync=False)
-                if parts == 2 and p == 0:
-                    ev_half.record(tstream)
-                elif use_dist:
-                    pk.gather(p)                           # last (or only) part: on the compute stream
-            if parts == 2 and p == 0:
-                with torch.cuda.stream(cstream):
-                    cstream.wait_event(ev_half)
-                    pk.gather(0)                           # overlaps the second half's kernels
-        if parts == 2:
-            tstream.wait_stream(cstream)
+        s = step_no[0]; step_no[0] += 1
+        i = s % n_buf
+        cur = pks[i]
+        with torch.cuda.stream(tstream):
+            if use_dist and s >= n_buf:
+                tstream.wait_event(ev_free[i])             # the gather that last read this buffer (step s - 2) is done
+            b, e = cur.rows(0)
+            p_idx, p_val, p_cnt, p_stride = cur.pointers(0)
+            if e > b:
+                clib.predict_device_rows(h, q, beam, None, args.topk, p_idx, p_val, p_cnt, p_stride, b, e - b, stream=stream, sync=False)
+            if use_dist:
+                ev_done[i].record(tstream)
+        if use_dist:
+            with torch.cuda.stream(cstream):
+                cstream.wait_event(ev_done[i])
+                cur.gather(0)                              # under the next step's kernels
+                ev_free[i].record(cstream)
 
     step = step_upload if args.include_upload else step_resident
 
@@ -246,6 +252,7 @@ def main():
             if rank == 0:
                 G = smat.vstack([pc for pc in pieces if pc is not None], format="csr")
         else:
+            pk = pks[(step_no[0] - 1) % n_buf] if step_no[0] else pks[0]     # what the LAST timed step wrote (and gathered)
             if not use_dist:
                 with torch.cuda.stream(tstream):
                     for p in range(parts):
@@ -267,7 +274,7 @@ def main():
         roof = roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_step)
         cfg_out = dict(workload=f"{args.config} synthetic x{args.scale}: N={n_total} D={Xs.shape[1]} L={ks[-1]} tree={ks} "
                                 f"nnz/row={nnz_row:.1f} beam={beam} topk={k} pp=l3-hinge bias=1.0",
-                       parallelism=f"query-shard x{world}" + (f" + rccl all-gather of packed top-k rows ({parts} part(s); the first overlaps the second half's kernels)" if world > 1 else ""),
+                       parallelism=f"query-shard x{world}" + (" + rccl all-gather of the packed top-k rows of step s on a second stream under the kernels of step s+1 (two result buffers)" if world > 1 else ""),
                        model_hbm_gb=round(clib.model_device_bytes(h) / 1e9, 3),
                        dense_format_layers=[l for l in range(depth) if linfo[l]["dense"]])
         out = dict(metric=baseline_metric(), value=round(value, 1), unit="queries/s", n_gpus=world,
