@@ -469,6 +469,9 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
                 frac_ref_layout=round(ref_layout / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 2) if ref_layout else None,
                 frac_ref_layout_note="SURVEY.md 8(d): every active reference chunk streamed whole, over the whole step; > 1 because chunks are looked up, not streamed",
                 requests=requests, issue=issue, l2=l2,
+                pruning=None if any(o.replace(" ", "") == "prune=0" for o in args.opt) else
+                        "exact bound pruning is on: frac_matched and frac_ref_layout count the candidate set of the UNPRUNED beam search (what the reference "
+                        "evaluates); the kernels prove most of it unnecessary and never request it, so both exceed 1 -- `frac` (counter bytes) is what moved",
                 alg_bytes_per_launch=per_launch, avg_launch_ms=round(avg_ms, 4), launches_per_step=launches_per_step,
                 model="frac: counter bytes; frac_matched: matched work, no inter-query reuse (compulsory bytes for cache-resident structures); "
                       "frac_ref_layout: SURVEY 8(d) chunk streaming (see bench.py docstring / DESIGN.md section 4)",
