@@ -171,7 +171,7 @@ def main():
     use_dist = dist.is_initialized()
     # packed rows [idx(k) | val(k) | cnt].  With a process group the all-gather of step s runs on a second stream under the kernels
     # of step s+1 (two result buffers take turns): a rank's launches are latency-bound at a shard's size (61 k rows take 0.96 ms,
-    # two halves of it 2 x 0.70 ms -- profiles/r03_batch_size.md), so the shard is NOT cut to hide the gather inside its own step.
+    # two halves of it 2 x 0.70 ms -- profiles/r03_pruning_topk.md section 3), so the shard is NOT cut to hide the gather inside its own step.
     # Every step's gathered result is complete before the closing barrier; the last step's is what the parity check reads.
     parts = 1
     n_buf = 2 if use_dist else 1

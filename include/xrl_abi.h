@@ -285,10 +285,12 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *                         the box has fewer).  A predict then cuts X into nnz-balanced row shards, one host thread + stream + pinned
  *                         staging per device, no inter-GPU traffic, results of all shards into the arrays of the ONE allocator call.
  *                         Only for models loaded from a folder.  c_xlinear_get_int_attr "nr_devices" reads it back.
- *   "prune"               1 (default): EXACT bound pruning -- a layer scores the children of the best beam parent first and skips the other
- *                         parents for every query whose k-th best candidate already reaches the next parent's score (every post-processor
- *                         with a combiner keeps a child's score <= its parent's, and later candidates lose ties by position), so the
- *                         result is unchanged bit for bit; 0: every candidate of every beam parent is scored
+ *   "prune"               1 (default): EXACT bound pruning -- a layer scores the children of the best beam parent(s) first (tile format: one
+ *                         parent; dense row format and the dense-X SGEMM: as many as fill 64 candidates) and skips the other parents
+ *                         for every query whose k-th best candidate already reaches the next parent's bound (every post-processor with
+ *                         a combiner keeps a child's score <= max(its parent's, 0) resp. <= its parent's, and later candidates lose
+ *                         ties by position), so the result is unchanged bit for bit; NaN parent scores and "noop" disable it per
+ *                         query / layer; 0: every candidate of every beam parent is scored (what the reference evaluates)
  *   "k1r_min_items"       sparse X: run a tile-format layer with the tile-RESIDENT kernel K1R (tile-sorted items, the tile's
  *                         image in LDS, accumulators in registers) once a tile serves this many items on average
  *                         (0 = never, the default: profiles/r03_k1r_experiments.txt); needs the tile images (XRL_K1R=1 in the environment at load;

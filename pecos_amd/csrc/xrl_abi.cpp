@@ -269,7 +269,7 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     const bool staged = m.host_pipeline && bytes >= (32ull << 20);
     // CSR: batches GROW (x1.6 from a third of host_batch_mb up to 3x host_batch_mb): the first kernels start after a few megabytes have
     // arrived, the later launches are large enough to fill the chip (a 40 k-row launch of the query-stationary kernel runs at 0.7x
-    // the per-row rate of a 490 k-row one: measured with rocprofv3's copy + kernel trace, profiles/r03_host_abi.md)
+    // the per-row rate of a 490 k-row one: measured with rocprofv3's copy + kernel trace, profiles/r03_pruning_topk.md section 4)
     std::vector<uint64_t> share;                                        // cumulative element targets of the batch ends
     if (staged && rows >= 8192) {
         if (is_csr) {

@@ -148,7 +148,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
 
 // Small k: take the best remaining candidate k times.  The bisection below costs ~15 scalar instructions per step and needs all 32
 // steps when the k-th score is tied (saturated post-processor outputs are the rule on deep trees) -- about 1000 scalar instructions
-// per selection, which made the query-stationary kernels scalar-issue bound (one scalar unit per CU; profiles/r03_topk.md).  One
+// per selection, which made the query-stationary kernels scalar-issue bound (one scalar unit per CU; profiles/r03_pruning_topk.md).  One
 // extraction is a wavefront maximum (DPP), a ballot per candidate register to find the FIRST holder of that maximum -- lowest
 // register, then lowest lane = lowest position, the reference's tie-break -- two readlanes and three selects: ~19 vector and ~12
 // scalar instructions, and the winners come out already ranked (lane i receives the i-th best).
