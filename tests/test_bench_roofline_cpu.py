@@ -114,3 +114,20 @@ def test_counter_based_frac_when_the_counter_file_matches():
     # tuning options or the upload mode change what runs: the recorded counters then do not apply
     a2 = _args(config=tj["config"], scale=tj["scale"], steps=10); a2.opt = ["k1r_min_items=1"]
     assert bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, a2, k, rows, tj["n_gpus"], 9.5)["traffic"] is None
+
+
+def test_round3_amazon_line_is_counter_based_and_self_consistent():
+    # the line of the final kernels (exact bound pruning + extraction top-k): `frac` is counter bytes / launch time / peak, the request and
+    # issue roofs stay under their ceilings, the matched-work figures are flagged as counting the unpruned candidate set
+    j = _recorded("r03_bench_amazon670k_n1.json")
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["basis"].startswith("pmc") and r["kernel"].startswith("k1q")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] <= 1.0
+    assert abs(r["achieved"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+    assert 0.0 < r["requests"]["frac"] <= 1.05 and 0.0 < r["issue"]["valu_busy_frac"] <= 1.0 and 0.0 < r["issue"]["salu_issue_frac"] <= 1.0
+    assert r["frac_matched"] > 1.0 and "UNPRUNED" in r["pruning"]
+    assert r["avg_launch_ms"] <= j["ms_per_step"]
+    assert abs(j["value"] - 490000 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-3
+    p = j["parity"]
+    assert p["timed_output_identical"] and p["timed_output_scores_bit_identical"] and p["scores_bit_identical"] and p["indices_identical"]
+    assert j["cpu_baseline"]["kind"] == "reference" and j["cpu_baseline"]["all_cores"]["cores"] >= j["cpu_baseline"]["cores"]
