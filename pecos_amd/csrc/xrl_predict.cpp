@@ -253,8 +253,21 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             // ---- exact bound pruning, tile format: score the children of the best beam parent first (K0 -> K1 -> K2 on one slot), then
             //      only the remaining slots of the queries whose top-k is not final yet (see K2Args).  Needs a combiner (a child's score
             //      is then <= its parent's) and the register top-k kernel.
-            if (m.prune && mode == 0 && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P, m.k2_legacy != 0)) {
-                const uint32_t J = 1;
+            bool pruned = m.prune && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P, m.k2_legacy != 0);
+            uint32_t J = 1;
+            if (o.stats_out) {
+                // the stats pass walks the tile format whatever kernel the timed pass runs: stage it the way THAT kernel stages the layer, so
+                // that the work it counts is the work the timed kernels evaluate (K1G: J parents first; K1Q: the parents of candidate
+                // register 0 first, nothing skipped when the whole beam fits one register)
+                const bool dense_x = X.dense != 0 || m.dense_layers >= 2;
+                if (mode == 3) J = (uint32_t)std::max<uint64_t>(1, 64 / std::max<uint64_t>(1, L.cand_bound(1)));
+                else if (m.dense_layers && k1q_regs(L.dev, beam_in[l], k[l], dense_x) != 0) {
+                    if (k1q_regs(L.dev, beam_in[l], k[l], dense_x) <= 1) pruned = false;
+                    else J = std::max<uint32_t>(1, (64u >> L.dev.d_gp_log2) / std::max<uint32_t>(1, L.dev.d_max_tiles));
+                }
+                if (J >= beam_in[l]) pruned = false;
+            } else if (mode != 0) pruned = false;
+            if (pruned) {
                 const uint64_t slots_b = (uint64_t)nrows * (beam_in[l] - J) * L.max_tiles_per_parent;
                 lw.prune_done.reserve((size_t)nb * 4); lw.prune_cnt.reserve(256);
                 lw.items_sorted.reserve(slots_max * k0_item_bytes());
