@@ -125,7 +125,10 @@ def test_round3_amazon_line_is_counter_based_and_self_consistent():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] <= 1.0
     assert abs(r["achieved"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
     assert 0.0 < r["requests"]["frac"] <= 1.05 and 0.0 < r["issue"]["valu_busy_frac"] <= 1.0 and 0.0 < r["issue"]["salu_issue_frac"] <= 1.0
-    assert r["frac_matched"] > 1.0 and "UNPRUNED" in r["pruning"]
+    # matched work = what the kernels evaluate (the stats pass stages the layers like the timed kernels): a real fraction again;
+    # only the reference-layout model (unpruned chunk streaming) is far above 1, and the line says so
+    assert 0.0 < r["frac_matched"] <= 1.0 and r["frac_ref_layout"] > 1.0 and "UNPRUNED" in r["pruning"]
+    assert sum(w["items"] for w in r["work"]) < 490000 * (1 + 2 + 10 + 10 + 10)
     assert r["avg_launch_ms"] <= j["ms_per_step"]
     assert abs(j["value"] - 490000 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-3
     p = j["parity"]
