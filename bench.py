@@ -99,7 +99,7 @@ def main():
     import xrl_synth
     from pecos_amd import XLinearModel, clib
     from pecos_amd.core import ScipyCompressedSparseAllocator, ScipyCsrF32, ScipyDrmF32
-    from pecos_amd.distributed import PackedTopk, shard_bounds, take_rows
+    from pecos_amd.distributed import GatherPipeline, shard_bounds, take_rows
 
     cfg = dict(xrl_synth.CONFIGS[args.config])
     beam = args.beam or cfg["beam"]
@@ -174,14 +174,10 @@ def main():
     # two halves of it 2 x 0.70 ms -- profiles/r03_pruning_topk.md section 3), so the shard is NOT cut to hide the gather inside its own step.
     # Every step's gathered result is complete before the closing barrier; the last step's is what the parity check reads.
     parts = 1
-    n_buf = 2 if use_dist else 1
     cstream = torch.cuda.Stream(device=dev) if use_dist else None
-    ev_done = [torch.cuda.Event() for _ in range(n_buf)]        # step's kernels queued (compute stream)
-    ev_free = [torch.cuda.Event() for _ in range(n_buf)]        # step's gather finished (gather stream): the buffer may be overwritten
     with torch.cuda.stream(tstream):
-        pks = [PackedTopk(bounds, rank, k, dev, parts=parts) for _ in range(n_buf)]
-    pk = pks[0]
-    step_no = [0]
+        pipe = GatherPipeline(bounds, rank, k, dev, n_buf=2 if use_dist else 1, compute_stream=tstream if use_dist else None,
+                              gather_stream=cstream, gather=use_dist)
 
     view = (ScipyCsrF32.init_from(Xs) if sparse else ScipyDrmF32.init_from(Xs)) if args.include_upload else None
     last_host = [None]
@@ -194,23 +190,13 @@ def main():
             last_host[0] = alloc
 
     def step_resident():
-        s = step_no[0]; step_no[0] += 1
-        i = s % n_buf
-        cur = pks[i]
         with torch.cuda.stream(tstream):
-            if use_dist and s >= n_buf:
-                tstream.wait_event(ev_free[i])             # the gather that last read this buffer (step s - 2) is done
+            cur = pipe.begin()                             # (waits for the gather that last read this buffer: step s - 2)
             b, e = cur.rows(0)
             p_idx, p_val, p_cnt, p_stride = cur.pointers(0)
             if e > b:
                 clib.predict_device_rows(h, q, beam, None, args.topk, p_idx, p_val, p_cnt, p_stride, b, e - b, stream=stream, sync=False)
-            if use_dist:
-                ev_done[i].record(tstream)
-        if use_dist:
-            with torch.cuda.stream(cstream):
-                cstream.wait_event(ev_done[i])
-                cur.gather(0)                              # under the next step's kernels
-                ev_free[i].record(cstream)
+            pipe.end()                                     # the step's all-gather: on the second stream, under the next step's kernels
 
     step = step_upload if args.include_upload else step_resident
 
@@ -252,7 +238,7 @@ def main():
             if rank == 0:
                 G = smat.vstack([pc for pc in pieces if pc is not None], format="csr")
         else:
-            pk = pks[(step_no[0] - 1) % n_buf] if step_no[0] else pks[0]     # what the LAST timed step wrote (and gathered)
+            pk = pipe.last()                               # what the LAST timed step wrote (and gathered)
             if not use_dist:
                 with torch.cuda.stream(tstream):
                     for p in range(parts):

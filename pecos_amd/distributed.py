@@ -116,6 +116,54 @@ class PackedTopk:
         return rows[:, : self.k].contiguous(), rows[:, self.k: 2 * self.k].contiguous().view(torch.float32), rows[:, 2 * self.k].contiguous()
 
 
+class GatherPipeline:
+    """Back-to-back predict steps of one rank with the all-gather of step s running under the kernels of step s+1.
+
+    ``n_buf`` PackedTopk buffers take turns: :meth:`begin` hands out the buffer of the coming step (and makes the compute stream wait
+    until the gather that last read that buffer has finished), the caller queues its kernels on the compute stream writing through
+    ``buffer.pointers()``, :meth:`end` queues the buffer's all-gather on the gather stream behind an event recorded on the compute
+    stream.  Every rank must call begin/end the same number of times (the collectives are issued in step order on every rank).
+    Why not hide the gather inside its own step by cutting the shard in halves: a rank's launches are latency-bound at a shard's size
+    (61 k Amazon-670K rows: 0.96 ms; two halves: 2 x 0.70 ms -- profiles/r03_pruning_topk.md section 3).
+
+    ``compute_stream`` / ``gather_stream``: torch.cuda.Stream objects, or None on CPU (tests under gloo): then the gather runs
+    synchronously inside :meth:`end`.  ``gather=False`` (single process without a process group) only rotates the buffers."""
+
+    def __init__(self, bounds, rank, k, device, n_buf=2, compute_stream=None, gather_stream=None, group=None, gather=True):
+        import torch
+        self.n_buf, self.group, self.gather = int(n_buf), group, bool(gather)
+        self.cs, self.gs = compute_stream, gather_stream
+        self.bufs = [PackedTopk(bounds, rank, k, device, parts=1) for _ in range(self.n_buf)]
+        on_gpu = self.cs is not None and self.gs is not None
+        self.ev_done = [torch.cuda.Event() for _ in range(self.n_buf)] if on_gpu else None   # step's kernels queued (compute stream)
+        self.ev_free = [torch.cuda.Event() for _ in range(self.n_buf)] if on_gpu else None   # step's gather finished (gather stream)
+        self.step = 0
+
+    def begin(self):
+        i = self.step % self.n_buf
+        if self.ev_free is not None and self.gather and self.step >= self.n_buf:
+            self.cs.wait_event(self.ev_free[i])              # the gather of step - n_buf has left this buffer
+        return self.bufs[i]
+
+    def end(self):
+        import torch
+        i = self.step % self.n_buf
+        if self.gather:
+            if self.ev_done is not None:
+                self.ev_done[i].record(self.cs)
+                with torch.cuda.stream(self.gs):
+                    self.gs.wait_event(self.ev_done[i])
+                    self.bufs[i].gather(0, self.group)       # under the next step's kernels
+                    self.ev_free[i].record(self.gs)
+            else:
+                self.bufs[i].gather(0, self.group)
+        self.step += 1
+
+    def last(self):
+        """the buffer of the most recent finished step (its gathered result is complete once the gather stream has been synchronised)"""
+        return self.bufs[(self.step - 1) % self.n_buf] if self.step else self.bufs[0]
+
+
 class ShardedXLinear:
     """Wraps a loaded :class:`pecos_amd.XLinearModel` for data-parallel prediction.
 

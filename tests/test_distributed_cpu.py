@@ -96,3 +96,45 @@ def test_packed_topk_uneven_and_empty_shards_two_parts():
                     pks[0].gathered[p][r].copy_(pks[r].buf[p])      # what the all-gather would deliver
             gi, gv, gc = pks[0].unpack()
             assert torch.equal(gi, idx) and torch.equal(gv.view(torch.int32), val.view(torch.int32)) and torch.equal(gc, cnt), (sizes, parts)
+
+
+def _pipeline_worker(rank, world, port, out_dir):
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    from pecos_amd.distributed import GatherPipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k = 3
+    for sizes in ([5, 2], [0, 4], [3, 3]):                      # uneven and empty shards
+        bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        n_all, lo, hi = int(bounds[-1]), int(bounds[rank]), int(bounds[rank + 1])
+        pipe = GatherPipeline(bounds, rank, k, torch.device("cpu"), n_buf=2)       # CPU: no streams, the gather runs inside end()
+        seen = []
+        for step in range(5):
+            pk = pipe.begin()
+            seen.append(id(pk))
+            # what this rank's kernels would write in this step: labels / scores that encode (step, global row, slot)
+            rows = torch.arange(lo, hi, dtype=torch.int32)[:, None]
+            idx = (step * 1000 + rows * 10 + torch.arange(k, dtype=torch.int32)[None, :]).to(torch.int32)
+            val = idx.to(torch.float32) * 0.5
+            cnt = torch.full((hi - lo,), (step % k) + 1, dtype=torch.int32)
+            pk.store(idx, val, cnt)
+            pipe.end()
+            gi, gv, gc = pipe.last().unpack()                  # every rank holds every shard's rows of THIS step
+            want = step * 1000 + torch.arange(n_all, dtype=torch.int32)[:, None] * 10 + torch.arange(k, dtype=torch.int32)[None, :]
+            assert torch.equal(gi, want.to(torch.int32)) and torch.equal(gv, want.to(torch.float32) * 0.5), (sizes, step, rank)
+            assert torch.equal(gc, torch.full((n_all,), (step % k) + 1, dtype=torch.int32))
+        assert seen[0] != seen[1] and seen[0] == seen[2] == seen[4] and seen[1] == seen[3]      # two buffers taking turns
+    open(os.path.join(out_dir, f"pipe_ok{rank}"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gather_pipeline_world2_gloo(tmp_path):
+    # bench.py's N > 1 step: two result buffers take turns, the all-gather of a step is issued when the step's kernels are queued
+    # (on the GPU: on a second stream under the next step's kernels; here synchronously) -- same collectives in the same order on every rank
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert os.path.exists(tmp_path / "pipe_ok0") and os.path.exists(tmp_path / "pipe_ok1")
