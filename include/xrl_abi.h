@@ -83,8 +83,7 @@ void c_xlinear_compile_mmap_model(const char* model_path, const char* mmap_model
 void c_xlinear_destruct_model(void* ptr);
 
 /* libpecos.cpp:147-150; attr in {depth, nr_features, nr_labels, nr_codes} (inference.hpp:2367-2379).
- * Additive attrs: nr_pred_cols (columns of predict()'s CSR), nr_bucket_layers / nr_bitmap64_layers (layers on the bucket / 64-feature-word row lookup),
- * nr_k1r_layers (layers carrying K1R tile images). */
+ * Additive attrs: nr_pred_cols (columns of predict()'s CSR), nr_bucket_layers / nr_bitmap64_layers (layers on the bucket / 64-feature-word row lookup). */
 uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr);
 
 /* libpecos.cpp:152-156 */
@@ -263,16 +262,9 @@ int xrl_predict_stats(void* model, void* queries, uint32_t beam_size, const char
  *   cum[0..n], such that every tile has <= 128 columns and fewer than `limit` entries (0: impossible).
  * xrl_debug_layout_rows: places a tile's rows (rptr[0..nrows] = packed CSR starts); with align != 0 a row that would touch
  *   more 128-byte lines than its length requires starts on the next 16-entry boundary.  Writes one packed extent
- *   `offset | (len-1) << 25` per row to ext_out (may be NULL) and returns the padded entry count of the tile.
- * xrl_debug_k1r_image: the LDS image the tile-resident kernel K1R walks, for ONE tile given as rows (ascending feature ids),
- *   rptr[0..nrows] and its {column, value} entries (row-major, columns ascending): writes the image (u32 words; layout in
- *   csrc/xrl_model.cpp) and returns its size in words, 0 when the tile does not fit cap_bytes (image may be NULL: size only). */
+ *   `offset | (len-1) << 25` per row to ext_out (may be NULL) and returns the padded entry count of the tile. */
 uint32_t xrl_debug_split_chunk(const uint64_t* cum, uint32_t n, uint64_t limit);
 uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, uint32_t* ext_out);
-uint64_t xrl_debug_k1l_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, const uint32_t* rows, const uint32_t* rptr,
-                             const uint32_t* ent_col, const float* ent_val, uint64_t cap_bytes, uint32_t* image, uint64_t image_cap_words);   /* the K1L image (all rows in entry form) */
-uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, const uint32_t* rows, const uint32_t* rptr,
-                             const uint32_t* ent_col, const float* ent_val, uint64_t cap_bytes, uint32_t* image, uint64_t image_cap_words);
 
 /* Tuning knobs (benchmark / tests only).  Results never depend on them.
  *   "k1_group"            lanes per (query, tile) item in K1: 0 = auto, else a power of two <= 64
@@ -291,14 +283,6 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *                         a combiner keeps a child's score <= max(its parent's, 0) resp. <= its parent's, and later candidates lose
  *                         ties by position), so the result is unchanged bit for bit; NaN parent scores and "noop" disable it per
  *                         query / layer; 0: every candidate of every beam parent is scored (what the reference evaluates)
- *   "k1r_min_items"       sparse X: run a tile-format layer with the tile-RESIDENT kernel K1R (tile-sorted items, the tile's
- *                         image in LDS, accumulators in registers) once a tile serves this many items on average
- *                         (0 = never, the default: profiles/r03_k1r_experiments.txt); needs the tile images (XRL_K1R=1 in the environment at load;
- *                         built only when every tile of the layer fits in LDS)
- *   "k1r_items_per_block" K1R / K1L: consecutive tile-sorted items per workgroup (default 1024)
- *   "k1l_min_items"       sparse X: run a tile-format layer with the tile-resident kernel K1L (lane == entry, accumulators in LDS, four
- *                         items per wavefront) once a tile serves this many items on average (0 = never); needs the K1L tile images
- *                         (XRL_K1L=1 in the environment at load)
  *   "overlap_min_rows"    split predicts of at least this many rows into two batches on two streams (0 = never)
  *   "host_batch_mb"       12 (default): CSR input of the pipelined host ABI is computed in batches that grow x1.6 from a third of this
  *                         many megabytes of (column id, value) pairs up to three times it (measured on Amazon-670K: 12 -> 10.4 ms per
@@ -315,9 +299,8 @@ uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, co
  *   "k1g_min_items"       dense X: a dense-format layer runs the tiled, k-ordered SGEMM K1G (tile-sorted items, weight and query
  *                         panels staged in LDS) once a parent serves this many queries on average (default 16; 0 = never: K1Q)
  *   "k1g_variant"         1: the alternative register-tile / panel shapes of K1G (A/B, tests; results identical)
- *   "k2_legacy"           1: round-1 insertion top-k kernels instead of the ballot-bisection K2 (A/B, tests)
  *   "k1_wpb", "k1_lds_pad", "k1_ablate"   debug: wavefronts per K1 workgroup, extra LDS per wavefront, phase ablation
- * Environment read at model load: XRL_K1R=1 / XRL_K1L=1 (build the tile images of the optional tile-resident kernels), XRL_LOOKUP=bitmap|bitmap64|bucket (force the row
+ * Environment read at model load: XRL_LOOKUP=bitmap|bitmap64|bucket (force the row
  * lookup structure; default per layer: bucket table if rank-bitmaps would take more than a quarter of the free HBM, else
  * 64-feature words carrying the first row's extent on sparse tiles, else 32-feature words),
  * XRL_ROW_ALIGN=0 (keep tile rows packed instead of line-aligned), XRL_MAX_TILE_ENTRIES (lower the tile splitter's

@@ -266,7 +266,7 @@ class corelib(object):
             self._lib.c_xlinear_destruct_model(c_void_p(c_model))
 
     def xlinear_get_int_attr(self, c_model, attr):
-        assert attr in {"depth", "nr_features", "nr_labels", "nr_codes", "nr_pred_cols", "nr_bucket_layers", "nr_bitmap64_layers", "nr_k1r_layers", "nr_k1l_layers", "nr_dense_layers", "device", "nr_devices"}, f"attr {attr} not implemented"
+        assert attr in {"depth", "nr_features", "nr_labels", "nr_codes", "nr_pred_cols", "nr_bucket_layers", "nr_bitmap64_layers", "nr_dense_layers", "device", "nr_devices"}, f"attr {attr} not implemented"
         v = self.clib_float32.c_xlinear_get_int_attr(c_void_p(c_model), c_char_p(attr.encode("utf-8")))
         self._check()
         return v
@@ -516,31 +516,6 @@ class corelib(object):
                        ext.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
         self._check()
         return ext & 0x1FFFFFF, (ext >> 25) + 1, total
-
-    def debug_k1l_image(self, w_rows, ncols, rows, rptr, ent_col, ent_val, cap_bytes=104 * 1024):
-        """Host-only: the LDS image of ONE tile for the tile-resident kernel K1L (every row in entry form), or None."""
-        return self.debug_k1r_image(w_rows, ncols, rows, rptr, ent_col, ent_val, cap_bytes, fn_name="xrl_debug_k1l_image")
-
-    def debug_k1r_image(self, w_rows, ncols, rows, rptr, ent_col, ent_val, cap_bytes=152 * 1024, fn_name="xrl_debug_k1r_image"):
-        """Host-only: the LDS image of ONE tile as the model compiler builds it for the tile-resident kernel K1R
-        (u32 words), or None when the tile does not fit cap_bytes."""
-        rows = np.ascontiguousarray(rows, dtype=np.uint32); rptr = np.ascontiguousarray(rptr, dtype=np.uint32)
-        ent_col = np.ascontiguousarray(ent_col, dtype=np.uint32); ent_val = np.ascontiguousarray(ent_val, dtype=np.float32)
-        fn = getattr(self.clib_float32, fn_name)
-        fn.restype = ctypes.c_uint64
-        P32 = ctypes.POINTER(ctypes.c_uint32)
-        fn.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, P32, P32, P32, ctypes.POINTER(ctypes.c_float),
-                       ctypes.c_uint64, P32, ctypes.c_uint64]
-        args = (int(w_rows), int(ncols), len(rows), rows.ctypes.data_as(P32), rptr.ctypes.data_as(P32), ent_col.ctypes.data_as(P32),
-                ent_val.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(cap_bytes))
-        words = int(fn(*args, None, 0))
-        self._check()
-        if words == 0:
-            return None
-        img = np.zeros(words, dtype=np.uint32)
-        got = int(fn(*args, img.ctypes.data_as(P32), words))
-        self._check()
-        return img if got == words else None
 
     def profile_enable(self, c_model, on=True):
         self.clib_float32.xrl_profile_enable(c_void_p(c_model), 1 if on else 0)

@@ -847,10 +847,6 @@ uint32_t c_xlinear_get_int_attr(void* ptr, const char* attr) {
             for (auto& l : m.layers) v += l->dev.wd ? 1u : 0u;
         }
         else if (!std::strcmp(attr, "nr_devices")) v = 1u + (uint32_t)m.replicas.size();   // additive: devices behind the handle (xrl_set_option "devices")
-        else if (!std::strcmp(attr, "nr_k1l_layers")) { for (auto& l : m.layers) v += l->dev.limg ? 1u : 0u; }   // additive: layers that carry K1L tile images
-        else if (!std::strcmp(attr, "nr_k1r_layers")) {      // additive: layers that carry K1R tile images
-            for (auto& l : m.layers) v += l->dev.img ? 1u : 0u;
-        }
         else fail(std::string(attr) + " is not implemented in get_int_attr.");
     });
     return v;
@@ -1225,23 +1221,6 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
     return v;
 }
 
-uint64_t xrl_debug_k1r_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, const uint32_t* rows, const uint32_t* rptr,
-                             const uint32_t* ent_col, const float* ent_val, uint64_t cap_bytes, uint32_t* image, uint64_t image_cap_words) {
-    uint64_t words = 0;
-    guarded([&] {
-        if (!rows || !rptr || !ent_col || !ent_val) fail("null argument");
-        uint32_t thr = 0;
-        words = k1r_image_words(rptr, nrows, ncols, w_rows, cap_bytes, &thr);
-        if (words == 0 || !image) return;
-        if (words > image_cap_words) fail("image buffer too small");
-        std::vector<Entry> ent(rptr[nrows]);
-        for (uint32_t e = 0; e < rptr[nrows]; ++e) ent[e] = Entry{ent_col[e], ent_val[e]};
-        std::memset(image, 0, words * 4);
-        if (!k1r_build_image(rows, rptr, ent.data(), nrows, ncols, w_rows, thr, words, image)) words = 0;
-    });
-    return words;
-}
-
 static void set_option_one(Model& m, const char* key, int64_t value) {
     if (!std::strcmp(key, "k1_group")) m.k1_group = (int)value;
     else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
@@ -1252,11 +1231,7 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     else if (!std::strcmp(key, "k1q_fuse")) m.k1q_fuse = (int)value;           // 0: one K1Q launch per dense-format layer
     else if (!std::strcmp(key, "k1g_min_items")) m.k1g_min_items = (int)value;   // dense X: queries per parent from which a dense-format layer runs the tiled SGEMM K1G (0 = never)
     else if (!std::strcmp(key, "dense_layers")) m.dense_layers = (int)value;   // 0: never run the fused dense-format kernel K1Q
-    else if (!std::strcmp(key, "k2_legacy")) m.k2_legacy = (int)value;        // debug / A-B: round-1 insertion top-k
     else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
-    else if (!std::strcmp(key, "k1r_min_items")) m.k1r_min_items = (int)value;
-    else if (!std::strcmp(key, "k1r_items_per_block")) m.k1r_items_per_block = (int)value;
-    else if (!std::strcmp(key, "k1l_min_items")) m.k1l_min_items = (int)value;
     else if (!std::strcmp(key, "prune")) m.prune = (int)value;            // 0: evaluate every candidate of every beam parent (no exact bound pruning)
     else if (!std::strcmp(key, "k1g_variant")) m.k1g_variant = (int)value;   // K1G tile-shape alternative (tuning; results identical)
     else if (!std::strcmp(key, "k1_wpb")) m.k1_wpb = (int)value;
@@ -1265,21 +1240,6 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     else fail(std::string("unknown option ") + key);
 }
 
-uint64_t xrl_debug_k1l_image(uint32_t w_rows, uint32_t ncols, uint32_t nrows, const uint32_t* rows, const uint32_t* rptr,
-                             const uint32_t* ent_col, const float* ent_val, uint64_t cap_bytes, uint32_t* image, uint64_t image_cap_words) {
-    uint64_t words = 0;
-    guarded([&] {
-        if (!rows || !rptr || !ent_col || !ent_val) fail("null argument");
-        words = k1l_image_words(rptr, nrows, ncols, w_rows, cap_bytes);
-        if (words == 0 || !image) return;
-        if (words > image_cap_words) fail("image buffer too small");
-        std::vector<Entry> ent(rptr[nrows]);
-        for (uint32_t e = 0; e < rptr[nrows]; ++e) ent[e] = Entry{ent_col[e], ent_val[e]};
-        std::memset(image, 0, words * 4);
-        k1l_build_image(rows, rptr, ent.data(), nrows, ncols, w_rows, words, image);
-    });
-    return words;
-}
 
 int xrl_set_option(void* model, const char* key, int64_t value) {
     int rc = -1;
@@ -1302,8 +1262,8 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
                 std::unique_ptr<Model> r = m.src_kind == 0 ? load_model_from_disk(m.src_path, m.weight_matrix_type) : load_mmap_model_from_disk(m.src_path);
                 r->device = dev;
                 r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->host_pipeline = m.host_pipeline; r->host_batch_mb = m.host_batch_mb; r->host_register = m.host_register;
-                r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers; r->k2_legacy = m.k2_legacy;
-                r->overlap_min_rows = m.overlap_min_rows; r->k1r_min_items = m.k1r_min_items; r->k1r_items_per_block = m.k1r_items_per_block; r->k1l_min_items = m.k1l_min_items; r->prune = m.prune;
+                r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers;
+                r->overlap_min_rows = m.overlap_min_rows; r->prune = m.prune;
                 r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;
                 m.replicas.push_back(std::move(r));
             }

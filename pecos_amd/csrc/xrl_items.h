@@ -1,4 +1,4 @@
-// The (query, beam slot, tile) work item K0 lays out and K1 / K1R / K1G consume (device code only).
+// The (query, beam slot, tile) work item K0 lays out and K1 / K1G consume (device code only).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -47,7 +47,7 @@ void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, const QueriesDe
 // bound-pruned layers, second phase: items of the beam slots >= first_rank of the queries with done[q] == 0, compact; *n_items = their number
 void launch_k0b_remaining(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* done,
                           uint32_t first_rank, void* items, uint32_t* n_items, hipStream_t s);
-bool k2_wave_path(const LayerPlan& P, bool legacy);   // the register top-k kernel serves this layer (what bound pruning needs)
+bool k2_wave_path(const LayerPlan& P);   // the register top-k kernel serves this layer (what bound pruning needs)
 size_t k0_item_bytes();
 // K1  (query, tile) inner products + bias + post-processor + combine, one item per G lanes.
 void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, const uint32_t* n_items,
@@ -57,15 +57,11 @@ void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, v
                        uint32_t* start, hipStream_t s,
                        const uint32_t* n_dev = nullptr);   // n_dev: device count of a compacted list (<= n_slots)
 uint32_t sort_max_tiles();
-// K1R (xrl_k1r.hip): tile-resident K1 (sparse queries, tile-sorted items, tile image held in LDS, accumulators in registers)
-bool k1r_eligible(const LayerDev& L);   // the layer carries tile images (every tile fits in LDS)
-void launch_k1r(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
-                float* cand, uint32_t items_per_block, hipStream_t s);
 size_t sort_hist_bytes(uint64_t n_slots, uint32_t n_tiles);
 // K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
-                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, bool legacy = false /* round-1 insertion kernels (A/B) */,
+                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s,
                     uint32_t rank_limit = 0 /* > 0: only the candidates of the first rank_limit beam slots */, uint32_t limited_cands = 0 /* their maximum number */,
                     uint32_t* done = nullptr /* out: that selection is final (exact bound, see K2Args) */, const uint32_t* skip_done = nullptr /* queries to skip */);
 // stats: sum over (query, parent) of the reference chunk's algorithmic bytes, and of candidates
@@ -97,10 +93,6 @@ void launch_k1c_csc(const LayerDev& L, const uint64_t* col_ptr, const uint32_t* 
 // [X_feat | X_emb] -> one CSR on the device (concat_model's query form, matcher.py:864-890)
 void launch_concat_csr(const uint64_t* in_ptr, const uint32_t* in_idx, const float* in_val, const float* emb, uint32_t rows,
                        uint32_t sparse_cols, uint32_t dense_cols, int normalize_emb, uint64_t* out_ptr, uint32_t* out_idx, float* out_val, hipStream_t s);
-// K1L (xrl_k1l.hip): tile-resident, lane == entry, LDS accumulators, four items per wavefront
-bool k1l_eligible(const LayerDev& L);
-void launch_k1l(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
-                float* cand, uint32_t items_per_block, hipStream_t s);
 // xrl_features.hip: the weighting half of the reference's TF-IDF vectorizer (tfidf.hpp:798-822) on a device CSR of term counts
 void launch_tfidf_weight(const uint64_t* row_ptr, const uint32_t* col_idx, const float* count, const float* idf, uint32_t rows, uint32_t cols,
                          int binary, int sublinear_tf, int norm_p, float* out, hipStream_t s);

@@ -5,7 +5,6 @@
 //   K1 k1_kernel       compute_sparse_predictions + chunk_ops + transform + combine
 //                                                           inference.hpp:925-1007, 769-839, 506-518,
 //                                                           1360-1384, PostProcessor :192-240
-//   K1R k1r_kernel     the same, tile-RESIDENT: tile image held in LDS, accumulators in registers (xrl_k1r.hip)
 //   K2 k2_topk_*       sorted_csr + reorder_prediction      inference.hpp:1223-1298, 1919-1923
 //   K3 k3_kernel       sparse_inner_products                matrix.hpp:1049-1060, 836-877
 //   K4 k4_selected     predict_on_selected_outputs (CSC)    inference.hpp:1018-1078, 1302-1358
@@ -866,17 +865,17 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
 
 size_t k2_max_k() { return (160 * 1024) / 8; }
 
-bool k2_wave_path(const LayerPlan& P, bool legacy) { return P.k <= 64 && P.cand_stride <= 64u * 32u && !legacy; }
+bool k2_wave_path(const LayerPlan& P) { return P.k <= 64 && P.cand_stride <= 64u * 32u; }
 
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
-                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, bool legacy, uint32_t rank_limit, uint32_t limited_cands,
+                    uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, uint32_t rank_limit, uint32_t limited_cands,
                     uint32_t* done, const uint32_t* skip_done) {
     if (P.nrows == 0) return;
     K2Args a;
     a.p_val = prev.val; a.rank_limit = rank_limit; a.done = done; a.skip_done = skip_done;
     a.mult = (P.pp.kind == PP_SIGMOID || P.pp.kind == PP_LP_HINGE) ? 1 : 0;
-    if ((rank_limit || done || skip_done) && !k2_wave_path(P, legacy)) fail("k2: bound pruning needs the register top-k path");
+    if ((rank_limit || done || skip_done) && !k2_wave_path(P)) fail("k2: bound pruning needs the register top-k path");
     a.chunk_col = L.chunk_col; a.perm_inv = L.perm_inv;
     a.p_idx = prev.idx; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
     a.cand_off = cand_off; a.ncand = ncand; a.cand = cand;
@@ -884,7 +883,7 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
     a.nrows = P.nrows; a.beam_in = P.beam_in; a.cand_stride = P.cand_stride; a.k = P.k; a.out_stride = out_stride;
     a.implicit_root = P.implicit_root;
     if (P.k == 0) fail("k2: only_topk / beam_size resolved to 0");
-    if (k2_wave_path(P, legacy)) {
+    if (k2_wave_path(P)) {
         // (a rank-limited selection looks at the first slots' candidates only: registers for that many)
         const uint32_t ns = ((rank_limit ? std::min(P.cand_stride, std::max(1u, limited_cands)) : P.cand_stride) + 63u) / 64u;
         const dim3 grid((P.nrows + 3u) / 4u), block(256);

@@ -136,126 +136,6 @@ uint64_t layout_tile_rows(const uint32_t* rptr, uint32_t nrows, bool align, uint
     return (cur + 15) & ~15ull;
 }
 
-// ---- tile images of the tile-RESIDENT kernel K1R (xrl_k1r.hip): one self-contained blob per tile, copied verbatim into LDS
-//      by the workgroup that owns the tile.  Row lookup = a rank-bitmap over the feature ids (one LDS read per probe); rows
-//      longer than a per-tile threshold T are held DENSE (lane == column pair, accumulators in registers), shorter ones as
-//      {column, value} pairs.  T is the smallest value in [2, kK1RMaxShort] for which the image fits `cap_bytes`.
-//      Layout (u32 words):
-//        [0] words  [1] R  [2] ncols  [3] off_rank  [4] off_rowdesc  [5] off_bias  [6] nw64  [7] T  [8] off_zero_row  [9..11] 0
-//        bits u64[nw64] | rank u16[nw64] | rowdesc u32[R] | bias f32[ncols] | pairs (8-byte aligned) | zero row | dense rows
-//        dense row: 4 words of column mask, then (npairs + 1) x {w[2p], w[2p+1]} with npairs = ceil(ncols / 2): the weight bits,
-//                   +0.0 where the row has no entry (acc + x * 0 == acc for finite x: K1R's accumulators are never -0.0) and a
-//                   zero pair at the end (where lanes past the tile's width read); the mask serves the exact path taken for
-//                   non-finite x.  The zero row (mask 0) is what a short row's dense step reads.
-//        rowdesc: dense  0x80000000 | word offset of the row's first pair
-//                 short  word offset of the row's first {column, value} | (len - 1) << 24
-// k1r_image_words: size of the image in words (a multiple of 4) and T, or 0 when no T fits.
-static inline uint64_t k1r_dense_row_words(uint32_t ncols) { return 4 + 2 * (((uint64_t)ncols + 1) / 2 + 1); }
-uint64_t k1r_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t cap_bytes, uint32_t* thr_out) {
-    if (R >= 65536 || ncols > kMaxTileCols) return 0;
-    const uint64_t nw64 = ((uint64_t)w_rows + 63) / 64;
-    uint64_t n_len[kMaxTileCols + 2] = {0};                               // rows by length
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t len = rptr[r + 1] - rptr[r];
-        if (len == 0 || len > kMaxTileCols) return 0;
-        n_len[len] += 1;
-    }
-    const uint64_t fixed = 12 + 2 * nw64 + (nw64 + 1) / 2 + R + ncols + 1 + k1r_dense_row_words(ncols);   // + alignment of the pairs, + the zero row
-    for (uint32_t thr = 2; thr <= kK1RMaxShort; ++thr) {
-        uint64_t dense_rows = 0, short_ent = 0;
-        for (uint32_t len = 1; len <= kMaxTileCols; ++len) { if (len <= thr) short_ent += n_len[len] * len; else dense_rows += n_len[len]; }
-        const uint64_t w = (fixed + dense_rows * k1r_dense_row_words(ncols) + 2 * short_ent + 3) & ~3ull;
-        if (w * 4 <= cap_bytes && w < (1ull << 22)) { if (thr_out) *thr_out = thr; return w; }
-    }
-    return 0;
-}
-
-// writes the image (words[0..words) zero-initialised by the caller; the bias words are filled in later); false when a
-// (feature, column) pair is stored twice in a row held dense (one cell cannot hold both: the layer then stays on K1)
-bool k1r_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* ent, uint32_t R, uint32_t ncols, uint32_t w_rows,
-                     uint32_t thr, uint64_t words, uint32_t* b) {
-    const uint32_t nw64 = (uint32_t)(((uint64_t)w_rows + 63) / 64);
-    const uint32_t off_bits = 12, off_rank = off_bits + 2 * nw64, off_desc = off_rank + (nw64 + 1) / 2, off_bias = off_desc + R;
-    const uint32_t drw = (uint32_t)k1r_dense_row_words(ncols);
-    uint32_t cur = (off_bias + ncols + 1u) & ~1u;                          // {column, value} pairs and dense pairs are read as 8-byte words
-    b[0] = (uint32_t)words; b[1] = R; b[2] = ncols; b[3] = off_rank; b[4] = off_desc; b[5] = off_bias; b[6] = nw64; b[7] = thr;
-    uint16_t* rank = reinterpret_cast<uint16_t*>(b + off_rank);
-    bool ok = true;
-    for (uint32_t r = 0; r < R; ++r) {                                     // rows kept in entry form first, dense rows after them
-        const uint32_t f = rows[r];
-        if (f >= w_rows) fail("layer: W row index out of range");
-        b[off_bits + 2 * (f >> 6) + ((f >> 5) & 1u)] |= 1u << (f & 31u);
-        const uint32_t len = rptr[r + 1] - rptr[r];
-        if (len > thr) continue;
-        b[off_desc + r] = cur | ((len - 1u) << 24);
-        for (uint32_t e = rptr[r]; e < rptr[r + 1]; ++e) { b[cur] = ent[e].col; std::memcpy(&b[cur + 1], &ent[e].val, 4); cur += 2; }
-    }
-    b[8] = cur + 4; cur += drw;                                            // the zero row (already zero)
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t len = rptr[r + 1] - rptr[r];
-        if (len <= thr) continue;
-        b[off_desc + r] = 0x80000000u | (cur + 4);
-        for (uint32_t e = rptr[r]; e < rptr[r + 1]; ++e) {
-            const uint32_t c = ent[e].col;
-            if (c >= ncols) fail("layer: internal error, K1R column out of range");
-            if (b[cur + (c >> 5)] & (1u << (c & 31u))) ok = false;
-            b[cur + (c >> 5)] |= 1u << (c & 31u);
-            std::memcpy(&b[cur + 4 + c], &ent[e].val, 4);
-        }
-        cur += drw;
-    }
-    uint32_t run = 0;
-    for (uint32_t w = 0; w < nw64; ++w) {
-        rank[w] = (uint16_t)run;
-        run += (uint32_t)__builtin_popcount(b[off_bits + 2 * w]) + (uint32_t)__builtin_popcount(b[off_bits + 2 * w + 1]);
-    }
-    if (cur > words) fail("layer: internal error, K1R tile image overflow");
-    return ok;
-}
-
-// ---- tile images of the tile-resident kernel K1L (xrl_k1l.hip): lane == entry, LDS accumulators -- every row stays in entry form.
-//      Layout (u32 words): [0] words [1] R [2] ncols [3] off_rank [4] off_rowext [5] off_bias [6] nw64 [7] off_entries [8..11] 0
-//        bits u64[nw64] | rank u16[nw64] | rowext u32[R] = first entry (20 bits) | (len - 1) << 20 | bias f32[ncols] |
-//        entries {column * 4, value bits}[E] (8-byte aligned, rows ascending, columns ascending inside a row) | 64 zero entries
-uint64_t k1l_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t cap_bytes) {
-    if (R >= 65536 || ncols > kMaxTileCols) return 0;
-    const uint64_t nw64 = ((uint64_t)w_rows + 63) / 64, E = rptr[R];
-    if (E >= (1u << 20)) return 0;
-    const uint64_t w = (12 + 2 * nw64 + (nw64 + 1) / 2 + R + ncols + 1 + 2 * (E + 64) + 3) & ~3ull;
-    return w * 4 <= cap_bytes ? w : 0;
-}
-void k1l_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* ent, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t words, uint32_t* b) {
-    const uint32_t nw64 = (uint32_t)(((uint64_t)w_rows + 63) / 64);
-    const uint32_t off_bits = 12, off_rank = off_bits + 2 * nw64, off_ext = off_rank + (nw64 + 1) / 2, off_bias = off_ext + R;
-    const uint32_t off_ent = (off_bias + ncols + 1u) & ~1u;
-    b[0] = (uint32_t)words; b[1] = R; b[2] = ncols; b[3] = off_rank; b[4] = off_ext; b[5] = off_bias; b[6] = nw64; b[7] = off_ent;
-    uint16_t* rank = reinterpret_cast<uint16_t*>(b + off_rank);
-    for (uint32_t r = 0; r < R; ++r) {
-        const uint32_t f = rows[r], len = rptr[r + 1] - rptr[r];
-        if (f >= w_rows) fail("layer: W row index out of range");
-        if (len == 0 || len > kMaxTileCols) fail("layer: internal error, tile row length");
-        b[off_bits + 2 * (f >> 6) + ((f >> 5) & 1u)] |= 1u << (f & 31u);
-        b[off_ext + r] = rptr[r] | ((len - 1u) << 20);
-    }
-    const uint32_t E = rptr[R];
-    for (uint32_t e = 0; e < E; ++e) { b[off_ent + 2 * e] = ent[e].col * 4u; std::memcpy(&b[off_ent + 2 * e + 1], &ent[e].val, 4); }
-    uint32_t run = 0;
-    for (uint32_t w = 0; w < nw64; ++w) {
-        rank[w] = (uint16_t)run;
-        run += (uint32_t)__builtin_popcount(b[off_bits + 2 * w]) + (uint32_t)__builtin_popcount(b[off_bits + 2 * w + 1]);
-    }
-    if ((uint64_t)off_ent + 2ull * (E + 64) > words) fail("layer: internal error, K1L tile image overflow");
-}
-
-static bool k1l_images_enabled() {   // XRL_K1L=1: build the K1L tile images (the kernel is an option, default off: profiles/r03_k1r_experiments.txt)
-    const char* e = std::getenv("XRL_K1L");
-    return e && e[0] && e[0] != '0';
-}
-static bool k1r_images_enabled() {   // XRL_K1R=1: build the K1R tile images (about the entries' size in HBM; the kernel is an option, default off)
-    const char* e = std::getenv("XRL_K1R");
-    return e && e[0] && e[0] != '0';
-}
-
 std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, float bias, uint32_t only_topk,
                                      const std::string& post_processor, const std::vector<uint32_t>* perm_inv_override,
                                      uint32_t orig_rows, bool structure_only) {
@@ -448,63 +328,6 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
         L->bk_shift = shift; L->bk_n = NBK; L->bk_levels = levels;
     }
 
-    // ---- tile images for the tile-RESIDENT kernel K1R (k1r_image_words / k1r_build_image above): built when EVERY tile fits
-    std::vector<uint32_t> img; std::vector<uint64_t> img_off;
-    if (k1r_images_enabled() && T > 0 && !structure_only && L->max_tile_cols <= kMaxTileCols) {
-        std::vector<uint32_t> t_thr(T, 0);
-        std::vector<uint64_t> t_words(T, 0);
-        std::atomic<bool> all_fit{true};
-        parallel_for(T, [&](size_t t) {
-            t_words[t] = k1r_image_words(t_rptr[t].data(), tiles[t].nrows, tiles[t].ncols, W.rows, kMaxTileImageBytes, &t_thr[t]);
-            if (t_words[t] == 0) all_fit = false;
-        });
-        if (all_fit) {   // the images cost about as much HBM as the entries themselves: never more than a quarter of what is free
-            uint64_t tot = 0; for (uint32_t t = 0; t < T; ++t) tot += t_words[t];
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && tot * 4 > free_b / 4) all_fit = false;
-        }
-        if (all_fit) {
-            img_off.assign((size_t)T + 1, 0);
-            uint64_t max_words = 0; uint32_t max_thr = 0;
-            for (uint32_t t = 0; t < T; ++t) { img_off[t + 1] = img_off[t] + t_words[t]; max_words = std::max(max_words, t_words[t]); max_thr = std::max(max_thr, t_thr[t]); }
-            img.assign(img_off[T] + 4, 0u);
-            parallel_for(T, [&](size_t t) {
-                if (!k1r_build_image(t_rows[t].data(), t_rptr[t].data(), entries.data() + tiles[t].ent_base, tiles[t].nrows, tiles[t].ncols, W.rows,
-                                     t_thr[t], t_words[t], img.data() + img_off[t])) all_fit = false;
-            });
-            L->max_tile_img = max_words * 4;
-            L->img_max_short = max_thr;
-            if (!all_fit) { img.clear(); img_off.clear(); L->max_tile_img = 0; L->img_max_short = 0; }
-        }
-    }
-
-    // ---- K1L tile images (same policy: only when every tile fits)
-    std::vector<uint32_t> limg; std::vector<uint64_t> limg_off;
-    if (k1l_images_enabled() && T > 0 && !structure_only && L->max_tile_cols <= kMaxTileCols) {
-        std::vector<uint64_t> t_words(T, 0);
-        std::atomic<bool> all_fit{true};
-        parallel_for(T, [&](size_t t) {
-            t_words[t] = k1l_image_words(t_rptr[t].data(), tiles[t].nrows, tiles[t].ncols, W.rows, kMaxK1LImageBytes);
-            if (t_words[t] == 0) all_fit = false;
-        });
-        if (all_fit) {
-            uint64_t tot = 0; for (uint32_t t = 0; t < T; ++t) tot += t_words[t];
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && tot * 4 > free_b / 4) all_fit = false;
-        }
-        if (all_fit) {
-            limg_off.assign((size_t)T + 1, 0);
-            uint64_t max_words = 0;
-            for (uint32_t t = 0; t < T; ++t) { limg_off[t + 1] = limg_off[t] + t_words[t]; max_words = std::max(max_words, t_words[t]); }
-            limg.assign(limg_off[T] + 4, 0u);
-            parallel_for(T, [&](size_t t) {
-                k1l_build_image(t_rows[t].data(), t_rptr[t].data(), entries.data() + tiles[t].ent_base, tiles[t].nrows, tiles[t].ncols, W.rows,
-                                t_words[t], limg.data() + limg_off[t]);
-            });
-            L->max_tile_limg = max_words * 4;
-        }
-    }
-
     // algorithmic bytes of the REFERENCE chunk layout per parent:
     // 8*E_p (entries) + 4*R_p (row_idx) + 4*(R_p+1) (row_ptr as u32)
     std::vector<float> chunk_alg(P, 0.f);
@@ -532,20 +355,6 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
             for (uint64_t e = cb; e < ce; ++e)
                 if (W.row_idx[e] == W.rows - 1) { volatile float pr = bias * W.val[e]; bias_prod[c] = 0.0f + pr; }
         }
-    }
-    if (!img.empty()) {
-        for (uint32_t t = 0; t < T; ++t) {
-            uint32_t* b = img.data() + img_off[t];
-            std::memcpy(b + b[5], bias_prod.data() + tiles[t].col_begin, (size_t)tiles[t].ncols * 4);
-        }
-        L->d_img.upload(img); L->d_img_off.upload(img_off);
-    }
-    if (!limg.empty()) {
-        for (uint32_t t = 0; t < T; ++t) {
-            uint32_t* b = limg.data() + limg_off[t];
-            std::memcpy(b + b[5], bias_prod.data() + tiles[t].col_begin, (size_t)tiles[t].ncols * 4);
-        }
-        L->d_limg.upload(limg); L->d_limg_off.upload(limg_off);
     }
     // ---- device layout of rows: {start, length} per row, and the entries re-laid so that NO ROW TOUCHES MORE
     //      128-BYTE LINES THAN ITS LENGTH REQUIRES (a row that would straddle an extra line starts at the next
@@ -693,7 +502,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
                       L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap +
-                      L->d_img.cap + L->d_img_off.cap + L->d_limg.cap + L->d_limg_off.cap + L->d_bucket.cap + L->d_bitmap64.cap + L->d_wd.cap + L->d_dptile.cap + L->d_dtcol.cap;
+                      L->d_bucket.cap + L->d_bitmap64.cap + L->d_wd.cap + L->d_dptile.cap + L->d_dtcol.cap;
 
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
@@ -706,11 +515,6 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     d.bias_prod = L->d_bias_prod.as<float>();
     d.n_parents = P; d.n_children = L->n_children; d.n_tiles = T; d.nwords = L->nwords; d.w_rows = W.rows;
     d.max_tiles_per_parent = L->max_tiles_per_parent; d.max_tile_cols = L->max_tile_cols;
-    d.max_tile_img = (uint32_t)std::min<uint64_t>(L->max_tile_img, 0xFFFFFFFFull);
-    d.img = img.empty() ? nullptr : L->d_img.as<uint32_t>(); d.img_off = img.empty() ? nullptr : L->d_img_off.as<uint64_t>();
-    d.img_max_short = L->img_max_short;
-    d.limg = limg.empty() ? nullptr : L->d_limg.as<uint32_t>(); d.limg_off = limg.empty() ? nullptr : L->d_limg_off.as<uint64_t>();
-    d.max_tile_limg = (uint32_t)std::min<uint64_t>(L->max_tile_limg, 0xFFFFFFFFull);
     d.bias = bias; d.has_bias = has_bias ? 1 : 0;
     d.wd = L->dense_bytes ? L->d_wd.as<uint32_t>() : nullptr; d.d_ld = d_ld; d.d_gp_log2 = d_gp_log2; d.d_max_tiles = d_max_tiles;
     d.d_ptile = L->dense_bytes ? L->d_dptile.as<uint32_t>() : nullptr; d.d_tcol = L->dense_bytes ? L->d_dtcol.as<uint32_t>() : nullptr;

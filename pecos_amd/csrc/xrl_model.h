@@ -30,9 +30,6 @@ namespace xrl {
 constexpr uint32_t kMaxTileCols = 128;       // accumulators per (query, tile) item held in LDS
 constexpr uint32_t kNoBias = 0xFFFFFFFFu;
 constexpr uint32_t kMissing = 0x7FA5A5A5u;   // dense row format: "W has no entry here" (a signalling-NaN pattern no weight file holds)
-constexpr uint64_t kMaxTileImageBytes = 152 * 1024;   // K1R: largest tile image kept in LDS (160 KiB minus the kernel's static LDS and a margin)
-constexpr uint64_t kMaxK1LImageBytes = 104 * 1024;   // K1L: the image shares the LDS with the wavefronts' unit queues and accumulators
-constexpr uint32_t kK1RMaxShort = 8;                  // K1R: rows of up to this many entries may stay in entry form (longer rows are held dense)
 
 enum PPKind : int { PP_NOOP = 0, PP_SIGMOID = 1, PP_LOG_SIGMOID = 2, PP_LP_HINGE = 3, PP_LOG_LP_HINGE = 4 };
 struct PostProc { int kind = PP_NOOP; int p = 0; };
@@ -71,12 +68,6 @@ struct LayerDev {
     const float* bias_prod;      // [n_children] fl32(bias * W[bias_row, child]) or +0.0 (no explicit entry / no bias)
     uint32_t n_parents, n_children, n_tiles, nwords, w_rows;
     uint32_t max_tiles_per_parent, max_tile_cols;
-    uint32_t max_tile_img;       // bytes of the largest K1R tile image
-    const uint32_t* img;         // K1R tile images (nullptr: some tile does not fit in LDS), image t at img + img_off[t] (u32 words); layout: xrl_k1r.h
-    const uint64_t* img_off;
-    uint32_t img_max_short;      // longest row kept in entry form by any tile of the layer (<= kK1RMaxShort)
-    // K1L tile images (xrl_k1l.hip: tile-resident, lane == entry, LDS accumulators): every row in entry form; nullptr when a tile does not fit
-    const uint32_t* limg; const uint64_t* limg_off; uint32_t max_tile_limg;
     float bias;
     int has_bias;
     // DENSE row format (K1Q, xrl_k1q.hip), nullptr when the layer is held in the tile format only:
@@ -106,8 +97,6 @@ struct Layer {
     bool reordered = false;
     uint32_t n_children = 0;               // nnz(C)
     uint32_t n_tiles = 0, nwords = 0, max_tiles_per_parent = 0, max_tile_cols = 0, max_chunk_cols = 0;
-    uint64_t max_tile_img = 0, max_tile_limg = 0;
-    uint32_t img_max_short = 0;
     uint64_t nnz = 0, total_rows = 0;
     std::vector<uint32_t> chunk_sizes_desc;  // chunk sizes sorted descending (cand stride bound)
     // predict_on_selected_outputs (inference.hpp:2507-2571): host copy of C's pattern, child -> parent,
@@ -117,7 +106,7 @@ struct Layer {
     DevBuf d_csc_ptr, d_csc_idx, d_csc_val; bool csc_ready = false;
     // device storage
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
-    DevBuf d_img, d_img_off, d_limg, d_limg_off, d_bucket, d_bitmap64;
+    DevBuf d_bucket, d_bitmap64;
     DevBuf d_wd, d_dptile, d_dtcol, d_tile_parent;   // dense row format (see LayerDev::wd)
     uint64_t dense_bytes = 0;
     uint32_t bk_shift = 0, bk_n = 0, bk_levels = 0;
@@ -175,18 +164,12 @@ struct Model {
     int64_t max_batch_rows = 0;             // 0 = auto
     int overlap_min_rows = 0;               // split a predict of at least this many rows into two half batches on two streams so that one half's
                                             // K0/K2 run under the other half's K1; 0 = never (measured on Amazon-670K: 25.9 vs 25.5 ms, no gain)
-    int k1r_min_items = 0;                  // sparse X: run a tile-format layer tile-RESIDENT (K1R: tile-sorted items, the tile's image in LDS) once a tile serves
-                                            // at least this many items on average; 0 = never (default: measured slower than K1, profiles/r03_k1r_experiments.txt)
-    int k1r_items_per_block = 1024;         // K1R / K1L: consecutive tile-sorted items per workgroup
     int prune = 1;                          // exact bound pruning (xrl_predict.cpp): 1 = a layer first scores the children of the best beam parent(s) only and
                                             // skips the rest for every query whose k-th best already reaches the next parent's score; 0 = score every candidate
-    int k1l_min_items = 0;                  // sparse X: run a tile-format layer with the tile-resident kernel K1L (lane == entry, LDS accumulators, 4 items per
-                                            // wavefront) once a tile serves at least this many items on average (0 = never)
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
     int k1q_fuse = 3;                       // consecutive dense-format layers of <= this many candidate registers (1..3) share one K1Q launch (the beam stays in LDS); 0: one launch per layer
     int k1g_min_items = 16;                 // dense X: run a dense-format layer as the tiled SGEMM K1G once a parent serves this many queries on average (0 = never)
-    int k2_legacy = 0;                      // A/B and tests: 1 = round-1 insertion top-k kernels instead of the ballot-bisection K2
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
     // multi-GPU behind the drop-in entry points (xrl_set_option "devices"): further copies of the compiled model on other devices; the
     // host-ABI predict shards the rows over this handle's device and the replicas' (xrl_abi.cpp predict_host)
@@ -203,11 +186,6 @@ struct Model {
 // host-only pieces of the model compiler (also exported for tests: xrl_debug_split_chunk / xrl_debug_layout_rows)
 uint32_t split_chunk(const uint64_t* cum, uint32_t n, uint64_t limit);
 uint64_t layout_tile_rows(const uint32_t* rptr, uint32_t nrows, bool align, uint32_t* ext);
-uint64_t k1l_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t cap_bytes);
-void k1l_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* ent, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t words, uint32_t* image);
-uint64_t k1r_image_words(const uint32_t* rptr, uint32_t R, uint32_t ncols, uint32_t w_rows, uint64_t cap_bytes, uint32_t* thr_out);
-bool k1r_build_image(const uint32_t* rows, const uint32_t* rptr, const Entry* ent, uint32_t R, uint32_t ncols, uint32_t w_rows,
-                     uint32_t thr, uint64_t words, uint32_t* image);
 
 // Build one layer from host CSC W / C (LayerData<chunked>::init, inference.hpp:1849-1883).
 // perm_inv_override / orig_rows: W and C are already in the rearranged (contiguous) child order and the

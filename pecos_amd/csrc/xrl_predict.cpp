@@ -90,8 +90,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     uint64_t slots_max = 1;
     for (size_t l = 0; l < T; ++l) slots_max = std::max<uint64_t>(slots_max, nb * beam_in[l] * m.layers[l]->max_tiles_per_parent);
     for (int ln = 0; ln < lanes; ++ln) ws.lane[ln].items.reserve(slots_max * k0_item_bytes());
-    // per layer: 0 = K1 on the items in natural order, 1 = K1 on tile-sorted items, 2 = K1R / 4 = K1L (tile-resident:
-    // tile-sorted items, tile image in LDS) -- chosen when every tile image fits and a tile serves enough items
+    // per layer: 0 = K1 on the items in natural order, 1 = K1 on tile-sorted items, 3 = K1G (dense X, tiled SGEMM over tile-sorted items)
     auto layer_mode = [&](size_t l, uint64_t rows) -> int {
         const Layer& L = *m.layers[l];
         if (L.n_tiles > sort_max_tiles()) return 0;
@@ -99,8 +98,6 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         // 3 = K1G: dense queries against a dense-format layer as a tiled SGEMM over tile-sorted items
         if (X.dense && m.dense_layers && m.k1g_min_items > 0 && !csc && k1g_cols(L.dev) != 0 && k[l] <= k2_max_k() &&
             slots / std::max<uint32_t>(1, L.n_tiles) >= (uint64_t)m.k1g_min_items) return 3;
-        if (!X.dense && X.nnz > 0 && m.k1l_min_items > 0 && k1l_eligible(L.dev) && slots / L.n_tiles >= (uint64_t)m.k1l_min_items) return 4;
-        if (!X.dense && X.nnz > 0 && m.k1r_min_items > 0 && k1r_eligible(L.dev) && slots / L.n_tiles >= (uint64_t)m.k1r_min_items) return 2;
         if (m.sort_min_tiles > 0 && L.n_tiles >= (uint32_t)m.sort_min_tiles) return 1;
         return 0;
     };
@@ -185,7 +182,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S); });
                 timed("k1c_csc", (uint32_t)l, [&] { launch_k1c_csc(L.dev, Lm.d_csc_ptr.as<uint64_t>(), Lm.d_csc_idx.as<uint32_t>(), Lm.d_csc_val.as<float>(), P, X, prev,
                                                                    lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), S); });
-                timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
+                timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S); });
                 continue;
             }
             if (!o.stats_out && layer_mode(l, nrows) == 3) {
@@ -197,7 +194,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 // ---- exact bound pruning (see the tile-format path below): the GEMM over the children of the J best beam parents first,
                 //      then a second, tile-sorted GEMM over the remaining slots of the queries whose top-k is not final yet.  J covers about
                 //      one candidate register (64 candidates), like K1Q's first stage.
-                if (m.prune && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P, m.k2_legacy != 0)) {
+                if (m.prune && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P)) {
                     const uint32_t J = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(beam_in[l] - 1, 64 / std::max<uint64_t>(1, L.cand_bound(1))));
                     const uint64_t slots_a = (uint64_t)nrows * J * L.max_tiles_per_parent, slots_b = (uint64_t)nrows * (beam_in[l] - J) * L.max_tiles_per_parent;
                     lw.prune_done.reserve((size_t)nb * 4); lw.prune_cnt.reserve(256);
@@ -206,14 +203,14 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                     timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S, J); });
                     timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, slots_a, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
                     timed("k1g_dense_x", (uint32_t)l, [&] { launch_k1g(L.dev, PA, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.x_ok.as<uint32_t>(), lw.cand.as<float>(), S); });
-                    timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, false,
+                    timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
                                                                        J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr); });
                     timed("k0b_remaining", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), J, lw.items.p,
                                                                                    lw.prune_cnt.as<uint32_t>(), S); });
                     timed("k1_sort_items_rest", (uint32_t)l, [&] { launch_sort_items(L.dev, slots_b, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S,
                                                                                      lw.prune_cnt.as<uint32_t>()); });
                     timed("k1g_dense_x_rest", (uint32_t)l, [&] { launch_k1g(L.dev, PB, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.x_ok.as<uint32_t>(), lw.cand.as<float>(), S); });
-                    timed("k2_topk_rest", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, false,
+                    timed("k2_topk_rest", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
                                                                             0, 0, nullptr, lw.prune_done.as<uint32_t>()); });
                     continue;
                 }
@@ -221,7 +218,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 const uint64_t n_slots3 = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
                 timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots3, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
                 timed("k1g_dense_x", (uint32_t)l, [&] { launch_k1g(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.x_ok.as<uint32_t>(), lw.cand.as<float>(), S); });
-                timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
+                timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S); });
                 continue;
             }
             auto runs_k1q = [&](size_t ll) { return m.dense_layers && !o.stats_out && !csc && layer_mode(ll, nrows) != 3 && k1q_regs(m.layers[ll]->dev, beam_in[ll], k[ll], X.dense != 0 || m.dense_layers >= 2) != 0; };
@@ -253,7 +250,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             // ---- exact bound pruning, tile format: score the children of the best beam parent first (K0 -> K1 -> K2 on one slot), then
             //      only the remaining slots of the queries whose top-k is not final yet (see K2Args).  Needs a combiner (a child's score
             //      is then <= its parent's) and the register top-k kernel.
-            bool pruned = m.prune && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P, m.k2_legacy != 0);
+            bool pruned = m.prune && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P);
             uint32_t J = 1;
             if (o.stats_out) {
                 // the stats pass walks the tile format whatever kernel the timed pass runs: stage it the way THAT kernel stages the layer, so
@@ -277,14 +274,14 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S, J); });
                 if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));
                 timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] { launch_k1(L.dev, PA, X, lw.items.p, nullptr, lw.cand.as<float>(), g, S); });
-                timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, false,
+                timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
                                                                    J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr); });
                 if (o.stats_out) XRL_HIP(hipMemsetAsync(lw.items_sorted.p, 0xFF, slots_b * k0_item_bytes(), S));   // the stats pass walks the whole list: unused slots read as "no tile"
                 timed("k0b_remaining", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), J, lw.items_sorted.p,
                                                                                lw.prune_cnt.as<uint32_t>(), S); });
                 timed(X.dense ? "k1_dense_rest" : "k1_sparse_rest", (uint32_t)l, [&] { launch_k1(L.dev, PB, X, lw.items_sorted.p, lw.prune_cnt.as<uint32_t>(), lw.cand.as<float>(), g, S); });
                 if (lanes == 2) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
-                timed("k2_topk_rest", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, false,
+                timed("k2_topk_rest", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
                                                                         0, 0, nullptr, lw.prune_done.as<uint32_t>()); });
                 if (o.stats_out) {
                     launch_stats(L.dev, P, X, prev, lw.ncand.as<uint32_t>(), lw.items.p, ws.stats.as<double>() + kStatsPerLayer * l, S, (uint64_t)nrows * J * L.max_tiles_per_parent);
@@ -296,16 +293,11 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             const uint64_t n_slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
             if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
             if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));   // K1 launches take turns across the lanes
-            if (mode == 4)
-                timed("k1l_sparse", (uint32_t)l, [&] { launch_k1l(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.cand.as<float>(), (uint32_t)std::max(16, m.k1r_items_per_block), S); });
-            else if (mode == 2)
-                timed("k1r_sparse", (uint32_t)l, [&] { launch_k1r(L.dev, P, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.cand.as<float>(), (uint32_t)std::max(16, m.k1r_items_per_block), S); });
-            else
-                timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] {
+            timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] {
                     launch_k1(L.dev, P, X, mode == 1 ? lw.items_sorted.p : lw.items.p, mode == 1 ? lw.sort_start.as<uint32_t>() + L.n_tiles : nullptr,
                               lw.cand.as<float>(), g, S); });
             if (lanes == 2) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
-            timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S, m.k2_legacy != 0); });
+            timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S); });
             if (o.stats_out) launch_stats(L.dev, P, X, prev, lw.ncand.as<uint32_t>(), lw.items.p, ws.stats.as<double>() + kStatsPerLayer * l, S);
         }
     }

@@ -9,9 +9,6 @@ import scipy.sparse as smat
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")
-# build the tile images of the optional tile-resident kernels (K1R, K1L) at model load, so that the parity tests can force them
-os.environ.setdefault("XRL_K1R", "1")
-os.environ.setdefault("XRL_K1L", "1")
 
 
 def pytest_configure(config):

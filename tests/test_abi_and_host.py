@@ -248,108 +248,6 @@ def test_synthetic_queries_carry_the_specified_number_of_features():
         assert np.allclose(nrm, 1.0, atol=1e-4)                  # L2-normalised rows (xrl_predict.py:143)
 
 
-def _k1r_walk(img, x_idx, x_val, w_rows):
-    """The traversal xrl_k1r.hip performs on a tile image, restated with numpy scalars: per query feature in ascending
-    order probe the rank-bitmap, then apply the row -- a dense row to every column (its weight, or the +0.0 it holds where
-    the row has no entry), a short row as the all-zero row plus its pairs in stored order -- with a separate fp32 multiply and add."""
-    R, ncols, off_rank, off_desc, off_bias, zero_row = (int(img[k]) for k in (1, 2, 3, 4, 5, 8))
-    npairs = (ncols + 1) // 2
-    rank16 = img[off_rank:].view(np.uint16)
-    assert not img[zero_row - 4:zero_row + 2 * (npairs + 1)].any()
-    acc = np.zeros(2 * (npairs + 1), dtype=np.float32)
-    for f, v in zip(x_idx, x_val):
-        if f >= w_rows:
-            continue
-        w = int(f) >> 6
-        bits = int(img[12 + 2 * w]) | (int(img[12 + 2 * w + 1]) << 32)
-        b = int(f) & 63
-        if not (bits >> b) & 1:
-            continue
-        slot = int(rank16[w]) + bin(bits & ((1 << b) - 1)).count("1")
-        assert slot < R
-        d = int(img[off_desc + slot])
-        row_at = (d & 0x3FFFFF) if d & 0x80000000 else zero_row
-        assert row_at % 2 == 0
-        row = img[row_at:row_at + 2 * (npairs + 1)].view(np.float32)
-        mask = img[row_at - 4:row_at]
-        for c in range(2 * (npairs + 1)):
-            present = c < ncols and (int(mask[c >> 5]) >> (c & 31)) & 1
-            assert present or row[c:c + 1].view(np.uint32)[0] == 0          # no entry <-> +0.0
-            acc[c] = np.float32(acc[c] + np.float32(np.float32(v) * row[c]))
-        if not d & 0x80000000:
-            n = ((d >> 24) & 7) + 1
-            base = d & 0xFFFFFF
-            assert base % 2 == 0
-            for k in range(n):
-                c = int(img[base + 2 * k]); wv = img[base + 2 * k + 1:base + 2 * k + 2].view(np.float32)[0]
-                acc[c] = np.float32(acc[c] + np.float32(np.float32(v) * wv))
-    assert not acc[ncols:].any()
-    return acc[:ncols]
-
-
-def _k1l_walk(img, x_idx, x_val, w_rows):
-    """xrl_k1l.hip's traversal of its tile image: probe, row extent, the row's entries in stored order, LDS accumulators."""
-    R, ncols, off_rank, off_ext, off_bias, off_ent = (int(img[k]) for k in (1, 2, 3, 4, 5, 7))
-    assert off_ent % 2 == 0
-    rank16 = img[off_rank:].view(np.uint16)
-    acc = np.zeros(ncols, dtype=np.float32)
-    for f, v in zip(x_idx, x_val):
-        if f >= w_rows:
-            continue
-        w = int(f) >> 6
-        bits = int(img[12 + 2 * w]) | (int(img[12 + 2 * w + 1]) << 32)
-        b = int(f) & 63
-        if not (bits >> b) & 1:
-            continue
-        slot = int(rank16[w]) + bin(bits & ((1 << b) - 1)).count("1")
-        assert slot < R
-        ext = int(img[off_ext + slot])
-        start, n = ext & 0xFFFFF, (ext >> 20) + 1
-        for e in range(start, start + n):
-            c4 = int(img[off_ent + 2 * e]); wv = img[off_ent + 2 * e + 1:off_ent + 2 * e + 2].view(np.float32)[0]
-            assert c4 % 4 == 0 and c4 // 4 < ncols
-            acc[c4 // 4] = np.float32(acc[c4 // 4] + np.float32(np.float32(v) * wv))
-    return acc
-
-
-@pytest.mark.parametrize("seed", range(6))
-def test_k1r_tile_image_walk(seed):
-    # the LDS image of the tile-resident kernel, built by the model compiler's host code, walked the way the kernel walks it
-    from pecos_amd import clib
-    rng = np.random.default_rng(seed)
-    w_rows = int(rng.choice([70, 700, 5000]))
-    ncols = int(rng.choice([1, 7, 64, 65, 82, 128]))
-    dens = float(rng.choice([0.02, 0.2, 0.7])) if w_rows * ncols < 50000 else 0.01   # (a tile must fit 152 KiB)
-    M = (rng.random((w_rows, ncols)) < dens * rng.random((w_rows, 1)) ** 2)
-    M[rng.integers(0, w_rows)] = True                                   # one full row
-    vals = rng.standard_normal((w_rows, ncols)).astype(np.float32)
-    vals[rng.random((w_rows, ncols)) < 0.05] = 0.0                      # explicit zeros are entries
-    rows = np.nonzero(M.any(axis=1))[0].astype(np.uint32)
-    rptr = np.concatenate([[0], np.cumsum(M[rows].sum(axis=1))]).astype(np.uint32)
-    ent_col = np.concatenate([np.nonzero(M[r])[0] for r in rows]).astype(np.uint32)
-    ent_val = np.concatenate([vals[r][M[r]] for r in rows]).astype(np.float32)
-    img = clib.debug_k1r_image(w_rows, ncols, rows, rptr, ent_col, ent_val)
-    assert img is not None and len(img) % 4 == 0 and img[0] == len(img) and img[1] == len(rows) and img[2] == ncols
-    assert 2 <= img[7] <= 8
-    # a tile that cannot fit is refused, not truncated
-    assert clib.debug_k1r_image(w_rows, ncols, rows, rptr, ent_col, ent_val, cap_bytes=64) is None
-    limg = clib.debug_k1l_image(w_rows, ncols, rows, rptr, ent_col, ent_val, cap_bytes=512 * 1024)    # the same tile in K1L's form (every row as entries)
-    assert limg is not None and limg[0] == len(limg) and limg[1] == len(rows) and not limg[int(limg[7]) + 2 * len(ent_col):int(limg[7]) + 2 * len(ent_col) + 128].any()
-    for _ in range(5):
-        nx = int(rng.integers(0, min(w_rows, 200)))
-        x_idx = np.sort(rng.choice(w_rows + 5, size=nx, replace=False))
-        x_val = rng.standard_normal(nx).astype(np.float32)
-        want = np.zeros(ncols, dtype=np.float32)
-        for f, v in zip(x_idx, x_val):
-            if f < w_rows:
-                for c in np.nonzero(M[f])[0]:
-                    want[c] = np.float32(want[c] + np.float32(np.float32(v) * vals[f, c]))
-        got = _k1r_walk(img, x_idx, x_val, w_rows)
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-        if limg is not None:
-            assert np.array_equal(_k1l_walk(limg, x_idx, x_val, w_rows).view(np.uint32), want.view(np.uint32))
-
-
 def test_concat_features_vs_reference_goldens(manifest):
     # pecos_amd.features.concat_features against outputs of the reference's own TransformerMatcher.concat_features
     # (pecos/xmc/xtransformer/matcher.py:864-890; tests/golden/make_golden_r03.py): same pattern, same order, same bits

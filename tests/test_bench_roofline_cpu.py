@@ -112,7 +112,7 @@ def test_counter_based_frac_when_the_counter_file_matches():
     if ent.get("valu_insts_per_launch"):
         assert 0.0 < r["issue"]["valu_busy_frac"] < 2.0
     # tuning options or the upload mode change what runs: the recorded counters then do not apply
-    a2 = _args(config=tj["config"], scale=tj["scale"], steps=10); a2.opt = ["k1r_min_items=1"]
+    a2 = _args(config=tj["config"], scale=tj["scale"], steps=10); a2.opt = ["sort_min_tiles=1"]
     assert bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, a2, k, rows, tj["n_gpus"], 9.5)["traffic"] is None
 
 

@@ -100,16 +100,12 @@ def test_fuzz(seed, tmp_path, oracle_mod):
             kw["post_processor"] = str(pp)
         # layers that carry the dense row format: fused kernel K1Q (when the beam's candidates fit its registers) / tile-format kernels
         clib.set_option(m.model.model_chain, "dense_layers", (2, 0, 1, 0)[trial])
-        clib.set_option(m.model.model_chain, "k2_legacy", 1 if trial == 3 else 0)
         clib.set_option(m.model.model_chain, "k1g_min_items", 1 if trial == 0 else 16)   # dense X: tiled SGEMM forced / by batch size
         clib.set_option(m.model.model_chain, "k1g_variant", int(rng.integers(0, 2)))      # its alternative tile shapes
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
-        # tile-resident kernel (K1R): off / forced for every layer whose tile images fit in LDS, short and long item runs
-        clib.set_option(m.model.model_chain, "k1r_min_items", int(rng.choice([0, 1, 1])))
-        clib.set_option(m.model.model_chain, "k1r_items_per_block", int(rng.choice([16, 100, 1024])))
-        clib.set_option(m.model.model_chain, "k1l_min_items", int(rng.choice([0, 0, 1])))
+        clib.set_option(m.model.model_chain, "sort_min_tiles", int(rng.choice([0, 1, 1])))       # tile-format layers: items in natural order / tile-sorted
         os.environ["XRL_K1Q_FUSE01"] = str(int(rng.choice([0, 1, 1])))                          # levels 0 + 1 in one feature walk (K1Q) / separately
-        clib.set_option(m.model.model_chain, "prune", int(rng.choice([0, 1, 1])))                  # exact bound pruning on / off: same bits          # K1L takes precedence over K1R when both are forced
+        clib.set_option(m.model.model_chain, "prune", int(rng.choice([0, 1, 1])))                  # exact bound pruning on / off: same bits
         # one or two row batches in flight (two streams), whole or ragged batches
         clib.set_option(m.model.model_chain, "overlap_min_rows", int(rng.choice([0, 2])))
         clib.set_option(m.model.model_chain, "max_batch_rows", int(rng.choice([0, 0, 7, 32])))
@@ -119,12 +115,10 @@ def test_fuzz(seed, tmp_path, oracle_mod):
             assert a.shape == b.shape
             assert_same_topk(a, b, exact_scores=True, what=f"seed={seed} sizes={sizes} D={D} bias={bias} {kw} dense={not smat.issparse(Xq)}")
     clib.set_option(m.model.model_chain, "k1_group", 0)
-    clib.set_option(m.model.model_chain, "k2_legacy", 0)
     clib.set_option(m.model.model_chain, "k1g_min_items", 16)
     clib.set_option(m.model.model_chain, "k1g_variant", 0)
     clib.set_option(m.model.model_chain, "dense_layers", 1)
-    clib.set_option(m.model.model_chain, "k1r_min_items", 1)
-    clib.set_option(m.model.model_chain, "k1l_min_items", 0)
+    clib.set_option(m.model.model_chain, "sort_min_tiles", 0)
     clib.set_option(m.model.model_chain, "prune", 1)
     os.environ.pop("XRL_K1Q_FUSE01", None)
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)

@@ -78,28 +78,14 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
         clib.set_option(m.model.model_chain, "dense_layers", 0)     # tile format: K0 -> K1 -> K2
         for g in (0, 1, 2, 8, 64):
             clib.set_option(m.model.model_chain, "k1_group", g)
-            clib.set_option(m.model.model_chain, "k1r_min_items", 0)
             P = m.predict(X, **c["kwargs"])
             assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} G={g}")
-        clib.set_option(m.model.model_chain, "k2_legacy", 1)        # round-1 insertion top-k kernels
-        P = m.predict(X, **c["kwargs"])
-        assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} legacy K2")
-        clib.set_option(m.model.model_chain, "k2_legacy", 0)
         clib.set_option(m.model.model_chain, "k1_group", 0)
-        # tile-resident kernel (K1R) forced on every layer whose tile images fit in LDS; one / several workgroups per tile
-        for ipb in (16, 1024):
-            clib.set_option(m.model.model_chain, "k1r_min_items", 1)
-            clib.set_option(m.model.model_chain, "k1r_items_per_block", ipb)
-            P = m.predict(X, **c["kwargs"])
-            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1R items_per_block={ipb}")
-        clib.set_option(m.model.model_chain, "k1r_min_items", 0)
-        # tile-resident kernel K1L (lane == entry, LDS accumulators, four items per wavefront), short and long item runs
-        for ipb in (16, 1024):
-            clib.set_option(m.model.model_chain, "k1l_min_items", 1)
-            clib.set_option(m.model.model_chain, "k1r_items_per_block", ipb)
-            P = m.predict(X, **c["kwargs"])
-            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} K1L items_per_block={ipb}")
-        clib.set_option(m.model.model_chain, "k1l_min_items", 0)
+        # tile-sorted items (counting sort by tile; both phases of a pruned layer) instead of the natural order
+        clib.set_option(m.model.model_chain, "sort_min_tiles", 1)
+        P = m.predict(X, **c["kwargs"])
+        assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} tile-sorted items")
+        clib.set_option(m.model.model_chain, "sort_min_tiles", 0)
         clib.set_option(m.model.model_chain, "dense_layers", 1)
 
 
@@ -160,26 +146,12 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
                          exact_scores=True, what=f"{name} two lanes, max_batch_rows={rows}")
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)
     clib.set_option(m.model.model_chain, "overlap_min_rows", 0)
-    for k1r in (0, 1):   # K1 everywhere / tile-resident K1R wherever the tile images fit in LDS
-        clib.set_option(m.model.model_chain, "k1r_min_items", k1r)
+    for srt in (0, 1):   # items in natural order / tile-sorted
+        clib.set_option(m.model.model_chain, "sort_min_tiles", srt)
         for pp in (None, "sigmoid"):
             kw = dict(beam_size=cfg["beam"], only_topk=10, **({"post_processor": pp} if pp else {}))
-            assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} k1r_min_items={k1r} {pp}")
-    for pp in (None, "sigmoid"):
-        clib.set_option(m.model.model_chain, "k1l_min_items", 1)
-        kw = dict(beam_size=cfg["beam"], only_topk=10, **({"post_processor": pp} if pp else {}))
-        assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} K1L {pp}")
-        clib.set_option(m.model.model_chain, "k1l_min_items", 0)
-    # the forced run really went through the tile-resident kernel
-    clib.set_option(m.model.model_chain, "k1r_min_items", 1)
-    clib.profile_enable(m.model.model_chain, True); clib.profile_reset(m.model.model_chain)
-    m.predict(X, beam_size=cfg["beam"], only_topk=10)
-    names = {r["name"] for r in clib.profile_get(m.model.model_chain)}
-    clib.profile_enable(m.model.model_chain, False)
-    assert ("k1r_sparse" in names) == (clib.xlinear_get_int_attr(m.model.model_chain, "nr_k1r_layers") > 0), names
-    if name != "wiki10-31k":
-        assert "k1r_sparse" in names, names
-    clib.set_option(m.model.model_chain, "k1r_min_items", 0)
+            assert_same_topk(m.predict(X, **kw), ref.predict(X, **kw), exact_scores=EXACT_PP(pp), what=f"{name} sort_min_tiles={srt} {pp}")
+    clib.set_option(m.model.model_chain, "sort_min_tiles", 0)
     clib.set_option(m.model.model_chain, "dense_layers", 1)
     assert_same_topk(m.predict(X, beam_size=5, only_topk=3, max_pred_chunk=37), ref.predict(X, beam_size=5, only_topk=3),
                      exact_scores=True, what="max_pred_chunk")
@@ -590,10 +562,10 @@ def test_hash_chunked_sparse_queries_bit_exact(manifest, XLM, clib, oracle_mod, 
         X = load_X(os.path.join(GOLDEN, "synth", c["model"] + "__X.npz"))
         G = load_raw_csr(os.path.join(GOLDEN, "preds", c["pred"]))
         ex = EXACT_PP(c["kwargs"].get("post_processor"))
-        for dl, k1r, k1l in ((1, 0, 0), (2, 0, 0), (0, 0, 0), (0, 1, 0), (0, 0, 1)):
-            clib.set_option(h, "dense_layers", dl); clib.set_option(h, "k1r_min_items", k1r); clib.set_option(h, "k1l_min_items", k1l)
-            assert_same_topk(m.predict(X, **c["kwargs"]), G, exact_scores=ex, what=f"HASH_CHUNKED {c} dense_layers={dl} k1r={k1r} k1l={k1l}")
-        clib.set_option(h, "dense_layers", 1); clib.set_option(h, "k1r_min_items", 0); clib.set_option(h, "k1l_min_items", 0)
+        for dl, srt in ((1, 0), (2, 0), (0, 0), (0, 1)):
+            clib.set_option(h, "dense_layers", dl); clib.set_option(h, "sort_min_tiles", srt)
+            assert_same_topk(m.predict(X, **c["kwargs"]), G, exact_scores=ex, what=f"HASH_CHUNKED {c} dense_layers={dl} sort_min_tiles={srt}")
+        clib.set_option(h, "dense_layers", 1); clib.set_option(h, "sort_min_tiles", 0)
     if oracle_mod.ref_available():
         import xrl_synth
         folder = str(tmp_path / "m")
@@ -675,7 +647,7 @@ def test_headline_config_full_size_all_rows_vs_reference(XLM, clib, oracle_mod):
     # D = 135 000, L = 670 091, tree [2, 32, 512, 8192, 670091], beam 10, top-k 10 -- EVERY row against the compiled reference
     # (test/pecos/xmc/xlinear/test_xlinear.py:106-245 in spirit): label ids, order and fp32 score bits.  The default policy runs the
     # kernel instantiations bench.py times (fused k1q_kernel<3,0,false,true> over levels 0-3, leaf k1_kernel<32,3,0,false,2>);
-    # dense_layers=0 sends every level through the tile-format kernels, k1r_min_items=1 the leaf through the tile-resident kernel.
+    # dense_layers=0 sends every level through the tile-format kernels.
     if not oracle_mod.ref_available():
         pytest.skip("oracle/_ref (the compiled reference) is not built: 490 k rows are out of reach of the single-threaded restatement")
     folder, ks, cfg = _bench_workload("amazon-670k")
@@ -696,14 +668,6 @@ def test_headline_config_full_size_all_rows_vs_reference(XLM, clib, oracle_mod):
     clib.set_option(h, "prune", 0)                    # every candidate of every beam parent scored (no exact bound pruning)
     assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, prune=0")
     clib.set_option(h, "prune", 1)
-    if clib.xlinear_get_int_attr(h, "nr_k1r_layers") > 0:
-        clib.set_option(h, "k1r_min_items", 1)
-        assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, tile-resident leaf (K1R)")
-        clib.set_option(h, "k1r_min_items", 0)
-    if clib.xlinear_get_int_attr(h, "nr_k1l_layers") > 0:
-        clib.set_option(h, "k1l_min_items", 1)
-        assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, tile-resident leaf (K1L)")
-        clib.set_option(h, "k1l_min_items", 0)
 
 
 @pytest.mark.timeout(2400)
