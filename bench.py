@@ -57,6 +57,39 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def csrc_sha16():
+    """First 16 hex digits of the SHA-256 over the kernel / host sources the library is built from (file names and contents, sorted):
+    profiles/pmc_traffic.json records it with every counter set, and a line only quotes counters taken on the SAME sources."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(REPO, "pecos_amd", "csrc")
+    for name in sorted(os.listdir(root)):
+        path = os.path.join(root, name)
+        if os.path.isfile(path) and name.rsplit(".", 1)[-1] in ("hip", "cpp", "h") or name == "Makefile":
+            h.update(name.encode()); h.update(b"\0"); h.update(open(path, "rb").read()); h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
+def pmc_key(config, scale, opts):
+    """Key of a counter set in profiles/pmc_traffic.json: workload, scale and the library options the run was made with."""
+    return f"{config}@{scale}" + ("+" + ",".join(sorted(o.replace(" ", "") for o in opts)) if opts else "")
+
+
+def pmc_entry(config, scale, opts, world):
+    """(entry, why-not) -- the counter set recorded for exactly this configuration on exactly these sources, or None and the reason."""
+    tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tfile):
+        return None, "no profiles/pmc_traffic.json"
+    ent = json.load(open(tfile)).get("entries", {}).get(pmc_key(config, scale, opts))
+    if ent is None:
+        return None, f"no counter set recorded for {pmc_key(config, scale, opts)}"
+    if ent.get("n_gpus") != world:
+        return None, f"counter set recorded at n_gpus={ent.get('n_gpus')}"
+    if ent.get("csrc_sha16") != csrc_sha16():
+        return None, f"counter set is STALE: taken on sources {ent.get('csrc_sha16')}, this tree is {csrc_sha16()}"
+    return ent, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,7 +298,11 @@ def main():
                        dense_format_layers=[l for l in range(depth) if linfo[l]["dense"]])
         out = dict(metric=baseline_metric(), value=round(value, 1), unit="queries/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
-                   scaling="strong", vs_baseline=None, dtype="f32", data="synthetic", config=cfg_out, roofline=roof)
+                   scaling="strong", vs_baseline=None, dtype="f32", data="synthetic", config=cfg_out, roofline=roof,
+                   value_definition=("PCIe-INCLUSIVE: every rank times the drop-in entry point c_xlinear_predict_* on its shard (pageable host X in, H2D, kernels, "
+                                     "D2H, allocator callback, host CSR out) -- SURVEY.md 8(d)'s metric" if args.include_upload else
+                                     "DEVICE-RESIDENT: queries/s with X already in HBM when the timed region starts and the top-k left in HBM (the bench contract's "
+                                     "`value`); SURVEY.md 8(d)'s metric -- timed around the C-ABI call incl. H2D of X and D2H of the results -- is `value_host_abi`"))
 
         if args.include_upload:
             cfg_out["mode"] = "include-upload: every rank times c_xlinear_predict_* on its shard (pageable host X in, H2D, kernels, D2H, host CSR out); no gather"
@@ -331,6 +368,8 @@ def main():
 def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_step):
     import scipy.sparse as smat
     sparse = smat.issparse(Xs)
+    if args.include_upload:   # the entry point cuts a call into row batches: a family's launches of one step count as ONE launch (time summed over the step)
+        prof = [dict(r, launches=min(r["launches"], max(1, args.steps))) for r in prof]
     st = clib.predict_stats(h, q, beam, None, args.topk) if (rows and not args.no_stats) else []
     nnz = float(Xs.nnz) if sparse else float(Xs.size)
     x_bytes_q = 8.0 * nnz if sparse else 4.0 * nnz               # the query rows read once
@@ -403,33 +442,44 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
     matched_rate = fam[dom]["matched"] / max(1, fam[dom]["launches"]) / (avg_ms * 1e-3) / 1e9
     cache_resident = fam[dom]["matched"] > fam[dom]["bytes"] * 1.0001
     traffic, tsrc, l2, requests, issue = None, None, None, None, None
-    tfile = os.path.join(REPO, "profiles", "pmc_traffic.json")     # written from separate rocprofv3 --pmc passes (scripts/pmc_traffic.py)
-    pmc_family = "k1q_dense" if dom.startswith("k1q") else dom
-    if os.path.exists(tfile):
-        tj = json.load(open(tfile))
-        ent = tj.get("kernels", {}).get(pmc_family)
-        if tj.get("config") == args.config and tj.get("scale") == args.scale and tj.get("n_gpus") == world and ent and not args.opt and not args.include_upload:
-            traffic, tsrc = ent.get("hbm_bytes_per_launch"), tj.get("source")
-            if ent.get("l2_read_req_per_launch"):
-                req = ent["l2_read_req_per_launch"]
-                l2b = req * 64.0 / (avg_ms * 1e-3) / 1e9
-                l2 = dict(bound="l2", read_requests_per_launch=req, request_bytes=64, achieved=round(l2b, 1), peak=L2_PEAK_GBPS, unit="GB/s",
-                          frac=round(l2b / L2_PEAK_GBPS, 4), requests_per_s_G=round(req / (avg_ms * 1e-3) / 1e9, 1),
-                          note="TCP_TCC_READ_REQ (L1->L2 read requests) x 64 B / launch time; the gathers of this kernel use 8-16 B of every request")
-            if ent.get("fabric_read_req_per_launch"):
-                fr = ent["fabric_read_req_per_launch"]
-                rate = fr / (avg_ms * 1e-3) / 1e9
-                requests = dict(fabric_read_req_per_launch=fr, fabric_req_per_s_G=round(rate, 1), ceiling_G=FABRIC_REQ_CEILING_G, frac=round(rate / FABRIC_REQ_CEILING_G, 3),
-                                note="L2 misses (TCC_MISS) / launch time against the fabric read-request ceiling measured with 8-byte gathers "
-                                     "(profiles/r02_calib_fetch.md: 51 G/s from HBM, 59 G/s from the Infinity Cache; 57 used)")
-            if ent.get("valu_insts_per_launch"):
-                cu_cycles = avg_ms * 1e-3 * SHADER_CLOCK_HZ
-                issue = dict(valu_insts_per_launch=ent["valu_insts_per_launch"], salu_insts_per_launch=ent.get("salu_insts_per_launch"),
-                             valu_busy_frac=round(ent.get("valu_active_quad_cycles_per_launch", 0.0) * 4.0 / (cu_cycles * N_SIMD), 3),
-                             salu_issue_frac=round((ent.get("salu_insts_per_launch") or 0.0) / (cu_cycles * N_CU), 3),
-                             note="SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (launch time x 2.4 GHz x 1024 SIMDs); SQ_INSTS_SALU / (launch time x 2.4 GHz x 256 CUs: "
-                                  "one scalar issue per CU per cycle).  A wavefront VALU instruction occupies its SIMD for 4 cycles, so instruction COUNT per "
-                                  "query is what these kernels run on (profiles/r03_k1r_experiments.txt)")
+    # counters: separate rocprofv3 --pmc passes over this same command on these same sources (scripts/gpu_round.sh pmc -> scripts/pmc_traffic.py).
+    # A counter set holds per-STEP sums per KERNEL (k1q_kernel, k1_kernel, ...): every bench family that kernel serves -- several layers, both
+    # phases of a pruned layer -- is priced together: counter bytes of the kernel per step / its GPU time per step.  Per launch = / the
+    # family's launches per step.
+    def pmc_family(name):
+        return ("k1q_dense" if name.startswith("k1q") else "k1g_dense_x" if name.startswith("k1g") else "k1_sort_items" if name.startswith("k1_sort") else
+                "k1_sparse" if name.startswith("k1_") else "k2_topk" if name.startswith("k2") else name)
+    pfam = pmc_family(dom)
+    pf_ms_step = sum(v["ms"] for n_, v in fam.items() if pmc_family(n_) == pfam) / max(1, args.steps)
+    pf_launches_step = max(1.0, sum(v["launches"] for n_, v in fam.items() if pmc_family(n_) == pfam) / max(1, args.steps))
+    tj, why_no_counters = (None, "the upload mode times per-batch launches") if args.include_upload else pmc_entry(args.config, args.scale, args.opt, world)
+    ent = tj.get("kernels", {}).get(pfam) if tj else None
+    if tj and not ent:
+        why_no_counters = f"the counter set has no kernel family {pfam}"
+    pmc_avg_ms = pf_ms_step / pf_launches_step
+    if ent:
+        traffic, tsrc = ent.get("hbm_bytes_per_step") / pf_launches_step, tj.get("source")
+        if ent.get("l2_read_req_per_step"):
+            req = ent["l2_read_req_per_step"]
+            l2b = req * 64.0 / (pf_ms_step * 1e-3) / 1e9
+            l2 = dict(bound="l2", read_requests_per_step=req, request_bytes=64, achieved=round(l2b, 1), peak=L2_PEAK_GBPS, unit="GB/s",
+                      frac=round(l2b / L2_PEAK_GBPS, 4), requests_per_s_G=round(req / (pf_ms_step * 1e-3) / 1e9, 1),
+                      hit_rate=round(ent["l2_hit_per_step"] / max(1.0, ent["l2_hit_per_step"] + (ent.get("fabric_read_req_per_step") or 0.0)), 3) if ent.get("l2_hit_per_step") else None,
+                      note="TCP_TCC_READ_REQ (L1->L2 read requests) x 64 B / kernel time; the gathers of this kernel use 8-64 B of every request")
+        if ent.get("fabric_read_req_per_step"):
+            fr = ent["fabric_read_req_per_step"]
+            rate = fr / (pf_ms_step * 1e-3) / 1e9
+            requests = dict(fabric_read_req_per_step=fr, fabric_req_per_s_G=round(rate, 1), ceiling_G=FABRIC_REQ_CEILING_G, frac=round(rate / FABRIC_REQ_CEILING_G, 3),
+                            note="L2 misses (TCC_MISS) / kernel time against the fabric read-request ceiling measured with 8-byte gathers "
+                                 "(profiles/r02_calib_fetch.md: 51 G/s from HBM, 59 G/s from the Infinity Cache; 57 used)")
+        if ent.get("valu_insts_per_step"):
+            cu_cycles = pf_ms_step * 1e-3 * SHADER_CLOCK_HZ
+            issue = dict(valu_insts_per_step=ent["valu_insts_per_step"], salu_insts_per_step=ent.get("salu_insts_per_step"),
+                         valu_busy_frac=round(ent.get("valu_active_quad_cycles_per_step", 0.0) * 4.0 / (cu_cycles * N_SIMD), 3),
+                         salu_issue_frac=round((ent.get("salu_insts_per_step") or 0.0) / (cu_cycles * N_CU), 3),
+                         note="SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (kernel time x 2.4 GHz x 1024 SIMDs); SQ_INSTS_SALU / (kernel time x 2.4 GHz x 256 CUs: "
+                              "one scalar issue per CU per cycle).  A wavefront VALU instruction occupies its SIMD for 4 cycles, so instruction COUNT per "
+                              "query is what these kernels run on")
     if l2 is None and cache_resident:
         l2 = dict(bound="l2", achieved=round(matched_rate, 1), peak=L2_PEAK_GBPS, unit="GB/s", frac=round(matched_rate / L2_PEAK_GBPS, 4),
                   note="the structure this kernel gathers from fits the on-chip cache: matched-work bytes (no inter-query reuse) / launch time against the L2 peak")
@@ -448,12 +498,13 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
                     work=[dict(layer=l, **{kk: st[l][kk] for kk in ("items", "probes", "hit_rows", "hit_entries", "candidates")}) for l in range(len(st))])
     ref_layout = (sum(s_["ref_chunk_bytes"] + 4.0 * s_["candidates"] for s_ in st) + x_bytes_q) if st else None
     if traffic is not None:
-        ach_c = traffic / (avg_ms * 1e-3) / 1e9
-        head = dict(achieved=round(ach_c, 1), frac=round(ach_c / HBM_PEAK_GBPS, 4),
-                    basis="pmc: rocprofv3 FETCH_SIZE + WRITE_SIZE per launch (profiles/pmc_traffic.json) / hipEvent launch time measured in this run")
+        ach_c = traffic / (pmc_avg_ms * 1e-3) / 1e9
+        head = dict(achieved=round(ach_c, 1), frac=round(ach_c / HBM_PEAK_GBPS, 4), pmc_kernel=pfam, pmc_kernel_ms_per_step=round(pf_ms_step, 4),
+                    basis="pmc: rocprofv3 FETCH_SIZE + WRITE_SIZE of the kernel per step (profiles/pmc_traffic.json, same sources: csrc " + csrc_sha16() +
+                          ") / its hipEvent time per step measured in this run")
     else:
         head = dict(achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBPS, 4),
-                    basis="matched-work bytes (no counter file for this configuration / option set): NOT an HBM fraction, see frac_matched")
+                    basis=f"matched-work bytes ({why_no_counters}): NOT an HBM fraction, see frac_matched")
     return dict(bound="hbm", kernel=dom, **head, peak=HBM_PEAK_GBPS, unit="GB/s",
                 traffic=traffic, traffic_source=tsrc,
                 frac_matched=round(matched_rate / HBM_PEAK_GBPS, 4), matched_gbps=round(matched_rate, 1),

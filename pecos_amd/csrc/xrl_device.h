@@ -18,6 +18,20 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Guard of the exact bound pruning (xrl_predict.cpp): "a child's score is at most its parent's bound" fails only when a child's
+// score is NaN, and a NaN needs a non-finite operand or an intermediate that overflows (inf - inf, 0 * inf).  A query whose
+// largest |x| is finite and small enough that no partial sum of (features + bias) products can reach the fp32 range keeps
+// every accumulator finite on every layer; all others are never pruned (they take the same path as prune = 0).
+//   xmax_bits: max over the query's values of (bits & 0x7FFFFFFF) -- a NaN / inf compares above every finite value
+//   wmax:      max over the layers of |weight| * max(1, |bias|), +inf when a weight is not finite
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool prune_guard_ok(uint32_t xmax_bits, uint32_t n_feat, float wmax) {
+    if (xmax_bits >= 0x7F800000u) return false;
+    const float b = fmaxf(__uint_as_float(xmax_bits), 1.0f) * wmax * (float)(n_feat + 2u);
+    return b < 1.0e37f;                                             // (NaN / inf compare false)
+}
+
+// ---------------------------------------------------------------------------------------------
 // post-processor (inference.hpp:192-240).  The reference lambdas take `const float&`:
 //   sigmoid / log-sigmoid evaluate std::exp(float) (= expf) and continue in double;
 //   l{p}-hinge keeps z in a FLOAT, then pow/exp in double.  Results are cast to float (:1369).

@@ -20,7 +20,7 @@
 //
 // Layers whose dense matrix holds kMissing cells (W has no entry there: sparse weight columns under dense X): with FINITE x a
 // missing weight is staged as +0.0 (the product is +-0 and leaves every reachable accumulator unchanged), so the same 2-op loop
-// serves them; a workgroup that holds a query with an inf / NaN (xfinite_kernel flags them once per predict) takes the exact
+// serves them; a workgroup that holds a query with an inf / NaN (xguard_kernel flags them once per predict) takes the exact
 // loop, which skips those cells like the reference's row walk does (select on the bit pattern, 4 lane-ops).
 #include <hip/hip_runtime.h>
 
@@ -63,19 +63,24 @@ struct K1GArgs {
 // which the model compiler computes exactly like that, so even a -0.0 product gives +0.0; and x*w + (-x*w) rounds to +0.0) --
 // so K1G's inner loop needs no select; rows with an inf / NaN take the exact loop.  (A weight whose bits equal kMissing keeps
 // the whole layer out of the dense format at load, xrl_model.cpp.)
-__global__ void __launch_bounds__(256) xfinite_kernel(const float* __restrict__ x, uint32_t rows, uint32_t cols, uint32_t row0, uint32_t* __restrict__ ok) {
+// The same flag doubles as the guard of the exact bound pruning (prune_guard_ok, xrl_device.h): 1 only if, besides being finite, the
+// row is small enough that no accumulator of any layer can overflow (wmax = the model's largest |weight| x max(1, |bias|)).
+__global__ void __launch_bounds__(256) xguard_kernel(const uint64_t* __restrict__ row_ptr, const float* __restrict__ x, uint32_t rows, uint32_t cols,
+                                                     uint32_t row0, float wmax, uint32_t* __restrict__ ok) {
     const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (r >= rows) return;
-    const float* __restrict__ p = x + ((uint64_t)row0 + r) * cols;
-    bool fin = true;
-    for (uint32_t c = lane; c < cols; c += 64u) { const uint32_t b = __float_as_uint(p[c]); fin = fin && ((b & 0x7F800000u) != 0x7F800000u); }
-    const bool all_fin = __all(fin);
-    if (lane == 0) ok[r] = all_fin ? 1u : 0u;
+    uint64_t b = ((uint64_t)row0 + r) * cols; uint32_t n = cols;
+    if (row_ptr) { b = row_ptr[(uint64_t)row0 + r]; n = (uint32_t)(row_ptr[(uint64_t)row0 + r + 1] - b); }
+    const float* __restrict__ p = x + b;
+    uint32_t mx = 0u;
+    for (uint32_t c = lane; c < n; c += 64u) mx = max(mx, __float_as_uint(p[c]) & 0x7FFFFFFFu);
+    mx = wave_max_u32(mx);
+    if (lane == 0) ok[r] = prune_guard_ok(mx, n, wmax) ? 1u : 0u;
 }
 
-void launch_xfinite(const QueriesDev& X, uint32_t row0, uint32_t nrows, uint32_t* ok, hipStream_t s) {
+void launch_xguard(const QueriesDev& X, uint32_t row0, uint32_t nrows, float wmax, uint32_t* ok, hipStream_t s) {
     if (nrows == 0) return;
-    hipLaunchKernelGGL(xfinite_kernel, dim3((nrows + 3u) / 4u), dim3(256), 0, s, X.val, nrows, X.cols, row0, ok);
+    hipLaunchKernelGGL(xguard_kernel, dim3((nrows + 3u) / 4u), dim3(256), 0, s, X.dense ? nullptr : X.row_ptr, X.val, nrows, X.cols, row0, wmax, ok);
     XRL_LAUNCH_CHECK();
 }
 
@@ -205,7 +210,7 @@ __global__ void __launch_bounds__(256) k1g_kernel(K1GArgs a) {
                 if (w16 && col + 4u <= WP) w = *reinterpret_cast<const uint4*>(src);
                 else { if (col + 0u < WP) w.x = src[0]; if (col + 1u < WP) w.y = src[1]; if (col + 2u < WP) w.z = src[2]; if (col + 3u < WP) w.w = src[3]; }
             }
-            if (padw == 0u) {                                     // fast loop: no entry -> +0.0 (finite x only, see xfinite_kernel)
+            if (padw == 0u) {                                     // fast loop: no entry -> +0.0 (finite x only, see xguard_kernel)
                 w.x = w.x == kMissing ? 0u : w.x; w.y = w.y == kMissing ? 0u : w.y; w.z = w.z == kMissing ? 0u : w.z; w.w = w.w == kMissing ? 0u : w.w;
             }
             wreg[it] = w;

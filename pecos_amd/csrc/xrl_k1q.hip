@@ -55,6 +55,8 @@ struct K1QArgs {
     const uint32_t* p_idx; const float* p_val; const uint32_t* p_cnt; uint32_t p_stride;
     uint32_t* out_idx; float* out_val; uint32_t* out_cnt; uint32_t out_stride;
     uint32_t row0, nrows;
+    float prune_wmax;                 // the model's largest |weight| x max(1, |bias|): the pruning guard (prune_guard_ok, xrl_device.h)
+    uint32_t* out_xok;                // non-null: the guard flag of every query is also written here (for a pruned tile-format layer that follows)
 };
 
 #ifndef XRL_K1Q_U1
@@ -73,7 +75,7 @@ template <int NS> struct K1QCfg {
 // last -- a compile-time switch: as a run-time one it cost the widest kernel 8 VGPRs and a wavefront per SIMD
 template <int NS, int PPC, bool DENSEX, bool BIASF>
 __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesDev& X, uint64_t xrow, uint32_t cnt_in,
-                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane) {
+                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane, float wmax) {
     // ---- prolongate: which (parent, dense tile, column) does each of this lane's candidates stand for
     const uint32_t gl = Ly.d_gp_log2, gmask = (1u << gl) - 1u, TT = Ly.d_max_tiles;
     const uint32_t cnt = Ly.implicit_root ? 1u : min(cnt_in, Ly.beam_in);
@@ -114,6 +116,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     const uint32_t* __restrict__ wd = Ly.wd;
     const uint64_t ld = Ly.d_ld;
     const uint32_t w_rows = Ly.w_rows;
+    uint32_t xmx = 0u, xn = 0u;                                        // pruning guard: largest |x| bits this lane has seen, features of the query
 
     // One pass over the query's features for the candidate registers [RB, RE): U features per batch, their U*(RE-RB) weight loads issued
     // together (addresses depend only on the feature ids: scalar row base + this lane's column offset), then applied in feature order
@@ -146,9 +149,11 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
             // chunk_ops<drm, bin_search> (inference.hpp:815-839): every chunk row except the bias row, x gathered by row id
             const float* __restrict__ xd = X.val + xrow * X.cols;
             const uint32_t n_feat = Ly.has_bias ? w_rows - 1u : w_rows;
+            xn = n_feat;
             for (uint32_t t0 = 0; t0 < n_feat; t0 += 64u) {
                 const uint32_t f = t0 + (uint32_t)lane;
                 const float xv = f < X.cols ? xd[f] : 0.0f;
+                xmx = max(xmx, __float_as_uint(xv) & 0x7FFFFFFFu);
                 const uint32_t fv = f < n_feat ? f : 0xFFFFFFFFu;
                 const uint32_t n = min(64u, n_feat - t0);
                 for (uint32_t t = 0; t < n; t += (uint32_t)UU) batch(fv, __float_as_uint(xv), t, w_rows);   // fv >= n_feat only on padding lanes (0xFFFFFFFF)
@@ -160,6 +165,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
             const uint32_t* __restrict__ xi = X.col_idx + xb;
             const float* __restrict__ xv = X.val + xb;
             uint32_t fv = 0xFFFFFFFFu, vb = 0u;
+            xn = xl;
             if (xl) { const bool ok = (uint32_t)lane < xl; const uint32_t t = ok ? (uint32_t)lane : 0u; fv = ok ? xi[t] : 0xFFFFFFFFu; vb = __float_as_uint(xv[t]); }
             for (uint32_t t0 = 0; t0 < xl; t0 += 64u) {
                 uint32_t fn = 0xFFFFFFFFu, vn = 0u;                          // next 64 features: in flight while this chunk is applied
@@ -169,6 +175,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                     fn = ok ? xi[tc] : 0xFFFFFFFFu; vn = __float_as_uint(xv[tc]);
                 }
                 const uint32_t n = min(64u, xl - t0);
+                xmx = max(xmx, vb & 0x7FFFFFFFu);                            // (lanes past the row's end hold one of its values again)
                 for (uint32_t t = 0; t < n; t += (uint32_t)UU) batch(fv, vb, t, w_rows);
                 fv = fn; vb = vn;
             }
@@ -195,7 +202,9 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
         const float v0 = finish(0);
         const uint32_t cge = (uint32_t)__popcll(__ballot(valid[0] && v0 >= ps_next));
-        if (!prune_all_in_first && cge < Ly.k) {
+        // (the guard: a query that could produce a NaN score -- non-finite or huge x, non-finite weights -- is never pruned)
+        const bool xok = prune_guard_ok(wave_max_u32(xmx), xn, wmax);
+        if (!prune_all_in_first && (cge < Ly.k || !xok)) {
             pass(std::integral_constant<int, (NS > 1 ? 1 : 0)>{}, std::integral_constant<int, NS>{});
 #pragma unroll
             for (int r = 1; r < NS; ++r) finish(r);
@@ -359,14 +368,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
-        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
-        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane);
+        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
+        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
+        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
+        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
+        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
+        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
+        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
+        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
     }
     if ((uint32_t)lane < cnt) {
         const size_t o = (size_t)q * a.out_stride + (uint32_t)lane;
@@ -374,6 +383,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI
         a.out_val[o] = s_bval[lane];
     }
     if (lane == 0) a.out_cnt[q] = cnt;
+    if (a.out_xok) {   // the pruning guard of this query, for a bound-pruned tile-format layer that follows (its K2 decides there)
+        uint32_t mx = 0u, n;
+        if (DENSEX) {
+            n = a.X.cols;
+            const float* __restrict__ xd = a.X.val + xrow * a.X.cols;
+            for (uint32_t c = (uint32_t)lane; c < n; c += 64u) mx = max(mx, __float_as_uint(xd[c]) & 0x7FFFFFFFu);
+        } else {
+            const uint64_t xb = a.X.row_ptr[xrow];
+            n = (uint32_t)(a.X.row_ptr[xrow + 1] - xb);
+            for (uint32_t c = (uint32_t)lane; c < n; c += 64u) mx = max(mx, __float_as_uint(a.X.val[xb + c]) & 0x7FFFFFFFu);
+        }
+        mx = wave_max_u32(mx);
+        if (lane == 0) a.out_xok[q] = prune_guard_ok(mx, n, a.prune_wmax) ? 1u : 0u;
+    }
 }
 
 // registers per lane a layer needs with `beam_in` parents per query, or 0 when K1Q cannot serve it
@@ -396,7 +419,7 @@ static uint32_t k1q_kernel_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 3 ? 
 
 // n consecutive dense-format layers (n <= kK1QMaxLayers) in ONE launch: previous beam in, the last layer's beam out
 void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
-                uint32_t* out_cnt, uint32_t out_stride, hipStream_t s) {
+                uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, float prune_wmax, uint32_t* out_xok) {
     if (n <= 0 || n > kK1QMaxLayers) fail("k1q: bad layer count");
     if (n > 1) for (int l = 0; l < n; ++l) if (k1q_regs(*Ls[l], Ps[l].beam_in, Ps[l].k, true) > 3) fail("k1q: only layers of <= 3 candidate registers can share a launch");
     if (Ps[0].nrows == 0) return;
@@ -425,6 +448,7 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     a.p_idx = prev.idx; a.p_val = prev.val; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
     a.out_idx = out_idx; a.out_val = out_val; a.out_cnt = out_cnt; a.out_stride = out_stride;
     a.row0 = Ps[0].row0; a.nrows = Ps[0].nrows;
+    a.prune_wmax = prune_wmax; a.out_xok = out_xok;
     const dim3 grid((a.nrows + 3u) / 4u), block(256);
     const bool bias_first = Ps[0].bias_first != 0;
 #define XRL_K1Q_M(NN, MM) do { \

@@ -63,7 +63,8 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
                     uint32_t* out_cnt, uint32_t out_stride, hipStream_t s,
                     uint32_t rank_limit = 0 /* > 0: only the candidates of the first rank_limit beam slots */, uint32_t limited_cands = 0 /* their maximum number */,
-                    uint32_t* done = nullptr /* out: that selection is final (exact bound, see K2Args) */, const uint32_t* skip_done = nullptr /* queries to skip */);
+                    uint32_t* done = nullptr /* out: that selection is final (exact bound, see K2Args) */, const uint32_t* skip_done = nullptr /* queries to skip */,
+                    const uint32_t* xok = nullptr /* with done: the per-query pruning guard (launch_xguard / K1Q's out_xok) */);
 // stats: sum over (query, parent) of the reference chunk's algorithmic bytes, and of candidates
 constexpr int kStatsPerLayer = 8;   // [0] reference-chunk bytes, [1] candidates, [2] items, [3] probes, [4] matched rows, [5] their entries,
                                     // [6] tile columns over the items, [7] query features x tile columns over the items
@@ -86,7 +87,7 @@ void launch_k4_selected(const uint64_t* col_ptr, const uint32_t* row_idx, const 
 uint32_t k1g_cols(const LayerDev& L);                 // 0: the layer cannot be served by K1G
 void launch_k1g(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items_sorted, const uint32_t* start,
                 uint32_t* blk_start, const uint32_t* x_ok, float* cand, hipStream_t s);
-void launch_xfinite(const QueriesDev& X, uint32_t row0, uint32_t nrows, uint32_t* ok, hipStream_t s);   // per dense query row: all values finite?
+void launch_xguard(const QueriesDev& X, uint32_t row0, uint32_t nrows, float wmax, uint32_t* ok, hipStream_t s);   // per query row (CSR or dense): finite and too small to overflow any accumulator (prune_guard_ok)
 // K1C (xrl_pairs.hip): the CSC route of a layer (w_ops<csc_t>, inference.hpp:1081-1149) over the candidates K0 laid out
 void launch_k1c_csc(const LayerDev& L, const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const LayerPlan& P,
                     const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* ncand, float* cand, hipStream_t s);
@@ -102,7 +103,8 @@ int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
 uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k, bool dense_x);   // 0: the layer / beam / k cannot (or should not) be served by K1Q
 // n consecutive dense-format layers in ONE launch (the beam stays in LDS between them); n <= 8
 void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
-                uint32_t* out_cnt, uint32_t out_stride, hipStream_t s);
+                uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, float prune_wmax, uint32_t* out_xok = nullptr);
+                // prune_wmax / out_xok: the bound-pruning guard (prune_guard_ok, xrl_device.h); out_xok[q] receives every query's flag
 size_t k2_max_k();
 
 }  // namespace xrl

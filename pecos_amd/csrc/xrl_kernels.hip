@@ -693,6 +693,7 @@ struct K2Args {
     uint32_t rank_limit;
     uint32_t* done;
     const uint32_t* skip_done;
+    const uint32_t* xok;         // [nrows] the pruning guard of every query (prune_guard_ok): 0 = never final before every candidate is scored
 };
 
 __device__ __forceinline__ uint32_t k2_child_id(const K2Args& a, uint64_t q, uint32_t pos) {
@@ -841,7 +842,7 @@ __global__ void __launch_bounds__(256) k2_topk_wave(K2Args a) {
     if (a.done) {   // (before the selection: it consumes the keys)
         bool d = true;
         // the k-th best >= the best any later slot can reach (a NaN parent score proves nothing: no pruning)
-        if (limited) d = ps_next == ps_next && wave_count_ge<NS>(key, score_key(a.mult ? fmaxf(ps_next, 0.0f) : ps_next)) >= a.k;
+        if (limited) d = a.xok[q] != 0u && ps_next == ps_next && wave_count_ge<NS>(key, score_key(a.mult ? fmaxf(ps_next, 0.0f) : ps_next)) >= a.k;
         if (lane == 0) a.done[q] = d ? 1u : 0u;
     }
     uint32_t rank, sb, pp;
@@ -870,10 +871,11 @@ bool k2_wave_path(const LayerPlan& P) { return P.k <= 64 && P.cand_stride <= 64u
 void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off,
                     const uint32_t* ncand, const float* cand, uint32_t* out_idx, float* out_val,
                     uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, uint32_t rank_limit, uint32_t limited_cands,
-                    uint32_t* done, const uint32_t* skip_done) {
+                    uint32_t* done, const uint32_t* skip_done, const uint32_t* xok) {
     if (P.nrows == 0) return;
     K2Args a;
-    a.p_val = prev.val; a.rank_limit = rank_limit; a.done = done; a.skip_done = skip_done;
+    a.p_val = prev.val; a.rank_limit = rank_limit; a.done = done; a.skip_done = skip_done; a.xok = xok;
+    if (done && !xok) fail("k2: bound pruning needs the per-query guard flags");
     a.mult = (P.pp.kind == PP_SIGMOID || P.pp.kind == PP_LP_HINGE) ? 1 : 0;
     if ((rank_limit || done || skip_done) && !k2_wave_path(P)) fail("k2: bound pruning needs the register top-k path");
     a.chunk_col = L.chunk_col; a.perm_inv = L.perm_inv;

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <thread>
 
@@ -347,6 +348,13 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     // bias contribution of every child column: the reference adds fl32(bias * w) to the column's
     // accumulator (inference.hpp:806-811 / :824-830); columns without an explicit bias entry add
     // nothing, and acc + (+0.0f) == acc for every reachable acc, so a dense vector is equivalent.
+    {   // largest weight magnitude (the bound-pruning guard, xrl_predict.cpp): any inf / NaN makes it +inf
+        float mx = 0.0f; bool fin = std::isfinite(bias);
+        const uint64_t wn = W_full.col_ptr[W_full.cols];
+        for (uint64_t e = 0; e < wn; ++e) { const float a = std::fabs(W_full.val[e]); if (!(a <= 3.0e38f)) { fin = false; break; } mx = std::max(mx, a); }
+        L->w_absmax = fin ? mx * std::max(1.0f, std::fabs(bias)) : INFINITY;
+        if (!(L->w_absmax <= 3.0e38f)) L->w_absmax = INFINITY;
+    }
     std::vector<float> bias_prod(c_nnz, 0.0f);
     if (has_bias) {
         for (uint32_t c = 0; c < (uint32_t)c_nnz; ++c) {

@@ -91,6 +91,8 @@ struct Layer {
     // host metadata
     uint32_t w_rows = 0, w_cols = 0, c_rows = 0, c_cols = 0;
     float bias = 0.f;
+    float w_absmax = 0.f;                  // max |weight| of the layer times max(1, |bias|); +inf when a weight (or the bias) is not finite -- what the
+                                           // pruning guard prices a query's largest possible partial sum with (xrl_predict.cpp: prune_wmax)
     uint32_t only_topk = 0;
     PostProc pp;
     std::string pp_name;

@@ -134,6 +134,10 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         XRL_HIP(hipStreamWaitEvent(m.aux_stream, e, 0));
     }
     hipEvent_t k1_done = nullptr;                                      // the most recent K1 launch (either lane)
+    // the bound-pruning guard (prune_guard_ok, xrl_device.h) prices a query's largest |x| with the model's largest |weight| x max(1, |bias|)
+    float prune_wmax = 0.0f;
+    for (size_t l = 0; l < T; ++l) prune_wmax = std::max(prune_wmax, m.layers[l]->w_absmax);
+    if (!(prune_wmax <= 3.0e38f)) prune_wmax = INFINITY;
 
     uint64_t batch = 0;
     for (uint64_t row0 = row_begin; row0 < row_end; row0 += nb, ++batch) {
@@ -150,7 +154,15 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             XRL_HIP(hipEventRecord(ev.b, S));
             m.pending.push_back(ev);
         };
+        // per row batch: lw.x_ok[q] = the pruning guard of query q (also "all x finite" for K1G's fast loop); written by launch_xguard or,
+        // for free, by a K1Q launch that runs before the first layer that needs it
         bool x_ok_done = false;
+        auto need_x_ok = [&]() {
+            if (x_ok_done) return;
+            lw.x_ok.reserve((size_t)nb * 4);
+            timed("xguard", 0u, [&] { launch_xguard(X, (uint32_t)row0, nrows, prune_wmax, lw.x_ok.as<uint32_t>(), S); });
+            x_ok_done = true;
+        };
         for (size_t l = 0; l < T; ++l) {
             const Layer& L = *m.layers[l];
             LayerPlan P{};
@@ -186,11 +198,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 continue;
             }
             if (!o.stats_out && layer_mode(l, nrows) == 3) {
-                if (!x_ok_done) {   // once per row batch: which dense query rows are finite (K1G's fast loop needs it on layers with missing cells)
-                    lw.x_ok.reserve((size_t)nb * 4);
-                    launch_xfinite(X, (uint32_t)row0, nrows, lw.x_ok.as<uint32_t>(), S);
-                    x_ok_done = true;
-                }
+                need_x_ok();   // once per row batch: which dense query rows are finite (K1G's fast loop needs it on layers with missing cells) + the pruning guard
                 // ---- exact bound pruning (see the tile-format path below): the GEMM over the children of the J best beam parents first,
                 //      then a second, tile-sorted GEMM over the remaining slots of the queries whose top-k is not final yet.  J covers about
                 //      one candidate register (64 candidates), like K1Q's first stage.
@@ -204,7 +212,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                     timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, slots_a, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
                     timed("k1g_dense_x", (uint32_t)l, [&] { launch_k1g(L.dev, PA, X, lw.items_sorted.p, lw.sort_start.as<uint32_t>(), lw.blk_start.as<uint32_t>(), lw.x_ok.as<uint32_t>(), lw.cand.as<float>(), S); });
                     timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
-                                                                       J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr); });
+                                                                       J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr, lw.x_ok.as<uint32_t>()); });
                     timed("k0b_remaining", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), J, lw.items.p,
                                                                                    lw.prune_cnt.as<uint32_t>(), S); });
                     timed("k1_sort_items_rest", (uint32_t)l, [&] { launch_sort_items(L.dev, slots_b, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S,
@@ -241,7 +249,10 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 if (l1 == T - 1) { qi = d_out_idx + row0 * out_stride; qv = d_out_val + row0 * out_stride; qc = d_out_cnt + row0; qs = out_stride; }
                 else { const int b = (int)(l1 & 1); qi = lw.beam_idx[b].as<uint32_t>(); qv = lw.beam_val[b].as<float>(); qc = lw.beam_cnt[b].as<uint32_t>(); qs = beam_stride; }
                 const std::string nm = (l1 > l) ? std::string(X.dense ? "k1q_fused_x_" : "k1q_fused_") + std::to_string(l) + "_" + std::to_string(l1) : std::string(X.dense ? "k1q_dense_x" : "k1q_dense");
-                timed(nm.c_str(), (uint32_t)l, [&] { launch_k1q(Ls, Ps, (int)(l1 - l + 1), X, prev, qi, qv, qc, qs, S); });
+                // (a later layer of this batch that is NOT served by K1Q decides its pruning in K2 and needs the guard flags: this launch writes them)
+                uint32_t* xok_out = nullptr;
+                if (!x_ok_done && m.prune && l1 + 1 < T) { lw.x_ok.reserve((size_t)nb * 4); xok_out = lw.x_ok.as<uint32_t>(); x_ok_done = true; }
+                timed(nm.c_str(), (uint32_t)l, [&] { launch_k1q(Ls, Ps, (int)(l1 - l + 1), X, prev, qi, qv, qc, qs, S, prune_wmax, xok_out); });
                 l = l1;
                 continue;
             }
@@ -270,12 +281,13 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 lw.items_sorted.reserve(slots_max * k0_item_bytes());
                 LayerPlan PA = P; PA.beam_in = J;                  // (K1 sizes its grid from beam_in x tiles per parent)
                 LayerPlan PB = P; PB.beam_in = beam_in[l] - J;
+                need_x_ok();
                 PB.tune.wpb = 4;                                   // the second phase's grid is sized for "nothing pruned": mostly empty wavefronts, 4 per workgroup to dispatch fewer groups
                 timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S, J); });
                 if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));
                 timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] { launch_k1(L.dev, PA, X, lw.items.p, nullptr, lw.cand.as<float>(), g, S); });
                 timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
-                                                                   J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr); });
+                                                                   J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr, lw.x_ok.as<uint32_t>()); });
                 if (o.stats_out) XRL_HIP(hipMemsetAsync(lw.items_sorted.p, 0xFF, slots_b * k0_item_bytes(), S));   // the stats pass walks the whole list: unused slots read as "no tile"
                 timed("k0b_remaining", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), J, lw.items_sorted.p,
                                                                                lw.prune_cnt.as<uint32_t>(), S); });

@@ -5,8 +5,8 @@
 #   tests           python -m pytest tests -m gpu
 #   smoke           __graft_entry__.smoke()
 #   bench[:ARGS]    python bench.py ARGS            (ARGS with ',' for spaces; output bench_<n>.json / .err)
-#   pmc[:ARGS]      four rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE / L2 requests / VALU) + a --kernel-trace --stats pass over
-#                   `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats ARGS`, reduced to per-kernel CSVs
+#   pmc[:ARGS]      two rocprofv3 --pmc passes (FETCH_SIZE + SQ counters | WRITE_SIZE + L2 hit / miss / requests) + a --kernel-trace --stats pass over
+#                   `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats ARGS`, reduced to per-kernel CSVs and one pmc_traffic entry
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
@@ -24,29 +24,42 @@ try:
     d=json.load(open('$O/bench_$n.json')); print({k:d.get(k) for k in ('value','ms_per_step','value_host_abi','parity')}); print(d['roofline'].get('per_kernel_ms_per_step'))
 except Exception as e: print('no json', e)
 " ;;
-    pmc) cd /tmp && export TMPDIR=/tmp
-         B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats $args"
-         timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.log 2>&1
-         timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > $O/pmc_write.log 2>&1
-         timeout 300 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- $B > $O/pmc_l2.log 2>&1
-         timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_sq -- $B > $O/pmc_sq.log 2>&1
-         timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-abi --no-stats $args > $O/ktrace.log 2>&1
-         python - $O <<'PY'
+    pmc) # pmc:BENCHARG,BENCHARG,...   two counter passes (TCC + TCP + SQ blocks have separate slots) + one --kernel-trace --stats pass; writes
+         # pmc_<n>_{fetch,write,l2,sq}.csv, kernel_stats_<n>.csv and the pmc_traffic entry pmc_entry_<n>.json (scripts/pmc_traffic.py)
+         n=$((n+1)); cd /tmp && export TMPDIR=/tmp
+         B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats --parity-rows 0 $args"
+         timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_a -- $B > $O/pmc_${n}_a.log 2>&1
+         timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $O/pmc_b -- $B > $O/pmc_${n}_b.log 2>&1
+         timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-abi --no-stats --parity-rows 0 $args > $O/ktrace_$n.log 2>&1
+         python - $O $n "$args" <<'PY'
 import csv, glob, os, sys, collections
-O = sys.argv[1]
-for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+O, n, args = sys.argv[1], sys.argv[2], sys.argv[3].split()
+rows = []
+for d in ("pmc_a", "pmc_b"):
     for f in glob.glob(f"{O}/{d}/**/*counter_collection.csv", recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "xrl::" in r["Kernel_Name"]]
-        with open(f"{O}/{d}.csv", "w", newline="") as out:
-            w = csv.DictWriter(out, fieldnames=["Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"], extrasaction="ignore")
-            w.writeheader(); w.writerows(rows)
-        agg = collections.defaultdict(list)
-        for r in rows: agg[(r["Kernel_Name"].split("(")[0][-48:], r["Counter_Name"])].append(float(r["Counter_Value"]))
-        for k, v in sorted(agg.items()): print(d, k, "n=%d mean=%.5g" % (len(v), sum(v) / len(v)))
+        rows += [r for r in csv.DictReader(open(f)) if "xrl::" in r["Kernel_Name"]]
     os.system(f"rm -rf {O}/{d}")
+split = {"fetch": ("FETCH_SIZE",), "write": ("WRITE_SIZE",), "l2": ("TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum")}
+for name, ctrs in list(split.items()) + [("sq", None)]:
+    known = sum(split.values(), ())
+    sel = [r for r in rows if (r["Counter_Name"] in ctrs if ctrs else r["Counter_Name"] not in known)]
+    with open(f"{O}/pmc_{n}_{name}.csv", "w", newline="") as out:
+        w = csv.DictWriter(out, fieldnames=["Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"], extrasaction="ignore")
+        w.writeheader(); w.writerows(sel)
+    os.system(f"cp {O}/pmc_{n}_{name}.csv {O}/pmc_{name}.csv")
+agg = collections.defaultdict(list)
+for r in rows: agg[(r["Kernel_Name"].split("(")[0][-44:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+for k, v in sorted(agg.items()): print(k, "n=%d mean=%.5g" % (len(v), sum(v) / len(v)))
 for f in glob.glob(f"{O}/ktrace/**/*kernel_stats.csv", recursive=True):
-    os.system(f"cp {f} {O}/kernel_stats.csv"); print(open(f).read()[:3000])
+    os.system(f"cp {f} {O}/kernel_stats_{n}.csv"); print(open(f).read()[:2500])
 os.system(f"rm -rf {O}/ktrace")
+cfg, scale, opts = "amazon-670k", "1.0", []
+for i, a in enumerate(args):
+    if a == "--config": cfg = args[i + 1]
+    if a == "--scale": scale = args[i + 1]
+    if a == "--opt": opts.append(args[i + 1])
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+os.system(f"cd {R} && python scripts/pmc_traffic.py {O} {O}/pmc_entry_{n}.json 1.0 {cfg} {scale} {','.join(opts)}")
 PY
          cd $R ;;
     pmcset) # pmcset:COUNTER,COUNTER,...[@BENCHARG,BENCHARG...]  one rocprofv3 --pmc pass with the given counters, per-kernel means printed

@@ -2,7 +2,11 @@
 gpurun_out/<tag>/ (each counter set in its OWN rocprofv3 --pmc pass, --kernel-trace only, over
 `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats`).
 
-usage: pmc_traffic.py <dir with pmc_fetch.csv pmc_write.csv pmc_l2.csv pmc_sq.csv> <out.json> [fetch_factor] [config] [scale]
+usage: pmc_traffic.py <dir with pmc_fetch.csv pmc_write.csv pmc_l2.csv pmc_sq.csv> <out.json> [fetch_factor] [config] [scale] [opt,opt,...]
+       pmc_traffic.py --merge <entry.json> [<entry.json> ...]      add / replace entries of profiles/pmc_traffic.json
+
+The output is ONE entry {key, config, scale, opts, n_gpus, csrc_sha16, kernels{...}}: csrc_sha16 (bench.csrc_sha16) names the sources the
+counters were taken on -- bench.py quotes an entry only for the same key on the same sources.
 
 fetch_factor: what FETCH_SIZE has to be multiplied with for THIS access pattern; from the calibration run
 (scripts/calib_fetch.hip, profiles/r02_calib_fetch.md): gfx950's FETCH_SIZE counts 64 B per fabric read request, a coalesced 16 B/lane
@@ -24,8 +28,12 @@ def family(kernel_name):
     return None
 
 
-def per_family(path, counter, per_step_sum=False):
-    """mean counter value per launch of every kernel family (sort_*: the four sort kernels of a step are one 'launch')"""
+N_STEPS = 4.0   # the profiled command runs --steps 3 --warmup 1
+
+
+def per_family(path, counter):
+    """counter value per STEP of every kernel family: the sum over all launches of the family (both phases of a bound-pruned layer, every
+    layer the family serves) divided by the number of steps the profiled command ran"""
     if not os.path.exists(path):
         return {}
     agg = collections.defaultdict(list)
@@ -34,17 +42,29 @@ def per_family(path, counter, per_step_sum=False):
         if r["Counter_Name"] != counter or fam is None:
             continue
         agg[fam].append(float(r["Counter_Value"]))
-    out = {}
-    for k, v in agg.items():
-        n = len(v) / 4.0 if k == "k1_sort_items" else len(v)
-        out[k] = {"launches": n, "mean": sum(v) / max(n, 1)}
-    return out
+    return {k: {"launches": len(v) / N_STEPS, "mean": sum(v) / N_STEPS} for k, v in agg.items()}
 
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (csrc_sha16 / pmc_key only; its heavy imports live in main())
+
+if sys.argv[1] == "--merge":
+    tfile = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    cur = json.load(open(tfile)) if os.path.exists(tfile) else {}
+    if "entries" not in cur:
+        cur = {"version": 2, "entries": {}}
+    for path in sys.argv[2:]:
+        e = json.load(open(path))
+        cur["entries"][e["key"]] = e
+        print("merged", e["key"], e["csrc_sha16"], sorted(e["kernels"]))
+    json.dump(cur, open(tfile, "w"), indent=1)
+    sys.exit(0)
 
 d, out = sys.argv[1:3]
 factor = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 config = sys.argv[4] if len(sys.argv) > 4 else "amazon-670k"
 scale = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
+opts = [o for o in sys.argv[6].split(",") if o] if len(sys.argv) > 6 else []
 f = per_family(os.path.join(d, "pmc_fetch.csv"), "FETCH_SIZE")
 w = per_family(os.path.join(d, "pmc_write.csv"), "WRITE_SIZE")
 l2 = per_family(os.path.join(d, "pmc_l2.csv"), "TCP_TCC_READ_REQ_sum")
@@ -57,17 +77,17 @@ kernels = {}
 for fam in f:
     fk = f[fam]["mean"]; wk = w.get(fam, {"mean": 0.0})["mean"]
     g = lambda t: t.get(fam, {}).get("mean")
-    kernels[fam] = {"launches_sampled": f[fam]["launches"], "fetch_kb_per_launch_raw": fk, "write_kb_per_launch_raw": wk,
-                    "hbm_bytes_per_launch": (factor * fk + wk) * 1024.0,
-                    "l2_read_req_per_launch": g(l2), "fabric_read_req_per_launch": g(miss), "l2_hit_per_launch": g(hit),
-                    "valu_insts_per_launch": g(valu), "salu_insts_per_launch": g(salu), "valu_active_quad_cycles_per_launch": g(vact)}
+    kernels[fam] = {"launches_per_step": f[fam]["launches"], "fetch_kb_per_step_raw": fk, "write_kb_per_step_raw": wk,
+                    "hbm_bytes_per_step": (factor * fk + wk) * 1024.0,
+                    "l2_read_req_per_step": g(l2), "fabric_read_req_per_step": g(miss), "l2_hit_per_step": g(hit),
+                    "valu_insts_per_step": g(valu), "salu_insts_per_step": g(salu), "valu_active_quad_cycles_per_step": g(vact)}
 json.dump({
-    "config": config, "scale": scale, "n_gpus": 1, "fetch_factor": factor,
+    "key": bench.pmc_key(config, scale, opts), "config": config, "scale": scale, "opts": opts, "n_gpus": 1, "fetch_factor": factor, "csrc_sha16": bench.csrc_sha16(),
     "source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum | SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU ...; "
-              "separate runs, --kernel-trace only) over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats`; mean over the "
-              "launches of the family; bytes = (FETCH_SIZE x fetch_factor + WRITE_SIZE) KiB, fetch_factor from the calibration run on 8..64-byte gathers "
+              "separate runs, --kernel-trace only) over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats`; SUM over all "
+              "launches of the kernel family in a step (every layer it serves, both phases of a bound-pruned layer), averaged over the 4 steps; bytes = (FETCH_SIZE x fetch_factor + WRITE_SIZE) KiB, fetch_factor from the calibration run on 8..64-byte gathers "
               "(profiles/r02_calib_fetch.md); counts fabric requests, Infinity-Cache hits included",
     "kernels": kernels,
 }, open(out, "w"), indent=1)
 for fam, e in kernels.items():
-    print(f"{fam}: hbm bytes per launch {e['hbm_bytes_per_launch']:.3e}  l2 read req {e['l2_read_req_per_launch']}  fabric req {e['fabric_read_req_per_launch']}  valu {e['valu_insts_per_launch']}")
+    print(f"{fam}: per step: hbm bytes {e['hbm_bytes_per_step']:.3e}  l2 read req {e['l2_read_req_per_step']}  fabric req {e['fabric_read_req_per_step']}  valu {e['valu_insts_per_step']}  launches {e['launches_per_step']}")

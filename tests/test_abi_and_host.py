@@ -248,6 +248,39 @@ def test_synthetic_queries_carry_the_specified_number_of_features():
         assert np.allclose(nrm, 1.0, atol=1e-4)                  # L2-normalised rows (xrl_predict.py:143)
 
 
+def test_hard_workload_generator(tmp_path):
+    # xrl_synth "amazon-670k-hard"  at 2 % of its size: the reference's on-disk layout, L2-normalised sorted rows,
+    # reproducible topics, nested supports (a query matches its own topic's column far better than the others), a post-processor that
+    # rarely saturates (largest margin >= 1 for ~5 % of the queries), small bias weights
+    import xrl_synth
+    from oracle.xrl_oracle import load_model_folder
+    folder = str(tmp_path / "m")
+    ks, X, cfg = xrl_synth.make_config("amazon-670k-hard", folder, scale=0.02)
+    assert ks == xrl_synth.tree_shape(cfg["L"]) and X.shape == (cfg["N"], cfg["D"]) and X.has_sorted_indices
+    per_row = np.diff(X.indptr)
+    assert abs(per_row.mean() / cfg["x_nnz"] - 1.0) < 0.05 and per_row.min() >= 1
+    assert np.allclose(np.sqrt(np.asarray(X.multiply(X).sum(axis=1)).ravel()), 1.0, atol=1e-4)
+    layers = load_model_folder(folder)
+    assert [L["W"].shape[1] for L in layers] == ks and all(L["W"].shape[0] == cfg["D"] + 1 for L in layers)
+    topics = xrl_synth.hard_query_topics(cfg["N"], cfg["x_nnz"], ks[-2], seed=1)
+    D = cfg["D"]
+    Xs = X[:600]
+    for d, L in enumerate(layers):
+        W = L["W"].tocsc()
+        assert np.abs(W[D].toarray()).max() < 0.2                                  # bias row: N(0, 0.03)
+        if W.shape[1] > 20000:
+            continue
+        M = (Xs @ W[:D]).toarray()
+        frac_sat = float((M.max(axis=1) >= 1.0).mean())
+        assert frac_sat <= 0.12, (d, frac_sat)                                       # calibrated at 5 % on other queries of the same generator
+        if d == len(layers) - 2:
+            own = M[np.arange(600), topics[:600]]
+            assert (own >= np.quantile(M, 0.99, axis=1)).mean() > 0.8                # the query's own topic is among the best 1 % of the columns
+    # same arguments, same bytes
+    ks2, X2, _ = xrl_synth.make_config("amazon-670k-hard", str(tmp_path / "m2"), scale=0.02)
+    assert (X2 != X).nnz == 0 and np.array_equal(X2.data.view(np.uint32), X.data.view(np.uint32))
+
+
 def test_concat_features_vs_reference_goldens(manifest):
     # pecos_amd.features.concat_features against outputs of the reference's own TransformerMatcher.concat_features
     # (pecos/xmc/xtransformer/matcher.py:864-890; tests/golden/make_golden_r03.py): same pattern, same order, same bits

@@ -90,10 +90,15 @@ def test_dense_query_line_is_priced_on_flops():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
 
 
-def test_counter_based_frac_when_the_counter_file_matches():
-    # profiles/pmc_traffic.json is keyed by (config, scale, n_gpus): for that configuration `frac` is counter bytes / launch time,
-    # the request and issue roofs are attached, and frac_matched / frac_ref_layout stand beside it
-    tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+def test_counter_based_frac_when_the_counter_file_matches(monkeypatch):
+    # profiles/pmc_traffic.json holds one counter set per (config, scale, options), each stamped with the hash of the sources it was taken
+    # on: for that key ON THOSE SOURCES `frac` is counter bytes / kernel time, the request and issue roofs are attached, and frac_matched /
+    # frac_ref_layout stand beside it; on other sources the set is reported as stale and the line falls back to matched work
+    tj_all = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))
+    assert tj_all["version"] == 2 and tj_all["entries"]
+    key = sorted(k for k in tj_all["entries"] if "+" not in k)[0]
+    tj = tj_all["entries"][key]
+    assert key == bench.pmc_key(tj["config"], tj["scale"], []) and len(tj["csrc_sha16"]) >= 8
     fam = "k1_sparse" if "k1_sparse" in tj["kernels"] else sorted(tj["kernels"])[0]
     ent = tj["kernels"][fam]
     rows, k = 1000, 10
@@ -102,18 +107,64 @@ def test_counter_based_frac_when_the_counter_file_matches():
                   hit_entries=float(X.nnz) * 60, item_cols=rows * 800.0, x_cols=float(X.nnz) * 800)]
     linfo = [dict(lookup=2, bucket_levels=0, dense=0, dense_bytes=0, device_bytes=3_000_000_000)]
     ms = 9.0
-    prof = [dict(name=fam if not fam.startswith("k1q") else "k1q_fused_0_0", layer=0, ms=ms * 10, launches=10)]
-    r = bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, _args(config=tj["config"], scale=tj["scale"], steps=10), k, rows, tj["n_gpus"], 9.5)
-    assert r["basis"].startswith("pmc") and r["traffic"] == ent["hbm_bytes_per_launch"]
-    assert abs(r["achieved"] - ent["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9) < 1.0 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
+    name = fam if not fam.startswith("k1q") else "k1q_fused_0_0"
+    # the two phases of a pruned layer are ONE launch of the family: their times add up, the kernel's counters per step cover both
+    prof = [dict(name=name, layer=0, ms=ms * 10 * 0.75, launches=10), dict(name=name + "_rest", layer=0, ms=ms * 10 * 0.25, launches=10)]
+    a1 = _args(config=tj["config"], scale=tj["scale"], steps=10)
+    monkeypatch.setattr(bench, "csrc_sha16", lambda: tj["csrc_sha16"])
+    r = bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, a1, k, rows, tj["n_gpus"], 9.5)
+    assert r["basis"].startswith("pmc") and abs(r["traffic"] - ent["hbm_bytes_per_step"]) < 1.0
+    assert abs(r["achieved"] - ent["hbm_bytes_per_step"] / (ms * 1e-3) / 1e9) < 1.0 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
     assert r["frac_matched"] is not None and r["frac_ref_layout"] is not None
-    if ent.get("fabric_read_req_per_launch"):
-        assert abs(r["requests"]["fabric_req_per_s_G"] - ent["fabric_read_req_per_launch"] / (ms * 1e-3) / 1e9) < 0.1
-    if ent.get("valu_insts_per_launch"):
+    if ent.get("fabric_read_req_per_step"):
+        assert abs(r["requests"]["fabric_req_per_s_G"] - ent["fabric_read_req_per_step"] / (ms * 1e-3) / 1e9) < 0.1
+    if ent.get("valu_insts_per_step"):
         assert 0.0 < r["issue"]["valu_busy_frac"] < 2.0
     # tuning options or the upload mode change what runs: the recorded counters then do not apply
     a2 = _args(config=tj["config"], scale=tj["scale"], steps=10); a2.opt = ["sort_min_tiles=1"]
     assert bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, a2, k, rows, tj["n_gpus"], 9.5)["traffic"] is None
+    a3 = _args(config=tj["config"], scale=tj["scale"], steps=10); a3.include_upload = True
+    assert bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, a3, k, rows, tj["n_gpus"], 9.5)["traffic"] is None
+    # other sources than the ones the counters were taken on: stale, said so in `basis`
+    monkeypatch.setattr(bench, "csrc_sha16", lambda: "0" * 16)
+    r4 = bench.roofline(_FakeClib(stats), None, None, X, prof, linfo, 10, a1, k, rows, tj["n_gpus"], 9.5)
+    assert r4["traffic"] is None and "STALE" in r4["basis"]
+
+
+def test_csrc_hash_follows_the_sources(tmp_path, monkeypatch):
+    h0 = bench.csrc_sha16()
+    assert len(h0) == 16 and h0 == bench.csrc_sha16()
+    import shutil
+    shutil.copytree(os.path.join(REPO, "pecos_amd", "csrc"), tmp_path / "pecos_amd" / "csrc", ignore=shutil.ignore_patterns("build*"))
+    monkeypatch.setattr(bench, "REPO", str(tmp_path))
+    assert bench.csrc_sha16() == h0                                        # build products do not count
+    with open(tmp_path / "pecos_amd" / "csrc" / "xrl_k1q.hip", "a") as f:
+        f.write("\n// edit\n")
+    assert bench.csrc_sha16() != h0
+
+
+def test_no_committed_line_of_this_round_claims_the_impossible():
+    # every committed bench line of the current round must carry a roofline block that is true -- no fraction of a
+    # hardware peak above 1, no dominant kernel priced with 0 bytes, counter-based blocks quoting the counters' sources
+    import glob
+    lines = sorted(glob.glob(os.path.join(REPO, "profiles", "r04_bench_*.json")))
+    for path in lines:
+        j = json.loads(open(path).read().strip().splitlines()[-1])
+        r = j.get("roofline")
+        assert j.get("value_definition"), path
+        if r is None:
+            continue
+        assert 0.0 < r["frac"] <= 1.0, (path, r["frac"])
+        assert r["achieved"] > 0.0, path
+        if r["bound"] == "hbm":
+            assert r["alg_bytes_per_launch"] > 0 or r["traffic"], path
+            if r.get("traffic") is not None:
+                assert r["basis"].startswith("pmc") and "csrc" in r["basis"], path
+        for extra in ("requests", "l2"):
+            if r.get(extra):
+                assert r[extra]["frac"] <= 1.1, (path, extra, r[extra]["frac"])
+        if r["bound"] == "mfma":
+            assert r.get("frac_of_reachable", 0.0) <= 1.0, path
 
 
 def test_round3_amazon_line_is_counter_based_and_self_consistent():

@@ -89,7 +89,7 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
         clib.set_option(m.model.model_chain, "dense_layers", 1)
 
 
-@pytest.mark.parametrize("name,scale", [("eurlex-4k", 0.5), ("wiki10-31k", 0.1), ("amazon-670k", 0.02)])
+@pytest.mark.parametrize("name,scale", [("eurlex-4k", 0.5), ("wiki10-31k", 0.1), ("amazon-670k", 0.02), ("amazon-670k-hard", 0.02)])
 def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
     import xrl_synth
     folder = str(tmp_path / "m")
@@ -623,6 +623,66 @@ def test_bound_pruning_with_massive_ties(variant, XLM, clib, oracle_mod, tmp_pat
     clib.set_option(h, "dense_layers", 1); clib.set_option(h, "prune", 1)
 
 
+@pytest.mark.parametrize("variant", ["x_nonfinite", "x_huge", "w_inf", "w_nan"])
+def test_bound_pruning_guard_nonfinite(variant, XLM, clib, oracle_mod, tmp_path):
+    # exact bound pruning assumes a child's score is at most its parent's bound, which fails when a child's score is NaN
+    # (non-finite x, inf * 0, inf - inf after an overflow, non-finite weights) -- a positive NaN ranks above +inf in the top-k order, so a
+    # later beam slot's NaN candidate belongs at the top of the reference's list.  The guard (prune_guard_ok, csrc/xrl_device.h) never prunes
+    # a query whose largest |x| times the model's largest |weight| could leave the fp32 range.  What must hold: prune = 1 gives the bits
+    # prune = 0 gives, on every kernel family, sparse and dense X -- and where no NaN can arise (all-positive weights, +inf / huge x) both equal
+    # the oracle.
+    import xrl_synth
+    folder = str(tmp_path / "m")
+    D = 120
+    xrl_synth.make_model(folder, D, 700, [60, 40, 12], seed=51, shape=[5, 40, 700], permute_leaf=True)
+    rng = np.random.default_rng(11)
+    positive = variant in ("x_huge", "w_inf")
+    for d in range(3):
+        f = os.path.join(folder, "ranker", f"{d}.model", "W.npz")
+        W = smat.load_npz(f).tocsc().astype(np.float32)
+        if positive:
+            W.data[:] = np.abs(W.data) + 0.01
+        if variant == "w_inf" and d >= 1:
+            W.data[rng.integers(0, len(W.data), 6)] = np.inf
+        if variant == "w_nan" and d >= 1:
+            W.data[rng.integers(0, len(W.data), 6)] = np.nan
+            W.data[rng.integers(0, len(W.data), 6)] = -np.inf
+        smat.save_npz(f, W, compressed=False)
+    X = xrl_synth.make_queries(64, D, 14, seed=53, relabel_seed=51).tocsr()
+    X.data = np.abs(X.data)
+    if variant == "x_nonfinite":      # NaN, +inf, -inf and explicit zeros on features the model uses
+        for r in range(0, 64, 2):
+            lo, hi = X.indptr[r], X.indptr[r + 1]
+            if hi - lo >= 3:
+                X.data[lo + int(rng.integers(0, hi - lo))] = [np.nan, np.inf, -np.inf, 0.0][(r // 2) % 4]
+    if variant == "x_huge":           # products overflow to +inf (weights are positive: no inf - inf)
+        for r in range(0, 64, 3):
+            lo, hi = X.indptr[r], X.indptr[r + 1]
+            if hi > lo:
+                X.data[lo + int(rng.integers(0, hi - lo))] = [3.0e38, np.inf, 1.0e30][(r // 3) % 3]
+    m = XLM.load(folder)
+    h = m.model.model_chain
+    om = oracle_mod.RefModel(folder) if oracle_mod.ref_available() else oracle_mod.OracleModel.load(folder)
+    for Xq in (X, np.ascontiguousarray(X.toarray())):
+        for kw in (dict(beam_size=10, only_topk=10), dict(beam_size=3, only_topk=30), dict(beam_size=25, only_topk=5, post_processor="log-l2-hinge"),
+                   dict(beam_size=7, only_topk=12, post_processor="sigmoid")):
+            base = None
+            for dl in (1, 2, 0):
+                clib.set_option(h, "dense_layers", dl)
+                for pr in (0, 1):
+                    clib.set_option(h, "prune", pr)
+                    got = m.predict(Xq, **kw)
+                    what = f"{variant} {kw} dense_layers={dl} prune={pr} dense_x={not smat.issparse(Xq)}"
+                    if pr == 0:
+                        base = got
+                    else:   # pruning must not change a bit, NaN scores included
+                        assert np.array_equal(got.indptr, base.indptr) and np.array_equal(got.indices, base.indices), what
+                        assert np.array_equal(got.data.view(np.uint32), base.data.view(np.uint32)), what
+                    if positive:
+                        assert_same_topk(got, om.predict(Xq, **kw), exact_scores=EXACT_PP(kw.get("post_processor")), what=what)
+    clib.set_option(h, "dense_layers", 1); clib.set_option(h, "prune", 1)
+
+
 def _bench_workload(name, cache=None):
     """The folder bench.py generates / re-uses for a workload at scale 1.0 (so that the driver's pytest and bench runs build it once)."""
     import json
@@ -642,7 +702,8 @@ def _bench_workload(name, cache=None):
 
 
 @pytest.mark.timeout(1500)
-def test_headline_config_full_size_all_rows_vs_reference(XLM, clib, oracle_mod):
+@pytest.mark.parametrize("workload", ["amazon-670k", "amazon-670k-hard"])
+def test_headline_config_full_size_all_rows_vs_reference(workload, XLM, clib, oracle_mod):
     # BASELINE.json configs[3], the configuration the target is quoted on, at FULL size: Amazon-670K shape, N = 490 000 queries,
     # D = 135 000, L = 670 091, tree [2, 32, 512, 8192, 670091], beam 10, top-k 10 -- EVERY row against the compiled reference
     # (test/pecos/xmc/xlinear/test_xlinear.py:106-245 in spirit): label ids, order and fp32 score bits.  The default policy runs the
@@ -650,7 +711,9 @@ def test_headline_config_full_size_all_rows_vs_reference(XLM, clib, oracle_mod):
     # dense_layers=0 sends every level through the tile-format kernels.
     if not oracle_mod.ref_available():
         pytest.skip("oracle/_ref (the compiled reference) is not built: 490 k rows are out of reach of the single-threaded restatement")
-    folder, ks, cfg = _bench_workload("amazon-670k")
+    # "amazon-670k-hard": the same shape on the model with query-dependent routing and an unsaturated post-processor (xrl_synth.make_model_hard),
+    # where bound pruning stops almost nothing -- the second phases of every kernel family do the bulk of the work.
+    folder, ks, cfg = _bench_workload(workload)
     X = smat.load_npz(os.path.join(folder, "X.npz")).tocsr().astype(np.float32); X.sort_indices()
     assert X.shape == (490000, 135000) and ks == [2, 32, 512, 8192, 670091]
     kw = dict(beam_size=10, only_topk=10)
@@ -658,15 +721,15 @@ def test_headline_config_full_size_all_rows_vs_reference(XLM, clib, oracle_mod):
     m = XLM.load(folder)
     h = m.model.model_chain
     clib.profile_enable(h, True); clib.profile_reset(h)
-    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, default policy")
+    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{workload} full size, default policy")
     names = {r["name"] for r in clib.profile_get(h)}
     clib.profile_enable(h, False)
     assert "k1q_fused_0_3" in names and "k1_sparse" in names, names
     clib.set_option(h, "dense_layers", 0)
-    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, tile format everywhere")
+    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{workload} full size, tile format everywhere")
     clib.set_option(h, "dense_layers", 1)
     clib.set_option(h, "prune", 0)                    # every candidate of every beam parent scored (no exact bound pruning)
-    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what="amazon-670k full size, prune=0")
+    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{workload} full size, prune=0")
     clib.set_option(h, "prune", 1)
 
 

@@ -30,7 +30,7 @@ CONFIGS = {
     "amazon-670k": dict(N=490000, D=135000, L=670091, x_nnz=76, w_nnz=[20000, 8000, 3000, 800, 100], beam=10),
     # the SAME shape on a model that does not flatter bound pruning: every level-3 cluster owns a topic (the
     # supports are nested down the tree), a query draws 60 % of its features from the topic of ONE uniformly chosen cluster (routing is
-    # query-dependent), bias-row weights ~N(0, 0.1), every level's weights scaled so that the BEST margin of a query reaches 1 -- where
+    # query-dependent), small bias-row weights, every level's weights scaled so that the BEST margin of a query reaches 1 -- where
     # l3-hinge saturates -- for 5 % of the queries only (make_model_hard / make_queries_hard)
     "amazon-670k-hard": dict(N=490000, D=135000, L=670091, x_nnz=76, w_nnz=[20000, 8000, 3000, 800, 100], beam=10, hard=True),
     # dense-input config (BASELINE.json configs[4]); N is per-bench adjustable
@@ -337,13 +337,14 @@ def hard_query_topics(N, x_nnz, n_topics, seed=1):
 
 
 def make_model_hard(folder, D, L, w_nnz, x_nnz, bias=1.0, post_processor="l3-hinge", only_topk=20, seed=0, permute_leaf=True,
-                    nr_splits=16, max_leaf_size=100, shape=None, share=(0.5, 0.5, 0.5, 0.5, 0.7), sat_quantile=0.95, calib_rows=384):
+                    nr_splits=16, max_leaf_size=100, shape=None, share=(0.5, 0.5, 0.5, 0.5, 0.7), sat_quantile=0.95, calib_rows=384, bias_std=0.03):
     """A synthetic model with query-dependent routing and an unsaturated post-processor (CONFIGS["amazon-670k-hard"]).
 
     Supports are nested down the tree: a node's column takes `share` of its features from its parent's support and the rest from
     the global Zipf popularity, so a query drawn from the topic of one level-(T-2) cluster matches that cluster's whole ancestor
     path better than their siblings.  Weights ~ N(0.5, 0.6) (a matched feature raises the margin on average) times the feature's
-    informativeness (the most popular features carry almost no weight); bias-row weights ~ N(0, 0.1).  Every level is then scaled so that the LARGEST margin a calibration query reaches over ALL columns of the level
+    informativeness (the most popular features carry almost no weight); bias-row weights ~ N(0, bias_std) -- 0.03: with 0.1 the tail of the bias weights
+    outranks the margins of unmatched columns (median 0.015) and the ten most common leaf parents hold 6.4 % of the final labels.  Every level is then scaled so that the LARGEST margin a calibration query reaches over ALL columns of the level
     is >= 1 for a fraction 1 - sat_quantile of the queries: P(margin >= 1) <= 5 % for any candidate at every level, i.e. l{p}-hinge
     saturates rarely and children do not tie with their parents' scores.  Returns (ks, topic_ptr, topic_idx) -- the supports of
     the level above the leaves, which make_queries_hard draws the queries from."""
@@ -392,7 +393,7 @@ def make_model_hard(folder, D, L, w_nnz, x_nnz, bias=1.0, post_processor="l3-hin
             dst = np.arange(len(idx)) + np.repeat(np.cumsum(np.concatenate([[0], has_b[:-1]])), cnt)
             new_idx[dst] = idx; new_val[dst] = val
             bpos = new_ptr[1:][has_b] - 1
-            new_idx[bpos] = D; new_val[bpos] = (0.1 * rng.standard_normal(len(bpos))).astype(np.float32)
+            new_idx[bpos] = D; new_val[bpos] = (bias_std * rng.standard_normal(len(bpos))).astype(np.float32)
             ptr, idx, val = new_ptr, new_idx, new_val
         rows = D + 1 if bias > 0 else D
         W = smat.csc_matrix((val, idx.astype(np.int32), ptr), shape=(rows, K))
