@@ -270,6 +270,9 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *   "k1_group"            lanes per (query, tile) item in K1: 0 = auto, else a power of two <= 64
  *   "max_batch_rows"      rows of X per internal batch (0 = auto: candidate buffer <= 6 GiB)
  *   "sort_min_tiles"      tile-sort the items of layers with at least this many tiles (0 = never)
+ *   "sort_rest"           1 (default): the second phase of a bound-pruned tile-format layer runs on tile-sorted items (counting sort of the
+ *                         compacted list by tile: the items of a tile run back to back on one XCD and share its lookup words and entries in
+ *                         that XCD's L2); 0: in query order
  *   "host_register"       host ABI: 1 = page-lock the caller's X arrays in place for the duration of the call (hipHostRegister) and let
  *                         the copy engine read them directly, instead of staging them through two pinned buffers with host threads
  *   "devices"             MULTI-GPU BEHIND THE DROP-IN ENTRY POINTS: the handle serves c_xlinear_predict_{csr,drm}_f32 from this many

@@ -101,11 +101,16 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         if (m.sort_min_tiles > 0 && L.n_tiles >= (uint32_t)m.sort_min_tiles) return 1;
         return 0;
     };
+    // the second phase of a bound-pruned tile-format layer runs on TILE-SORTED items (option sort_rest): what is left after the first phase
+    // is, on a model that does not let the bound stop much, most of the layer's work, and in query order every (query, tile) item finds its
+    // tile's lookup words and entries cold (Amazon-670K-hard: 7 % L2 hits, the fabric's request ceiling); tile-sorted, the items of a tile
+    // run back to back on one XCD and share them
+    auto sorts_rest = [&](size_t l) { return m.sort_rest != 0 && !o.stats_out && m.layers[l]->n_tiles <= sort_max_tiles() && m.layers[l]->n_tiles >= 64u; };
     {
         size_t hist_max = 0; uint32_t tiles_max = 0; bool any = false;
         for (size_t l = 0; l < T; ++l) {
             const Layer& L = *m.layers[l];
-            if (layer_mode(l, nb) != 0 || (n_rows % nb && layer_mode(l, n_rows % nb) != 0)) {
+            if (layer_mode(l, nb) != 0 || (n_rows % nb && layer_mode(l, n_rows % nb) != 0) || (m.prune && sorts_rest(l))) {
                 any = true;
                 hist_max = std::max(hist_max, sort_hist_bytes(nb * beam_in[l] * L.max_tiles_per_parent, L.n_tiles));
                 tiles_max = std::max(tiles_max, L.n_tiles);
@@ -289,9 +294,14 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
                                                                    J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr, lw.x_ok.as<uint32_t>()); });
                 if (o.stats_out) XRL_HIP(hipMemsetAsync(lw.items_sorted.p, 0xFF, slots_b * k0_item_bytes(), S));   // the stats pass walks the whole list: unused slots read as "no tile"
-                timed("k0b_remaining", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), J, lw.items_sorted.p,
+                const bool srt = sorts_rest(l);
+                // (sorted: the compacted list goes where the first phase's items were -- K1 has consumed them -- and is sorted into items_sorted)
+                timed("k0b_remaining", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), J, srt ? lw.items.p : lw.items_sorted.p,
                                                                                lw.prune_cnt.as<uint32_t>(), S); });
-                timed(X.dense ? "k1_dense_rest" : "k1_sparse_rest", (uint32_t)l, [&] { launch_k1(L.dev, PB, X, lw.items_sorted.p, lw.prune_cnt.as<uint32_t>(), lw.cand.as<float>(), g, S); });
+                if (srt) timed("k1_sort_items_rest", (uint32_t)l, [&] { launch_sort_items(L.dev, slots_b, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S,
+                                                                                         lw.prune_cnt.as<uint32_t>()); });
+                timed(X.dense ? "k1_dense_rest" : "k1_sparse_rest", (uint32_t)l, [&] { launch_k1(L.dev, PB, X, lw.items_sorted.p, srt ? lw.sort_start.as<uint32_t>() + L.n_tiles : lw.prune_cnt.as<uint32_t>(),
+                                                                                                 lw.cand.as<float>(), g, S); });
                 if (lanes == 2) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
                 timed("k2_topk_rest", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
                                                                         0, 0, nullptr, lw.prune_done.as<uint32_t>()); });

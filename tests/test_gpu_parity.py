@@ -678,7 +678,9 @@ def test_bound_pruning_guard_nonfinite(variant, XLM, clib, oracle_mod, tmp_path)
                     else:   # pruning must not change a bit, NaN scores included
                         assert np.array_equal(got.indptr, base.indptr) and np.array_equal(got.indices, base.indices), what
                         assert np.array_equal(got.data.view(np.uint32), base.data.view(np.uint32)), what
-                    if positive:
+                    # (dense X multiplies EVERY chunk row: 0 * inf is a NaN in the reference too, and where a NaN lands in its std::sort is
+                    #  not a defined order -- the oracle is consulted only where no NaN can arise)
+                    if positive and (smat.issparse(Xq) or variant == "x_huge"):
                         assert_same_topk(got, om.predict(Xq, **kw), exact_scores=EXACT_PP(kw.get("post_processor")), what=what)
     clib.set_option(h, "dense_layers", 1); clib.set_option(h, "prune", 1)
 
