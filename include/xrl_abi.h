@@ -16,6 +16,7 @@
 #define XRL_ABI_H
 
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -196,6 +197,26 @@ void* xrl_queries_from_device_drm(void* model, uint32_t rows, uint32_t cols, con
 void* xrl_queries_tfidf_device(void* model, uint32_t rows, uint32_t cols, const uint64_t* d_row_ptr, const uint32_t* d_col_idx,
                                const float* d_count, uint64_t nnz, const float* d_idf, int binary, int sublinear_tf, int norm_p,
                                float* d_out, void* hip_stream);
+/* ---- TF-IDF query producer with the reference's own entry points (libpecos.cpp:398-445 -> pecos/core/utils/tfidf.hpp) --------------
+ * c_tfidf_load reads a folder written by the reference's Tfidf.save (one BaseVectorizer folder: tokenizer/{config.json, vocab.txt},
+ * vectorizer/{config.json, tfidf-model.txt}; or an ensemble: meta.json + <i>.base/) -- host only.  c_tfidf_predict has the
+ * reference's signature and result (host CSR through the allocator, rows = documents, sorted feature ids): the tokenizer and the
+ * n-gram lookup run on host threads (`threads`, <= 0: all), their term counts go to the device once, weighting and normalisation run
+ * there (K5) and the result is copied back -- bit-identical to the reference (sublinear_tf: <= 1 ulp).  Training, saving and the
+ * *_from_file variants stay the reference's.
+ * xrl_tfidf_predict_device is the same pipeline WITHOUT the copy back: it returns a query handle (xrl_queries_free) whose X lives in
+ * the HBM of `model`'s device and feeds xrl_predict_device / xrl_predict_device_rows directly -- the call sites SURVEY.md 8f N4 names
+ * (pecos/apps/text2text/model.py:416-417: preprocessor.predict -> xlinear predict) without any host round trip of X.
+ * xrl_tfidf_counts (host only, tests): the hstacked CSR of term COUNTS the device half starts from. */
+void* c_tfidf_load(const char* model_dir);
+void c_tfidf_destruct(void* ptr);
+void c_tfidf_predict(void* ptr, void* corpus_ptr /* const char** */, const size_t* doc_lens, size_t nr_doc, int threads, py_sparse_allocator_t pred_alloc);
+uint32_t xrl_tfidf_nr_features(void* ptr);
+void* xrl_tfidf_predict_device(void* vectorizer, void* model, void* corpus_ptr /* const char** */, const size_t* doc_lens, size_t nr_doc, int threads);
+void xrl_tfidf_counts(void* ptr, void* corpus_ptr /* const char** */, const size_t* doc_lens, size_t nr_doc, int threads, py_sparse_allocator_t alloc);
+/* xrl_queries_concat_device_ex for a CSR query handle (e.g. xrl_tfidf_predict_device's): [X of the handle | X_emb] as a NEW handle on the
+ * same device (XR-Transformer's concat_model call site, pecos/xmc/xtransformer/model.py:589-603, with both halves device-resident). */
+void* xrl_queries_concat_handle(void* model, void* queries, uint32_t dense_cols, const float* d_emb, int normalize_emb, void* hip_stream);
 /* The query form of XR-Transformer's concat_model (TransformerMatcher.concat_features + smat_util.hstack_csr,
  * pecos/xmc/xtransformer/matcher.py:864-890, model.py:589-603): [X_feat (device CSR, sparse_cols columns) | X_emb (device dense
  * rows x dense_cols)] assembled into one device CSR owned by the returned handle; every cell of the dense block becomes a stored

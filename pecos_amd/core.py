@@ -200,6 +200,13 @@ class corelib(object):
             "xrl_queries_tfidf_device": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
             "xrl_queries_concat_device_ex": (c_void_p, [c_void_p, c_uint32, c_uint32, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_int, c_void_p]),
             "xrl_queries_free": (None, [c_void_p]),
+            "c_tfidf_load": (c_void_p, [c_char_p]),
+            "c_tfidf_destruct": (None, [c_void_p]),
+            "c_tfidf_predict": (None, [c_void_p, c_void_p, POINTER(c_uint64), c_uint64, c_int, ScipyCompressedSparseAllocator.CFUNCTYPE]),
+            "xrl_tfidf_counts": (None, [c_void_p, c_void_p, POINTER(c_uint64), c_uint64, c_int, ScipyCompressedSparseAllocator.CFUNCTYPE]),
+            "xrl_tfidf_nr_features": (c_uint32, [c_void_p]),
+            "xrl_tfidf_predict_device": (c_void_p, [c_void_p, c_void_p, c_void_p, POINTER(c_uint64), c_uint64, c_int]),
+            "xrl_queries_concat_handle": (c_void_p, [c_void_p, c_void_p, c_uint32, c_void_p, c_int, c_void_p]),
             "xrl_predict_device": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int]),
             "xrl_predict_device_rows": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_int, c_uint32, c_uint32]),
             "xrl_predict_stats": (c_int, [c_void_p, c_void_p, c_uint32, c_char_p, c_uint32, POINTER(c_double), c_uint32]),
@@ -447,6 +454,59 @@ class corelib(object):
         h = self.clib_float32.xrl_queries_concat_device_ex(c_void_p(c_model), rows, sparse_cols, c_void_p(row_ptr_addr), c_void_p(col_idx_addr),
                                                            c_void_p(val_addr), nnz, dense_cols, c_void_p(emb_addr), 1 if normalize_emb else 0,
                                                            c_void_p(stream or 0))
+        self._check()
+        return h
+
+    # ---- TF-IDF query producer (pecos/core/base.py:1696-1725, 1820-1862: tfidf_load / tfidf_destruct / tfidf_predict)
+    def tfidf_load(self, load_dir):
+        h = self.clib_float32.c_tfidf_load(c_char_p(load_dir.encode("utf-8")))
+        self._check()
+        return h
+
+    def tfidf_destruct(self, model):
+        if self._lib is not None and model:
+            self._lib.c_tfidf_destruct(c_void_p(model))
+
+    @staticmethod
+    def _corpus_arrays(corpus):
+        nr_doc = len(corpus)
+        arr = (c_char_p * nr_doc)()
+        arr[:] = [line.encode("utf-8") if isinstance(line, str) else bytes(line) for line in corpus]
+        lens = np.array([len(line) for line in arr], dtype=np.uint64)
+        return arr, lens, nr_doc
+
+    def tfidf_predict(self, model, corpus, buffer_size=0, threads=-1):
+        """Vectorize a list of strings (the reference's in-memory path; predict-from-file stays the reference's)."""
+        if isinstance(corpus, str):
+            raise NotImplementedError("predict from a corpus FILE is not offered by pecos_amd: read the lines and pass a list")
+        pred_alloc = ScipyCompressedSparseAllocator()
+        arr, lens, nr_doc = self._corpus_arrays(corpus)
+        self.clib_float32.c_tfidf_predict(c_void_p(model), arr, lens.ctypes.data_as(POINTER(c_uint64)), nr_doc, threads, pred_alloc.cfunc)
+        self._check()
+        return pred_alloc.get()
+
+    def tfidf_counts(self, model, corpus, threads=-1):
+        """Host only: the CSR of term COUNTS (hstacked over an ensemble's base vectorizers) the device weighting starts from."""
+        pred_alloc = ScipyCompressedSparseAllocator()
+        arr, lens, nr_doc = self._corpus_arrays(corpus)
+        self.clib_float32.xrl_tfidf_counts(c_void_p(model), arr, lens.ctypes.data_as(POINTER(c_uint64)), nr_doc, threads, pred_alloc.cfunc)
+        self._check()
+        return pred_alloc.get()
+
+    def tfidf_nr_features(self, model):
+        v = int(self.clib_float32.xrl_tfidf_nr_features(c_void_p(model)))
+        self._check()
+        return v
+
+    def tfidf_predict_device(self, model, c_model, corpus, threads=-1):
+        """Texts -> tf-idf X that STAYS on c_model's device: a query handle for predict_device (free it with queries_free)."""
+        arr, lens, nr_doc = self._corpus_arrays(corpus)
+        h = self.clib_float32.xrl_tfidf_predict_device(c_void_p(model), c_void_p(c_model), arr, lens.ctypes.data_as(POINTER(c_uint64)), nr_doc, threads)
+        self._check()
+        return h
+
+    def queries_concat_handle(self, c_model, queries, dense_cols, emb_addr, normalize_emb=False, stream=None):
+        h = self.clib_float32.xrl_queries_concat_handle(c_void_p(c_model), c_void_p(queries), dense_cols, c_void_p(emb_addr), 1 if normalize_emb else 0, c_void_p(stream or 0))
         self._check()
         return h
 

@@ -13,6 +13,7 @@
 #include <thread>
 
 #include "xrl_predict.h"
+#include "xrl_tfidf.h"
 
 using namespace xrl;
 
@@ -1299,6 +1300,138 @@ uint64_t xrl_model_device_bytes(void* model) {
     uint64_t v = 0;
     guarded([&] { v = as_model(model)->device_bytes(); });
     return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TF-IDF query producer (libpecos.cpp:398-445): c_tfidf_load / c_tfidf_destruct / c_tfidf_predict with the
+// reference's signatures, and xrl_tfidf_predict_device, which leaves X in HBM for xrl_predict_device.
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+struct TfidfHandle {
+    TfidfVectorizer v;
+    std::vector<float> idf_all;                  // the base vectorizers' idf side by side (hstack column order)
+};
+
+// texts -> term counts (host threads) -> device -> weighting + normalisation (K5): a query handle that owns its three arrays
+std::unique_ptr<Queries> tfidf_to_device(const TfidfHandle& H, const char* const* corpus, const size_t* doc_lens, size_t nr_doc, int threads, int device, hipStream_t s) {
+    if (nr_doc > 0xFFFFFFFFull) fail("tfidf: too many documents");
+    const TfidfVectorizer& V = H.v;
+    const uint32_t nb = (uint32_t)V.base.size(), rows = (uint32_t)nr_doc;
+    std::vector<uint64_t> seg_ptr; std::vector<uint32_t> col; std::vector<float> cnt;
+    V.count_corpus(corpus, doc_lens, nr_doc, threads, seg_ptr, col, cnt);
+    use_device(device);
+    auto q = std::make_unique<Queries>();
+    q->device = device; q->nnz = col.size();
+    DevBuf d_seg, d_idf, d_err;
+    d_seg.upload(seg_ptr); q->idx.upload(col); q->val.upload(cnt);
+    d_idf.upload(H.idf_all);
+    d_err.reserve(4); XRL_HIP(hipMemsetAsync(d_err.p, 0, 4, s));
+    for (uint32_t b = 0; b < nb; ++b) {
+        const TfidfBase& B = V.base[b];
+        launch_tfidf_weight(d_seg.as<uint64_t>(), q->idx.as<uint32_t>(), q->val.as<float>(), B.use_idf ? d_idf.as<float>() : nullptr, rows, V.nr_features,
+                            B.binary ? 1 : 0, B.sublinear_tf ? 1 : 0, B.norm_p, q->val.as<float>(), s, nb, b, d_err.as<uint32_t>());
+    }
+    // whole rows: the hstacked CSR's row pointer; the ensemble's normalisation (Vectorizer::predict, tfidf.hpp:1405-1430)
+    if (nb == 1) q->ptr = std::move(d_seg);
+    else {
+        std::vector<uint64_t> row_ptr((size_t)rows + 1);
+        for (size_t r = 0; r <= rows; ++r) row_ptr[r] = seg_ptr[r * nb];
+        q->ptr.upload(row_ptr);
+    }
+    if (nb > 1 || V.norm_p != V.base[0].norm_p)
+        launch_tfidf_weight(q->ptr.as<uint64_t>(), q->idx.as<uint32_t>(), q->val.as<float>(), nullptr, rows, V.nr_features, 0, 0, V.norm_p, q->val.as<float>(), s);
+    uint32_t err = 0;
+    XRL_HIP(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s));
+    XRL_HIP(hipStreamSynchronize(s));
+    if (err) fail("tfidf: a feature id outside the model's feature range");
+    q->dev.row_ptr = q->ptr.as<uint64_t>(); q->dev.col_idx = q->idx.as<uint32_t>(); q->dev.val = q->val.as<float>();
+    q->dev.rows = rows; q->dev.cols = V.nr_features; q->dev.dense = 0; q->dev.nnz = q->nnz;
+    return q;
+}
+}  // namespace
+
+extern "C" {
+
+void* c_tfidf_load(const char* model_dir) {
+    void* out = nullptr;
+    guarded([&] {
+        if (!model_dir) fail("null model_dir");
+        auto h = std::make_unique<TfidfHandle>();
+        h->v.load(model_dir);
+        for (const auto& b : h->v.base) h->idf_all.insert(h->idf_all.end(), b.idf.begin(), b.idf.end());
+        out = h.release();
+    });
+    return out;
+}
+
+void c_tfidf_destruct(void* ptr) { guarded([&] { delete static_cast<TfidfHandle*>(ptr); }); }
+
+uint32_t xrl_tfidf_nr_features(void* ptr) {
+    uint32_t v = 0;
+    guarded([&] { if (!ptr) fail("null vectorizer handle"); v = static_cast<TfidfHandle*>(ptr)->v.nr_features; });
+    return v;
+}
+
+void c_tfidf_predict(void* ptr, void* corpus_ptr, const size_t* doc_lens, size_t nr_doc, int threads, py_sparse_allocator_t pred_alloc) {
+    guarded([&] {
+        if (!ptr || !pred_alloc) fail("c_tfidf_predict: null argument");
+        if (nr_doc == 0) fail("Invalid nr_doc 0");                         // libpecos.cpp:442-444
+        if (!corpus_ptr || !doc_lens) fail("c_tfidf_predict: null corpus");
+        require_gpu();
+        const TfidfHandle& H = *static_cast<TfidfHandle*>(ptr);
+        hipStream_t s = nullptr;
+        use_device(g_device);
+        XRL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        std::unique_ptr<Queries> q;
+        try { q = tfidf_to_device(H, static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, g_device, s); }
+        catch (...) { (void)hipStreamDestroy(s); throw; }
+        (void)hipStreamDestroy(s);
+        uint32_t* indices = nullptr; uint64_t* indptr = nullptr; float* data = nullptr;
+        pred_alloc(false, q->dev.rows, q->dev.cols, q->nnz, &indices, &indptr, &data);
+        if (!indptr || (q->nnz && (!indices || !data))) fail("allocator returned null");
+        XRL_HIP(hipMemcpy(indptr, q->dev.row_ptr, ((size_t)q->dev.rows + 1) * 8, hipMemcpyDeviceToHost));
+        if (q->nnz) {
+            XRL_HIP(hipMemcpy(indices, q->dev.col_idx, q->nnz * 4, hipMemcpyDeviceToHost));
+            XRL_HIP(hipMemcpy(data, q->dev.val, q->nnz * 4, hipMemcpyDeviceToHost));
+        }
+    });
+}
+
+void* xrl_tfidf_predict_device(void* vectorizer, void* model, void* corpus_ptr, const size_t* doc_lens, size_t nr_doc, int threads) {
+    void* out = nullptr;
+    guarded([&] {
+        if (!vectorizer) fail("xrl_tfidf_predict_device: null vectorizer handle");
+        if (nr_doc && (!corpus_ptr || !doc_lens)) fail("xrl_tfidf_predict_device: null corpus");
+        Model& m = *as_model(model);
+        const TfidfHandle& H = *static_cast<TfidfHandle*>(vectorizer);
+        out = tfidf_to_device(H, static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, m.device, m.stream).release();
+    });
+    return out;
+}
+
+void* xrl_queries_concat_handle(void* model, void* queries, uint32_t dense_cols, const float* d_emb, int normalize_emb, void* hip_stream) {
+    if (!queries) { set_err("xrl_queries_concat_handle: null query handle"); return nullptr; }
+    const Queries& q = *static_cast<Queries*>(queries);
+    if (q.dev.dense) { set_err("xrl_queries_concat_handle: the query handle must hold a CSR"); return nullptr; }
+    return xrl_queries_concat_device_ex(model, q.dev.rows, q.dev.cols, q.dev.row_ptr, q.dev.col_idx, q.dev.val, q.dev.nnz, dense_cols, d_emb, normalize_emb, hip_stream);
+}
+
+// host only (no GPU): the hstacked TERM-COUNT CSR the device weighting starts from -- what the tokenizer and the n-gram lookup produce
+void xrl_tfidf_counts(void* ptr, void* corpus_ptr, const size_t* doc_lens, size_t nr_doc, int threads, py_sparse_allocator_t alloc) {
+    guarded([&] {
+        if (!ptr || !alloc || (nr_doc && (!corpus_ptr || !doc_lens))) fail("xrl_tfidf_counts: null argument");
+        const TfidfVectorizer& V = static_cast<TfidfHandle*>(ptr)->v;
+        std::vector<uint64_t> seg_ptr; std::vector<uint32_t> col; std::vector<float> cnt;
+        V.count_corpus(static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, seg_ptr, col, cnt);
+        uint32_t* indices = nullptr; uint64_t* indptr = nullptr; float* data = nullptr;
+        alloc(false, nr_doc, V.nr_features, col.size(), &indices, &indptr, &data);
+        if (!indptr || (!col.empty() && (!indices || !data))) fail("allocator returned null");
+        const size_t nb = V.base.size();
+        for (size_t r = 0; r <= nr_doc; ++r) indptr[r] = seg_ptr[r * nb];
+        if (!col.empty()) { std::memcpy(indices, col.data(), col.size() * 4); std::memcpy(data, cnt.data(), cnt.size() * 4); }
+    });
 }
 
 }  // extern "C"

@@ -96,7 +96,8 @@ void launch_concat_csr(const uint64_t* in_ptr, const uint32_t* in_idx, const flo
                        uint32_t sparse_cols, uint32_t dense_cols, int normalize_emb, uint64_t* out_ptr, uint32_t* out_idx, float* out_val, hipStream_t s);
 // xrl_features.hip: the weighting half of the reference's TF-IDF vectorizer (tfidf.hpp:798-822) on a device CSR of term counts
 void launch_tfidf_weight(const uint64_t* row_ptr, const uint32_t* col_idx, const float* count, const float* idf, uint32_t rows, uint32_t cols,
-                         int binary, int sublinear_tf, int norm_p, float* out, hipStream_t s);
+                         int binary, int sublinear_tf, int norm_p, float* out, hipStream_t s,
+                         uint32_t seg_stride = 1, uint32_t seg_off = 0, uint32_t* err = nullptr);   // rows = segments of row_ptr; *err = 1 on a column id >= cols
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
 // K1Q (xrl_k1q.hip): a whole layer -- prolongate, chunk products against the DENSE row format, post-processor,
 // combine, top-k, child re-ordering -- in one query-stationary kernel: previous beam in, next beam out.

@@ -125,3 +125,88 @@ def predict_tfidf_from_torch(model, crow, col, count, n_cols, idf=None, binary=F
     finally:
         clib.queries_free(q)
     return idx, sc, cnt
+
+
+class Tfidf:
+    """The PREDICT half of the reference's ``pecos.utils.featurization.text.vectorizers.Tfidf`` (vectorizers.py:163-308): ``load`` a
+    folder the reference saved, ``predict`` a list of strings to a scipy CSR -- same names, arguments and result -- with the tokenizer on
+    host threads and the weighting / normalisation on the device; plus ``predict_device``, which leaves X in HBM.  Training and saving
+    stay the reference's."""
+
+    def __init__(self, model=None):
+        self.model = model
+
+    def __del__(self):
+        try:
+            clib.tfidf_destruct(self.model)
+        except Exception:
+            pass
+
+    @classmethod
+    def load(cls, load_dir):
+        import os
+        if not os.path.exists(load_dir):
+            raise ValueError(f"tfidf model not exist at {load_dir}")
+        return cls(clib.tfidf_load(load_dir))
+
+    @property
+    def nr_features(self):
+        return clib.tfidf_nr_features(self.model)
+
+    def predict(self, corpus, **kwargs):
+        return clib.tfidf_predict(self.model, corpus, buffer_size=kwargs.get("buffer_size", 0), threads=kwargs.get("threads", -1))
+
+    def predict_device(self, xlinear_model, corpus, threads=-1):
+        """Texts -> X resident on ``xlinear_model``'s GPU: a query handle (``clib.queries_free`` it) for ``clib.predict_device``."""
+        return clib.tfidf_predict_device(self.model, xlinear_model.model.model_chain, corpus, threads)
+
+
+def _predict_handle_to_csr(model, q, rows, beam_size=None, only_topk=None, post_processor=None):
+    import torch
+    from .distributed import rows_to_csr
+    h = model.model.model_chain
+    k = clib.effective_topk(h, only_topk)
+    dev = torch.device("cuda", clib.xlinear_get_int_attr(h, "device"))
+    idx = torch.zeros((rows, k), dtype=torch.int32, device=dev)
+    sc = torch.zeros((rows, k), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((rows,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    if rows:
+        clib.predict_device(h, q, beam_size, post_processor, only_topk, idx.data_ptr(), sc.data_ptr(), cnt.data_ptr(), k, stream=None, sync=True)
+    return rows_to_csr(idx.cpu().numpy().view(np.uint32), sc.cpu().numpy(), cnt.cpu().numpy(), model.nr_pred_cols)
+
+
+def predict_text(vectorizer, models, corpus, X_emb=None, normalize_emb=True, threads=-1, **kwargs):
+    """The reference's text call sites with X DEVICE-RESIDENT end to end:
+
+    * ``Text2Text.predict`` (pecos/apps/text2text/model.py:416-422): ``X = preprocessor.predict(corpus); Y = [m.predict(X) ...]`` --
+      here the texts are tokenised on the host, their term counts uploaded once, weighted on the GPU, and every model of ``models``
+      (one XLinearModel or a list: the ensemble is averaged like ``CsrEnsembler.average``) searches that X in place;
+    * ``XTransformer.predict`` (pecos/xmc/xtransformer/model.py:589-603): with ``X_emb`` (float32 [rows, H] CUDA tensor, the encoder's
+      output) the concat model's input ``[X_feat | normalize(X_emb)]`` is assembled on the device as well.
+
+    kwargs: beam_size, only_topk, post_processor.  Returns the predicted label matrix as scipy CSR (rows score-sorted)."""
+    models = list(models) if isinstance(models, (list, tuple)) else [models]
+    outs = []
+    for m in models:
+        q = vectorizer.predict_device(m, corpus, threads=threads)
+        q2 = None
+        try:
+            if X_emb is not None:
+                import torch
+                assert X_emb.is_cuda and X_emb.dtype == torch.float32 and X_emb.shape[0] == len(corpus)
+                X_emb = X_emb.contiguous()
+                torch.cuda.current_stream().synchronize()
+                q2 = clib.queries_concat_handle(m.model.model_chain, q, X_emb.shape[1], X_emb.data_ptr(), normalize_emb=normalize_emb)
+            outs.append(_predict_handle_to_csr(m, q2 if q2 is not None else q, len(corpus), kwargs.get("beam_size"), kwargs.get("only_topk"), kwargs.get("post_processor")))
+        finally:
+            clib.queries_free(q)
+            if q2 is not None:
+                clib.queries_free(q2)
+    if len(outs) == 1:
+        return outs[0]
+    acc = outs[0].tocsr().copy()
+    for o in outs[1:]:
+        acc = acc + o
+    acc.data /= len(outs)                         # CsrEnsembler.average (pecos/utils/smat_util.py): the mean of the prediction matrices
+    return acc.tocsr()
