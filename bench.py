@@ -123,11 +123,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         log(f"WARNING: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    # N > 1 REHEARSAL on a one-GPU box (tests): XRL_BENCH_ONE_DEVICE=1 puts every rank on device 0 and XRL_BENCH_BACKEND=gloo exchanges the
+    # packed rows through host-staged tensors (RCCL refuses two ranks on one device) -- shard bounds, the double-buffered gather pipeline,
+    # max-over-ranks timing, timed-output parity on rows of every shard and rank 0's JSON line all run exactly as with N GPUs
+    backend = os.environ.get("XRL_BENCH_BACKEND", "nccl")
+    one_device = bool(os.environ.get("XRL_BENCH_ONE_DEVICE"))
+    gen_rank0 = local == 0                                   # who generates the synthetic workload on this node
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1 or os.environ.get("XRL_BENCH_FORCE_DIST"):   # the latter: exercise RCCL init + the gather with one rank (tests)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import xrl_synth
     from pecos_amd import XLinearModel, clib
@@ -139,7 +150,7 @@ def main():
     folder = os.path.join(args.cache, f"{args.config}_{args.scale}")
     done = os.path.join(folder, ".done")
     t0 = time.time()
-    if local == 0 and not os.path.exists(done):
+    if gen_rank0 and not os.path.exists(done):
         os.makedirs(folder, exist_ok=True)
         ks, X, cfg2 = xrl_synth.make_config(args.config, folder, scale=args.scale)
         if smat.issparse(X):
@@ -253,7 +264,7 @@ def main():
     dt = time.perf_counter() - t0
     clib.profile_enable(h, False)
     if use_dist and world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     prof = clib.profile_get(h)
@@ -293,7 +304,7 @@ def main():
         roof = roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_step)
         cfg_out = dict(workload=f"{args.config} synthetic x{args.scale}: N={n_total} D={Xs.shape[1]} L={ks[-1]} tree={ks} "
                                 f"nnz/row={nnz_row:.1f} beam={beam} topk={k} pp=l3-hinge bias=1.0",
-                       parallelism=f"query-shard x{world}" + (" + rccl all-gather of the packed top-k rows of step s on a second stream under the kernels of step s+1 (two result buffers)" if world > 1 else ""),
+                       parallelism=f"query-shard x{world}" + (f" + {'rccl' if backend == 'nccl' else backend + ' (host-staged REHEARSAL, all ranks on one device)'} all-gather of the packed top-k rows of step s on a second stream under the kernels of step s+1 (two result buffers)" if world > 1 else ""),
                        model_hbm_gb=round(clib.model_device_bytes(h) / 1e9, 3),
                        dense_format_layers=[l for l in range(depth) if linfo[l]["dense"]])
         out = dict(metric=baseline_metric(), value=round(value, 1), unit="queries/s", n_gpus=world,

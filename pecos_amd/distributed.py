@@ -97,6 +97,14 @@ class PackedTopk:
         if not dist.is_initialized():          # single process without a process group: nothing to exchange
             self.gathered[part][0].copy_(self.buf[part])
             return
+        if self.buf[part].is_cuda and dist.get_backend(group) == "gloo":
+            # host-staged exchange (the N > 1 rehearsal of bench.py on one GPU; gloo gathers CPU tensors only): the copy waits for
+            # everything queued on the current stream, i.e. for the step's kernels
+            host = self.buf[part].cpu()
+            chunks = [torch.empty_like(host) for _ in range(self.world)]
+            dist.all_gather(chunks, host, group=group)
+            self.gathered[part].copy_(torch.stack(chunks))
+            return
         try:                                   # (a one-rank group still runs the collective: tests exercise RCCL that way)
             dist.all_gather_into_tensor(self.gathered[part], self.buf[part], group=group)
         except (RuntimeError, NotImplementedError):  # backends without the fused form

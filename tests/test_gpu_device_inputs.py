@@ -227,6 +227,27 @@ def test_bench_step_under_rccl_one_rank(tmp_path):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
 
 
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_rehearsal_on_one_gpu(tmp_path):
+    # the whole N > 1 control flow of bench.py before the driver ever gets an 8-GPU node -- two ranks launched exactly as
+    # the driver launches them, both on device 0, packed rows exchanged through gloo (host-staged): nnz-balanced shard bounds, the
+    # double-buffered GatherPipeline, max-over-ranks timing, the timed output of BOTH shards compared with the reference, one JSON line
+    # from rank 0
+    env = dict(os.environ, XRL_BENCH_BACKEND="gloo", XRL_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29581", os.path.join(REPO, "bench.py"), "--gpus", "2", "--config", "eurlex-4k", "--scale", "0.5",
+           "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-host-abi", "--parity-rows", "1500", "--cache", str(tmp_path / "cache")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                  # rank 0 only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+    p = out["parity"]
+    assert p["timed_output_identical"] and p["timed_output_scores_bit_identical"] and "2 shard" in p["timed_output_sample"], p
+    assert "gloo" in out["config"]["parallelism"]
+
+
 def test_device_tfidf_weighting_vs_reference(manifest):
     # xrl_queries_tfidf_device: term counts on the device -> the reference's tf / idf / norm arithmetic -> query handle, read back and
     # compared with the output of the reference's own c_tfidf_predict (tests/golden/tfidf/): bit-identical (sublinear_tf: the
