@@ -83,12 +83,13 @@ def test_c_tfidf_predict_vs_reference_goldens(name, manifest):
 
 
 @pytest.mark.gpu
-def test_text_to_labels_device_resident(XLM, clib, oracle_mod, tmp_path):
+def test_text_to_labels_device_resident(oracle_mod, tmp_path):
     # Text2Text.predict's two lines (pecos/apps/text2text/model.py:416-417) with X device-resident: texts -> tf-idf on the GPU -> beam search in
     # place, against the reference doing both steps on the host (its own vectorizer output fed to the oracle / the compiled reference);
     # then the concat model's form (pecos/xmc/xtransformer/model.py:589-603) with a dense embedding block appended on the device
     import torch
     import xrl_synth
+    from pecos_amd import XLinearModel as XLM
     from pecos_amd.features import Tfidf, concat_features, predict_text
     folder, corpus, X = _case("word_bigram_trunc")
     vec = Tfidf.load(folder)
