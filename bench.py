@@ -387,7 +387,7 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
 
     def matched_bytes(name, layer):
         s, li = st[layer], linfo[layer]
-        if name.endswith("_rest") or name.startswith("k0b"):     # second phase of a bound-pruned layer: its (few) items are counted with the first phase's kernel
+        if name.endswith("_rest") or name.endswith("_mid") or name.startswith("k0b"):     # second phase of a bound-pruned layer: its (few) items are counted with the first phase's kernel
             return 0.0
         if name.startswith("k1q_fused"):                          # several dense-format layers in one launch: "k1q_fused[_x]_<first>_<last>"
             l0, l1 = (int(v) for v in name.split("_")[-2:])
@@ -437,8 +437,8 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
                             matched_gbps=round(mb / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0))
         # a bound-pruned layer runs a kernel twice (first beam slots, then the rest of the unfinished queries: "<name>_rest"); both count
         # as ONE launch of the family: time summed, work (counted for both phases together by the stats pass) attributed once
-        rest = r["name"].endswith("_rest")
-        f = fam.setdefault(r["name"][:-5] if rest else r["name"], dict(ms=0.0, launches=0, bytes=0.0, matched=0.0))
+        rest = r["name"].endswith("_rest") or r["name"].endswith("_mid")     # later stages of a bound-pruned layer
+        f = fam.setdefault(r["name"].rsplit("_", 1)[0] if rest else r["name"], dict(ms=0.0, launches=0, bytes=0.0, matched=0.0))
         f["ms"] += r["ms"]
         if not rest:
             f["launches"] += r["launches"]; f["bytes"] += hb * r["launches"]; f["matched"] += mb * r["launches"]

@@ -102,7 +102,9 @@ static int orc_cand_cmp(const void* a, const void* b) {
 /* weight_matrix_type HASH_CHUNKED with sparse X: chunk_ops<csr, hash_chunked> (inference.hpp:705-735) adds the bias row FIRST
  * and then the query's features in ascending order (the hash map only replaces the row lookup); set by the tests that pin
  * that layout.  Dense X under the hash layout walks the hash map in ITS order (:737-768) -- not restated. */
-static int orc_hash_arith = 0;
+/* thread-local: two OracleModel instances of different layouts driven from different threads -- pytest-xdist workers, bench.py's
+ * threaded parity check -- each set and read their own flag; the restatement itself is single-threaded. */
+static __thread int orc_hash_arith = 0;
 void orc_set_hash_arith(int on) { orc_hash_arith = on; }
 
 int orc_layer_predict(const orc_layer_t* L, uint32_t n_rows,

@@ -411,22 +411,39 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
 // shard's fixed-stride rows are copied to their place
 struct ShardOut { uint32_t r0, r1; const uint32_t* idx; const float* val; const uint32_t* cnt; };
 void emit_csr_shards(uint32_t rows, uint32_t cols, uint32_t stride, const std::vector<ShardOut>& sh, py_sparse_allocator_t alloc) {
-    std::vector<uint64_t> ptr((size_t)rows + 1);
-    ptr[0] = 0;
-    for (const ShardOut& s : sh) for (uint32_t r = s.r0; r < s.r1; ++r) ptr[r + 1] = ptr[r] + std::min(s.cnt[r - s.r0], stride);
-    const uint64_t nnz = ptr[rows];
+    // like emit_csr: nnz from partial sums (one per shard), then the row pointers are written straight into the allocator's array, every
+    // shard continuing from its partial sum, and all shards' rows are copied by one parallel pass over the global rows
+    double t0 = now_ms();
+    const size_t S = sh.size();
+    std::vector<uint64_t> part(S + 1, 0);
+    parallel_ranges(S, 1, [&](size_t sb, size_t se) {
+        for (size_t i = sb; i < se; ++i) { uint64_t a = 0; const ShardOut& s = sh[i]; for (uint32_t r = s.r0; r < s.r1; ++r) a += std::min(s.cnt[r - s.r0], stride); part[i + 1] = a; }
+    });
+    for (size_t i = 0; i < S; ++i) part[i + 1] += part[i];
+    const uint64_t nnz = part[S];
     uint32_t* o_idx = nullptr; uint64_t* o_ptr = nullptr; float* o_val = nullptr;
+    g_ht.prefix += now_ms() - t0; t0 = now_ms();
     alloc(false, rows, cols, nnz, &o_idx, &o_ptr, &o_val);
+    g_ht.alloc += now_ms() - t0; t0 = now_ms();
     if (!o_ptr || (nnz && (!o_idx || !o_val))) fail("allocator callback returned null buffers");
-    parallel_ranges((size_t)rows + 1, 1u << 16, [&](size_t b, size_t e) { std::memcpy(o_ptr + b, ptr.data() + b, (e - b) * 8); });
-    for (const ShardOut& s : sh)
-        parallel_ranges(s.r1 - s.r0, 1u << 15, [&](size_t b, size_t e) {
-            for (size_t r = b; r < e; ++r) {
-                const size_t g = s.r0 + r, n = (size_t)(ptr[g + 1] - ptr[g]);
-                std::memcpy(o_idx + ptr[g], s.idx + r * stride, n * 4);
-                std::memcpy(o_val + ptr[g], s.val + r * stride, n * 4);
-            }
-        });
+    o_ptr[0] = 0;
+    parallel_ranges(S, 1, [&](size_t sb, size_t se) {
+        for (size_t i = sb; i < se; ++i) { uint64_t run = part[i]; const ShardOut& s = sh[i]; for (uint32_t r = s.r0; r < s.r1; ++r) { run += std::min(s.cnt[r - s.r0], stride); o_ptr[r + 1] = run; } }
+    });
+    // shard of a global row: the shards are contiguous and ordered
+    std::vector<uint32_t> first(S);
+    for (size_t i = 0; i < S; ++i) first[i] = sh[i].r0;
+    parallel_ranges(rows, 1u << 15, [&](size_t b, size_t e) {
+        size_t i = (size_t)(std::upper_bound(first.begin(), first.end(), (uint32_t)b) - first.begin()) - 1;
+        for (size_t g = b; g < e; ++g) {
+            while (i + 1 < S && g >= sh[i + 1].r0) ++i;
+            const ShardOut& s = sh[i];
+            const size_t r = g - s.r0, n = (size_t)(o_ptr[g + 1] - o_ptr[g]);
+            std::memcpy(o_idx + o_ptr[g], s.idx + r * stride, n * 4);
+            std::memcpy(o_val + o_ptr[g], s.val + r * stride, n * 4);
+        }
+    });
+    g_ht.copy_out += now_ms() - t0;
 }
 
 // c_xlinear_predict_{csr,drm}_f32.  With replicas behind the handle (xrl_set_option "devices"): the rows are cut into nnz-balanced
@@ -505,7 +522,12 @@ void predict_host(void* ptr, const XT* input_x, uint32_t beam, const char* pp, u
         Workspace& ws = *(d == 0 ? m : *m.replicas[d - 1]).ws;
         sh.push_back(ShardOut{sb[d], sb[d + 1], ws.h_idx.as<uint32_t>(), ws.h_val.as<float>(), ws.h_cnt.as<uint32_t>()});
     }
+    g_ht = HostTimes{};                                       // (the shards' pipelines ran on their own threads: only the shared tail is timed here)
+    const double t_emit = now_ms();
     emit_csr_shards(rows, out_cols, k, sh, alloc);
+    if (host_timing())
+        std::fprintf(stderr, "[xrl host] rows=%u devices=%zu: result hand-off %.2f ms: row-pointer prefix %.2f | allocator callback %.2f | copy out %.2f\n",
+                     rows, R, now_ms() - t_emit, g_ht.prefix, g_ht.alloc, g_ht.copy_out);
 }
 
 HostCsc host_csc(const ScipyCscF32* M, const char* what) {
@@ -1035,8 +1057,13 @@ void* xrl_queries_tfidf_device(void* model, uint32_t rows, uint32_t cols, const 
         if (!d_out) q->val.reserve(nnz * 4);         // the handle owns the weighted values unless the caller supplies the buffer; row pointers and column ids stay the caller's
         float* dst = d_out ? d_out : q->val.as<float>();
         hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : m.stream;
-        launch_tfidf_weight(d_row_ptr, d_col_idx, d_count, d_idf, rows, cols, binary, sublinear_tf, norm_p, dst, s);
+        DevBuf d_err; d_err.reserve(4);
+        XRL_HIP(hipMemsetAsync(d_err.p, 0, 4, s));
+        launch_tfidf_weight(d_row_ptr, d_col_idx, d_count, d_idf, rows, cols, binary, sublinear_tf, norm_p, dst, s, 1, 0, d_err.as<uint32_t>());
+        uint32_t err = 0;
+        XRL_HIP(hipMemcpyAsync(&err, d_err.p, 4, hipMemcpyDeviceToHost, s));
         XRL_HIP(hipStreamSynchronize(s));
+        if (err) fail("xrl_queries_tfidf_device: a column id outside [0, cols) (the reference's idx_idf.at() throws)");
         q->dev.row_ptr = d_row_ptr; q->dev.col_idx = d_col_idx; q->dev.val = dst;
         q->dev.rows = rows; q->dev.cols = cols; q->dev.dense = 0; q->dev.nnz = nnz;
         out = q.release();
@@ -1227,6 +1254,7 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     else if (!std::strcmp(key, "max_batch_rows")) m.max_batch_rows = value;
     else if (!std::strcmp(key, "sort_min_tiles")) m.sort_min_tiles = (int)value;
     else if (!std::strcmp(key, "sort_rest")) m.sort_rest = (int)value;
+    else if (!std::strcmp(key, "prune_mid")) m.prune_mid = (int)value;
     else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;
     else if (!std::strcmp(key, "host_batch_mb")) m.host_batch_mb = (int)value;
     else if (!std::strcmp(key, "host_register")) m.host_register = (int)value;   // 1: page-lock the caller's X in place (hipHostRegister) instead of staging it through pinned buffers   // 0: the host ABI uploads X in one piece before computing
@@ -1263,7 +1291,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
                 use_device(dev);
                 std::unique_ptr<Model> r = m.src_kind == 0 ? load_model_from_disk(m.src_path, m.weight_matrix_type) : load_mmap_model_from_disk(m.src_path);
                 r->device = dev;
-                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->sort_rest = m.sort_rest; r->host_pipeline = m.host_pipeline; r->host_batch_mb = m.host_batch_mb; r->host_register = m.host_register;
+                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->sort_rest = m.sort_rest; r->prune_mid = m.prune_mid; r->host_pipeline = m.host_pipeline; r->host_batch_mb = m.host_batch_mb; r->host_register = m.host_register;
                 r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers;
                 r->overlap_min_rows = m.overlap_min_rows; r->prune = m.prune;
                 r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;

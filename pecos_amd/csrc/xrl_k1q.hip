@@ -59,6 +59,37 @@ struct K1QArgs {
     uint32_t* out_xok;                // non-null: the guard flag of every query is also written here (for a pruned tile-format layer that follows)
 };
 
+// the weight row of feature f as a raw buffer resource: base = wd + f * ld (scalar arithmetic), num_records = the row's bytes (a lane
+// offset past the row reads 0, never memory), dword 3 = the untyped 32-bit format word of gfx9-class buffer descriptors
+// (row_bytes = d_ld * 4 < 2^32: one 32 x 32 -> 64-bit scalar multiply per row)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t k1q_row_rsrc(const uint32_t* wd, uint32_t row_bytes, uint32_t f) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(wd) + (uint64_t)f * row_bytes), 0, (int)row_bytes, 0x00020000);
+}
+
+// A layer whose whole dense matrix is smaller than 4 GB keeps ONE resource (base = wd) and addresses a row through the instruction's
+// scalar offset, f * row_bytes: one scalar multiply per row instead of the 64-bit base arithmetic (Amazon-670K: levels 0-2; level 3,
+// 4.4 GB, rebuilds the base).  `small` is wavefront-uniform.
+struct K1QRows {
+    const uint32_t* wd; uint32_t row_bytes; bool small; __amdgpu_buffer_rsrc_t whole;
+    __device__ __forceinline__ K1QRows(const uint32_t* wd_, uint64_t d_ld, uint32_t w_rows) : wd(wd_), row_bytes((uint32_t)(d_ld * 4u)) {
+        const uint64_t total = ((uint64_t)w_rows + 1u) * row_bytes;
+        small = total < (1ull << 32);
+        whole = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wd_), 0, (int)(uint32_t)(small ? total : 0u), 0x00020000);
+    }
+};
+template <int N>
+__device__ __forceinline__ void k1q_load_row(const K1QRows& R, uint32_t f, const uint32_t (&voff)[N], uint32_t (&out)[N]) {
+    if (R.small) {
+        const uint32_t so = f * R.row_bytes;
+#pragma unroll
+        for (int r = 0; r < N; ++r) out[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(R.whole, (int)voff[r], (int)so, 0);
+    } else {
+        const __amdgpu_buffer_rsrc_t rs = k1q_row_rsrc(R.wd, R.row_bytes, f);
+#pragma unroll
+        for (int r = 0; r < N; ++r) out[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[r], 0, 0);
+    }
+}
+
 #ifndef XRL_K1Q_U1
 #define XRL_K1Q_U1 16
 #endif
@@ -114,26 +145,31 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     wave_sync_lds();                                                   // the beam has been read: the arrays may be overwritten below
 
     const uint32_t* __restrict__ wd = Ly.wd;
-    const uint64_t ld = Ly.d_ld;
+    const K1QRows rows(wd, Ly.d_ld, Ly.w_rows);
     const uint32_t w_rows = Ly.w_rows;
     uint32_t xmx = 0u, xn = 0u;                                        // pruning guard: largest |x| bits this lane has seen, features of the query
 
     // One pass over the query's features for the candidate registers [RB, RE): U features per batch, their U*(RE-RB) weight loads issued
-    // together (addresses depend only on the feature ids: scalar row base + this lane's column offset), then applied in feature order
+    // together, then applied in feature order.  Round 4 ("K1Q diet"):
+    //  * the (feature id, value) pairs of the query are read with SCALAR loads (the row is wavefront-uniform): no v_readlane broadcast;
+    //  * the weight row of a feature is a BUFFER resource (base = wd + f * ld, in SGPRs, rebuilt per feature with scalar arithmetic),
+    //    the lane's 32-bit byte offset its VGPR operand: no 64-bit vector address arithmetic;
+    //  * cells without a weight hold -0.0 (kMissing): with finite x the fast loop is `acc + x * w` for every cell (2 vector instructions
+    //    per (feature, register), packed in pairs by the compiler); a 64-feature chunk that holds a NON-FINITE x, and the last rows of X
+    //    (whose tail batch may not read past the array), run the exact loop, which skips cells on the marker like the reference's row walk.
     auto pass = [&](auto rb_tag, auto re_tag) {
         constexpr int RB = decltype(rb_tag)::value, RE = decltype(re_tag)::value, NR = RE - RB;
         constexpr int UU = K1QCfg<NR>::U;
-        auto batch = [&](uint32_t fv, uint32_t vbits, uint32_t t, uint32_t f_end) {
-            uint32_t wb[UU][NR]; float xs[UU];
+        uint32_t wofs[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) wofs[r] = woff[RB + r];
+        auto body = [&](auto exact_tag, const uint32_t (&fs)[UU], const float (&xs)[UU]) {
+            constexpr bool EX = decltype(exact_tag)::value;
+            uint32_t wb[UU][NR];
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
-                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)(t + (uint32_t)u));
-                xs[u] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)vbits, (int)(t + (uint32_t)u)));
-                // features outside the layer (and the padding lanes, f = 0xFFFFFFFF) read the all-kMissing row the model compiler
-                // appends after the last feature row: no separate "skip" state to carry
-                const char* __restrict__ row = reinterpret_cast<const char*>(wd + (uint64_t)min(f, f_end) * ld);
-#pragma unroll
-                for (int r = 0; r < NR; ++r) wb[u][r] = *reinterpret_cast<const uint32_t*>(row + woff[RB + r]);   // scalar base + 32-bit lane offset
+                // features outside the layer (and padding slots: fs = w_rows) read the all-missing row the model compiler appends
+                k1q_load_row<NR>(rows, min(fs[u], w_rows), wofs, wb[u]);
             }
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
@@ -141,43 +177,56 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                 for (int r = 0; r < NR; ++r) {
                     // scalar * val, then add: no fma (inference.hpp:512-517); no entry -> no operation
                     const float sm = __fadd_rn(acc[RB + r], __fmul_rn(xs[u], __uint_as_float(wb[u][r])));
-                    acc[RB + r] = (wb[u][r] == kMissing) ? acc[RB + r] : sm;
+                    acc[RB + r] = (EX && wb[u][r] == kMissing) ? acc[RB + r] : sm;
                 }
             }
         };
+        // the query's (feature, value) pairs: its CSR row (chunk_ops<csr, bin_search>, inference.hpp:769-813: ascending features), or every
+        // chunk row except the bias row with x gathered by row id (chunk_ops<drm, bin_search>, :815-839)
+        const uint32_t* __restrict__ fsrc = nullptr; const float* __restrict__ vsrc; uint32_t n; uint64_t room;
         if (DENSEX) {
-            // chunk_ops<drm, bin_search> (inference.hpp:815-839): every chunk row except the bias row, x gathered by row id
-            const float* __restrict__ xd = X.val + xrow * X.cols;
-            const uint32_t n_feat = Ly.has_bias ? w_rows - 1u : w_rows;
-            xn = n_feat;
-            for (uint32_t t0 = 0; t0 < n_feat; t0 += 64u) {
-                const uint32_t f = t0 + (uint32_t)lane;
-                const float xv = f < X.cols ? xd[f] : 0.0f;
-                xmx = max(xmx, __float_as_uint(xv) & 0x7FFFFFFFu);
-                const uint32_t fv = f < n_feat ? f : 0xFFFFFFFFu;
-                const uint32_t n = min(64u, n_feat - t0);
-                for (uint32_t t = 0; t < n; t += (uint32_t)UU) batch(fv, __float_as_uint(xv), t, w_rows);   // fv >= n_feat only on padding lanes (0xFFFFFFFF)
-            }
+            vsrc = X.val + xrow * X.cols;
+            n = Ly.has_bias ? w_rows - 1u : w_rows;
+            room = ((uint64_t)X.rows - xrow) * X.cols;                    // floats readable from vsrc[0]
         } else {
-            // chunk_ops<csr, bin_search> (inference.hpp:769-813): the query's features in ascending order
             const uint64_t xb = X.row_ptr[xrow];
-            const uint32_t xl = (uint32_t)(X.row_ptr[xrow + 1] - xb);
-            const uint32_t* __restrict__ xi = X.col_idx + xb;
-            const float* __restrict__ xv = X.val + xb;
-            uint32_t fv = 0xFFFFFFFFu, vb = 0u;
-            xn = xl;
-            if (xl) { const bool ok = (uint32_t)lane < xl; const uint32_t t = ok ? (uint32_t)lane : 0u; fv = ok ? xi[t] : 0xFFFFFFFFu; vb = __float_as_uint(xv[t]); }
-            for (uint32_t t0 = 0; t0 < xl; t0 += 64u) {
-                uint32_t fn = 0xFFFFFFFFu, vn = 0u;                          // next 64 features: in flight while this chunk is applied
-                if (t0 + 64u < xl) {
-                    const uint32_t tn = t0 + 64u + (uint32_t)lane;
-                    const bool ok = tn < xl; const uint32_t tc = ok ? tn : t0;
-                    fn = ok ? xi[tc] : 0xFFFFFFFFu; vn = __float_as_uint(xv[tc]);
+            n = (uint32_t)(X.row_ptr[xrow + 1] - xb);
+            fsrc = X.col_idx + xb; vsrc = X.val + xb;
+            room = X.nnz - xb;
+        }
+        xn = n;
+        for (uint32_t t0 = 0; t0 < n; t0 += 64u) {
+            const uint32_t nc = min(64u, n - t0);
+            // the chunk's values once per lane: the pruning guard's maximum, and "is every value finite"
+            const uint32_t vb = (uint32_t)lane < nc ? (__float_as_uint(vsrc[t0 + (uint32_t)lane]) & 0x7FFFFFFFu) : 0u;
+            xmx = max(xmx, vb);
+            const bool nonfinite = __ballot(vb >= 0x7F800000u) != 0ull;
+            for (uint32_t t = t0; t < t0 + nc; t += (uint32_t)UU) {
+                uint32_t fs[UU]; float xs[UU];
+                if (!nonfinite && t + (uint32_t)UU <= t0 + nc) {             // a full batch: plain uniform loads
+#pragma unroll
+                    for (int u = 0; u < UU; ++u) { fs[u] = DENSEX ? t + (uint32_t)u : fsrc[t + (uint32_t)u]; xs[u] = vsrc[t + (uint32_t)u]; }
+                    body(std::false_type{}, fs, xs);
+                } else if (!nonfinite && (uint64_t)t + (uint32_t)UU <= room) {  // the row's tail: the loads run on into the next row, the slots past the end are neutralised
+#pragma unroll
+                    for (int u = 0; u < UU; ++u) {
+                        const bool ok = t + (uint32_t)u < n;
+                        const uint32_t f = DENSEX ? t + (uint32_t)u : fsrc[t + (uint32_t)u];
+                        const float x = vsrc[t + (uint32_t)u];
+                        fs[u] = ok ? f : w_rows; xs[u] = ok ? x : 0.0f;
+                    }
+                    body(std::false_type{}, fs, xs);
+                } else {                                                      // non-finite x in the chunk, or the end of the X arrays: clamped loads, exact loop
+#pragma unroll
+                    for (int u = 0; u < UU; ++u) {
+                        const bool ok = t + (uint32_t)u < n;
+                        const uint32_t ic = ok ? t + (uint32_t)u : n - 1u;
+                        const uint32_t f = DENSEX ? ic : fsrc[ic];
+                        const float x = vsrc[ic];
+                        fs[u] = ok ? f : w_rows; xs[u] = ok ? x : 0.0f;
+                    }
+                    body(std::true_type{}, fs, xs);
                 }
-                const uint32_t n = min(64u, xl - t0);
-                xmx = max(xmx, vb & 0x7FFFFFFFu);                            // (lanes past the row's end hold one of its values again)
-                for (uint32_t t = 0; t < n; t += (uint32_t)UU) batch(fv, vb, t, w_rows);
-                fv = fn; vb = vn;
             }
         }
     };
@@ -264,42 +313,56 @@ __device__ __forceinline__ uint32_t k1q_layer01(const K1QLayer& L0, const K1QLay
     const uint32_t child1 = v1 ? cb + col : 0u;
     float acc1 = (BIASF && L1.has_bias && v1) ? L1.bias_prod[child1] : 0.0f;
 
-    // ---- one walk over the query's features, UU at a time: 2 * UU loads in flight
+    // ---- one walk over the query's features, UU at a time: 2 * UU loads in flight (scalar feature loads, buffer-resource rows, fast /
+    //      exact loops: see k1q_layer's pass)
     const uint32_t* __restrict__ wd0 = L0.wd; const uint32_t* __restrict__ wd1 = L1.wd;
-    const uint64_t ld0 = L0.d_ld, ld1 = L1.d_ld;
+    const K1QRows rows0(wd0, L0.d_ld, L0.w_rows), rows1(wd1, L1.d_ld, L1.w_rows);
     const uint32_t wr0 = L0.w_rows, wr1 = L1.w_rows;
     const uint64_t xb = X.row_ptr[xrow];
     const uint32_t xl = (uint32_t)(X.row_ptr[xrow + 1] - xb);
     const uint32_t* __restrict__ xi = X.col_idx + xb;
     const float* __restrict__ xv = X.val + xb;
-    uint32_t fv = 0xFFFFFFFFu, vb = 0u;
-    if (xl) { const bool ok = (uint32_t)lane < xl; const uint32_t t = ok ? (uint32_t)lane : 0u; fv = ok ? xi[t] : 0xFFFFFFFFu; vb = __float_as_uint(xv[t]); }
+    const uint64_t room = X.nnz - xb;
+    auto body = [&](auto exact_tag, const uint32_t (&fs)[UU], const float (&xs)[UU]) {
+        constexpr bool EX = decltype(exact_tag)::value;
+        uint32_t w0[UU], w1[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            { const uint32_t vo[1] = {woff0}; uint32_t o[1]; k1q_load_row<1>(rows0, min(fs[u], wr0), vo, o); w0[u] = o[0]; }
+            { const uint32_t vo[1] = {woff1}; uint32_t o[1]; k1q_load_row<1>(rows1, min(fs[u], wr1), vo, o); w1[u] = o[0]; }
+        }
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            const float s0 = __fadd_rn(acc0, __fmul_rn(xs[u], __uint_as_float(w0[u])));
+            acc0 = (EX && w0[u] == kMissing) ? acc0 : s0;
+            const float s1 = __fadd_rn(acc1, __fmul_rn(xs[u], __uint_as_float(w1[u])));
+            acc1 = (EX && w1[u] == kMissing) ? acc1 : s1;
+        }
+    };
     for (uint32_t t0 = 0; t0 < xl; t0 += 64u) {
-        uint32_t fn = 0xFFFFFFFFu, vn = 0u;
-        if (t0 + 64u < xl) {
-            const uint32_t tn = t0 + 64u + (uint32_t)lane;
-            const bool ok = tn < xl; const uint32_t tc = ok ? tn : t0;
-            fn = ok ? xi[tc] : 0xFFFFFFFFu; vn = __float_as_uint(xv[tc]);
-        }
-        const uint32_t n = min(64u, xl - t0);
-        for (uint32_t t = 0; t < n; t += (uint32_t)UU) {
-            uint32_t w0[UU], w1[UU]; float xs[UU];
+        const uint32_t nc = min(64u, xl - t0);
+        const uint32_t vb = (uint32_t)lane < nc ? (__float_as_uint(xv[t0 + (uint32_t)lane]) & 0x7FFFFFFFu) : 0u;
+        const bool nonfinite = __ballot(vb >= 0x7F800000u) != 0ull;
+        for (uint32_t t = t0; t < t0 + nc; t += (uint32_t)UU) {
+            uint32_t fs[UU]; float xs[UU];
+            if (!nonfinite && t + (uint32_t)UU <= t0 + nc) {
 #pragma unroll
-            for (int u = 0; u < UU; ++u) {
-                const uint32_t f = (uint32_t)__builtin_amdgcn_readlane((int)fv, (int)(t + (uint32_t)u));
-                xs[u] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)vb, (int)(t + (uint32_t)u)));
-                w0[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(wd0 + (uint64_t)min(f, wr0) * ld0) + woff0);
-                w1[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(wd1 + (uint64_t)min(f, wr1) * ld1) + woff1);
-            }
+                for (int u = 0; u < UU; ++u) { fs[u] = xi[t + (uint32_t)u]; xs[u] = xv[t + (uint32_t)u]; }
+                body(std::false_type{}, fs, xs);
+            } else if (!nonfinite && (uint64_t)t + (uint32_t)UU <= room) {
 #pragma unroll
-            for (int u = 0; u < UU; ++u) {
-                const float s0 = __fadd_rn(acc0, __fmul_rn(xs[u], __uint_as_float(w0[u])));
-                acc0 = (w0[u] == kMissing) ? acc0 : s0;
-                const float s1 = __fadd_rn(acc1, __fmul_rn(xs[u], __uint_as_float(w1[u])));
-                acc1 = (w1[u] == kMissing) ? acc1 : s1;
+                for (int u = 0; u < UU; ++u) { const bool ok = t + (uint32_t)u < xl; const uint32_t f = xi[t + (uint32_t)u]; const float x = xv[t + (uint32_t)u]; fs[u] = ok ? f : 0xFFFFFFFFu; xs[u] = ok ? x : 0.0f; }
+                body(std::false_type{}, fs, xs);
+            } else {
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    const bool ok = t + (uint32_t)u < xl; const uint32_t ic = ok ? t + (uint32_t)u : xl - 1u;
+                    const uint32_t f = xi[ic]; const float x = xv[ic];
+                    fs[u] = ok ? f : 0xFFFFFFFFu; xs[u] = ok ? x : 0.0f;
+                }
+                body(std::true_type{}, fs, xs);
             }
         }
-        fv = fn; vb = vn;
     }
     // ---- level 0: bias, transform (first layer: no combine), rank of every node in (value desc, position asc) order
     if (!BIASF && L0.has_bias && v0) acc0 = __fadd_rn(acc0, L0.bias_prod[child0]);
@@ -343,7 +406,10 @@ __device__ __forceinline__ uint32_t k1q_layer01(const K1QLayer& L0, const K1QLay
 // no spills; the exp-family post-processors would spill and keep the default): measured 6.57 vs 6.73 ms on Amazon-670K's levels 0-3; 8 (64 VGPRs, 8 spilled) loses, and so does any target
 // on the wide single-layer kernels.
 template <int NSMAX, int PPC, bool DENSEX, bool MULTI, bool BIASF>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI && NSMAX <= 3 && PPC == 0) ? 7 : 1, 8))) k1q_kernel(K1QArgs a) {
+#ifndef XRL_K1Q_WPE
+#define XRL_K1Q_WPE 8    // round 4: 8 wavefronts per SIMD (64 VGPRs) -- the buffer-resource loads need no 64-bit vector addresses; 4.42 -> 4.14 ms on Amazon-670K
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI && NSMAX <= 3 && PPC == 0) ? XRL_K1Q_WPE : 1, 8))) k1q_kernel(K1QArgs a) {
     __shared__ uint2 sc_all[4 * 64];
     __shared__ uint32_t bidx_all[4 * 64];
     __shared__ float bval_all[4 * 64];
@@ -480,7 +546,8 @@ densify_kernel(const uint64_t* __restrict__ col_ptr, const uint32_t* __restrict_
     if (c >= n_children) return;
     const uint32_t oc = src_col[c], off = dst_off[c];
     const uint64_t e0 = col_ptr[oc], e1 = col_ptr[oc + 1];
-    for (uint64_t e = e0 + (threadIdx.x & 63u); e < e1; e += 64u) wd[(uint64_t)row_idx[e] * ld + off] = __float_as_uint(val[e]);
+    // (an explicit -0.0 would read as "no entry": stored as +0.0 -- x * (+-0.0) leaves an accumulator unchanged either way)
+    for (uint64_t e = e0 + (threadIdx.x & 63u); e < e1; e += 64u) { const uint32_t b = __float_as_uint(val[e]); wd[(uint64_t)row_idx[e] * ld + off] = b == kMissing ? 0u : b; }
 }
 
 void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,

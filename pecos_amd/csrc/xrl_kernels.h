@@ -46,7 +46,7 @@ void launch_k0_prolongate(const LayerDev& L, const LayerPlan& P, const QueriesDe
                           uint32_t* ncand, void* items, hipStream_t s, uint32_t item_ranks = 0xFFFFFFFFu /* beam slots that get item descriptors */);
 // bound-pruned layers, second phase: items of the beam slots >= first_rank of the queries with done[q] == 0, compact; *n_items = their number
 void launch_k0b_remaining(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* done,
-                          uint32_t first_rank, void* items, uint32_t* n_items, hipStream_t s);
+                          uint32_t first_rank, void* items, uint32_t* n_items, hipStream_t s, uint32_t end_rank = 0xFFFFFFFFu);   // beam slots [first_rank, end_rank)
 bool k2_wave_path(const LayerPlan& P);   // the register top-k kernel serves this layer (what bound pruning needs)
 size_t k0_item_bytes();
 // K1  (query, tile) inner products + bias + post-processor + combine, one item per G lanes.

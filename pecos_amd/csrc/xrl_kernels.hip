@@ -93,14 +93,14 @@ size_t k0_item_bytes() { return sizeof(ItemDesc); }
 // prove its top-k final (done[q] == 0), appended to a compact list (one atomicAdd per wavefront).
 __global__ void __launch_bounds__(256)
 k0b_remaining(const uint32_t* __restrict__ chunk_col, const uint32_t* __restrict__ ptile, const TileDesc* __restrict__ tiles,
-              uint32_t nrows, uint32_t beam_in, uint32_t first_rank, uint32_t cand_stride, const uint32_t* __restrict__ p_idx,
+              uint32_t nrows, uint32_t beam_in, uint32_t first_rank, uint32_t end_rank, uint32_t cand_stride, const uint32_t* __restrict__ p_idx,
               const float* __restrict__ p_val, const uint32_t* __restrict__ p_cnt, uint32_t p_stride, const uint32_t* __restrict__ cand_off,
               const uint32_t* __restrict__ done, ItemDesc* __restrict__ items, uint32_t* __restrict__ n_items,
               const uint64_t* __restrict__ x_row_ptr) {
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool live = q < nrows && !done[q];
-    const uint32_t cnt = live ? min(p_cnt[q], beam_in) : 0u;
+    const uint32_t cnt = live ? min(min(p_cnt[q], beam_in), end_rank) : 0u;      // slots [first_rank, end_rank) of the unfinished queries
     uint32_t n = 0;
     for (uint32_t j = first_rank; j < cnt; ++j) { const uint32_t parent = p_idx[(size_t)q * p_stride + j]; n += ptile[parent + 1] - ptile[parent]; }
     uint32_t incl = n;
@@ -124,10 +124,10 @@ k0b_remaining(const uint32_t* __restrict__ chunk_col, const uint32_t* __restrict
 }
 
 void launch_k0b_remaining(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, BeamDev prev, const uint32_t* cand_off, const uint32_t* done,
-                          uint32_t first_rank, void* items, uint32_t* n_items, hipStream_t s) {
+                          uint32_t first_rank, void* items, uint32_t* n_items, hipStream_t s, uint32_t end_rank) {
     if (P.nrows == 0) return;
     XRL_HIP(hipMemsetAsync(n_items, 0, 4, s));
-    hipLaunchKernelGGL(k0b_remaining, dim3((P.nrows + 255) / 256), dim3(256), 0, s, L.chunk_col, L.ptile, L.tiles, P.nrows, P.beam_in, first_rank,
+    hipLaunchKernelGGL(k0b_remaining, dim3((P.nrows + 255) / 256), dim3(256), 0, s, L.chunk_col, L.ptile, L.tiles, P.nrows, P.beam_in, first_rank, end_rank,
                        P.cand_stride, prev.idx, prev.val, prev.cnt, prev.stride, cand_off, done, static_cast<ItemDesc*>(items), n_items,
                        X.dense ? nullptr : X.row_ptr + P.row0);
     XRL_LAUNCH_CHECK();

@@ -425,15 +425,11 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     {
         const char* de = std::getenv("XRL_DENSE");
         bool want = !(de && de[0] == '0') && c_nnz > 0 && W.rows > 0 && !structure_only;
-        // a column with duplicate or unsorted row ids cannot be scattered into one cell per (feature, column); neither can a
-        // weight whose bit pattern is the "no entry" marker itself (a NaN with that payload): such a layer stays in the tile format
+        // a column with duplicate or unsorted row ids cannot be scattered into one cell per (feature, column): such a layer stays in the
+        // tile format.  (A weight whose bits equal the "no entry" marker -- an explicit -0.0 -- is stored as +0.0 by densify_kernel.)
         for (uint32_t c = 0; want && c < W.cols; ++c)
             for (uint64_t e = W.col_ptr[c] + 1; e < W.col_ptr[c + 1]; ++e)
                 if (W.row_idx[e] <= W.row_idx[e - 1]) { want = false; break; }
-        if (want) {
-            const uint64_t wn = W.col_ptr[W.cols];
-            for (uint64_t e = 0; e < wn; ++e) { uint32_t b; std::memcpy(&b, &W.val[e], 4); if (b == kMissing) { want = false; break; } }
-        }
         if (want) {
             const uint32_t wide = L->max_chunk_cols;
             uint32_t gp = 1;

@@ -29,7 +29,10 @@ namespace xrl {
 
 constexpr uint32_t kMaxTileCols = 128;       // accumulators per (query, tile) item held in LDS
 constexpr uint32_t kNoBias = 0xFFFFFFFFu;
-constexpr uint32_t kMissing = 0x7FA5A5A5u;   // dense row format: "W has no entry here" (a signalling-NaN pattern no weight file holds)
+constexpr uint32_t kMissing = 0x80000000u;   // dense row format: "W has no entry here" = -0.0.  For finite x the product x * (-0.0) is a zero, which leaves every
+                                             // reachable accumulator unchanged (accumulators are never -0.0: they start at +0.0 or +0.0 + bias*w, and a + (-a) rounds
+                                             // to +0.0), so the kernels' fast loops multiply and add it like any weight; only a non-finite x needs the
+                                             // "is there an entry" test.  An explicit -0.0 stored in W is written as +0.0 (densify_kernel): same products.
 
 enum PPKind : int { PP_NOOP = 0, PP_SIGMOID = 1, PP_LOG_SIGMOID = 2, PP_LP_HINGE = 3, PP_LOG_LP_HINGE = 4 };
 struct PostProc { int kind = PP_NOOP; int p = 0; };
@@ -172,6 +175,7 @@ struct Model {
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
     int k1q_fuse = 3;                       // consecutive dense-format layers of <= this many candidate registers (1..3) share one K1Q launch (the beam stays in LDS); 0: one launch per layer
     int k1g_min_items = 16;                 // dense X: run a dense-format layer as the tiled SGEMM K1G once a parent serves this many queries on average (0 = never)
+    int prune_mid = 1;                      // bound-pruned tile-format layers with >= 16 beam parents: a middle stage (slots 1..4) between the first parent and "everything else"
     int sort_rest = 1;                      // bound-pruned tile-format layers: the second phase's compacted items are tile-sorted before K1 runs on them (0: query order)
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
     // multi-GPU behind the drop-in entry points (xrl_set_option "devices"): further copies of the compiled model on other devices; the

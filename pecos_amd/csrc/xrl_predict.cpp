@@ -18,6 +18,12 @@ size_t profile_slot(Model& m, const char* name, uint32_t layer) {
 }
 }  // namespace
 
+// dense-X SGEMM layers, bound pruning: beam slots whose children fill about one candidate register (64) are scored first -- never all of
+// them (the second stage must keep at least one slot)
+static uint32_t k1g_first_slots(const Layer& L, uint32_t beam_in) {
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(beam_in > 1 ? beam_in - 1 : 1, 64 / std::max<uint64_t>(1, L.cand_bound(1))));
+}
+
 uint32_t effective_topk(const Model& m, uint32_t only_topk) {
     return only_topk ? only_topk : m.layers.back()->only_topk;   // inference.hpp:2055
 }
@@ -208,7 +214,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 //      then a second, tile-sorted GEMM over the remaining slots of the queries whose top-k is not final yet.  J covers about
                 //      one candidate register (64 candidates), like K1Q's first stage.
                 if (m.prune && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P)) {
-                    const uint32_t J = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(beam_in[l] - 1, 64 / std::max<uint64_t>(1, L.cand_bound(1))));
+                    const uint32_t J = k1g_first_slots(L, beam_in[l]);
                     const uint64_t slots_a = (uint64_t)nrows * J * L.max_tiles_per_parent, slots_b = (uint64_t)nrows * (beam_in[l] - J) * L.max_tiles_per_parent;
                     lw.prune_done.reserve((size_t)nb * 4); lw.prune_cnt.reserve(256);
                     LayerPlan PA = P; PA.beam_in = J;
@@ -273,7 +279,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 // that the work it counts is the work the timed kernels evaluate (K1G: J parents first; K1Q: the parents of candidate
                 // register 0 first, nothing skipped when the whole beam fits one register)
                 const bool dense_x = X.dense != 0 || m.dense_layers >= 2;
-                if (mode == 3) J = (uint32_t)std::max<uint64_t>(1, 64 / std::max<uint64_t>(1, L.cand_bound(1)));
+                if (mode == 3) J = k1g_first_slots(L, beam_in[l]);      // (the SAME staging the timed K1G path uses: ADVICE r3)
                 else if (m.dense_layers && k1q_regs(L.dev, beam_in[l], k[l], dense_x) != 0) {
                     if (k1q_regs(L.dev, beam_in[l], k[l], dense_x) <= 1) pruned = false;
                     else J = std::max<uint32_t>(1, (64u >> L.dev.d_gp_log2) / std::max<uint32_t>(1, L.dev.d_max_tiles));
@@ -281,13 +287,19 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 if (J >= beam_in[l]) pruned = false;
             } else if (mode != 0) pruned = false;
             if (pruned) {
+                // stages of beam slots: [0, J) first, then -- wide beams only (>= 16 parents: Wiki10-31K's 20) -- a MIDDLE stage [J, J2) before
+                // "everything else": with 20 parents of ~60 children and k = 20 the first parent alone rarely settles the top-k, the first
+                // five usually do, and the last stage then sees few queries.  Every stage: k0b (the unfinished queries' items of its slots) ->
+                // sort -> K1 -> K2 over the candidates of all slots scored so far (+ the done flag for the next stage).
+                uint32_t stage_end[3]; int n_stage = 0;
+                stage_end[n_stage++] = J;
+                if (m.prune_mid != 0 && beam_in[l] >= 16u && !o.stats_out) stage_end[n_stage++] = std::min<uint32_t>(beam_in[l] - 1u, J + 4u);
+                stage_end[n_stage++] = beam_in[l];
                 const uint64_t slots_b = (uint64_t)nrows * (beam_in[l] - J) * L.max_tiles_per_parent;
                 lw.prune_done.reserve((size_t)nb * 4); lw.prune_cnt.reserve(256);
                 lw.items_sorted.reserve(slots_max * k0_item_bytes());
-                LayerPlan PA = P; PA.beam_in = J;                  // (K1 sizes its grid from beam_in x tiles per parent)
-                LayerPlan PB = P; PB.beam_in = beam_in[l] - J;
                 need_x_ok();
-                PB.tune.wpb = 4;                                   // the second phase's grid is sized for "nothing pruned": mostly empty wavefronts, 4 per workgroup to dispatch fewer groups
+                LayerPlan PA = P; PA.beam_in = J;                  // (K1 sizes its grid from beam_in x tiles per parent)
                 timed("k0_prolongate", (uint32_t)l, [&] { launch_k0_prolongate(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.items.p, S, J); });
                 if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));
                 timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] { launch_k1(L.dev, PA, X, lw.items.p, nullptr, lw.cand.as<float>(), g, S); });
@@ -295,19 +307,30 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                                                                    J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr, lw.x_ok.as<uint32_t>()); });
                 if (o.stats_out) XRL_HIP(hipMemsetAsync(lw.items_sorted.p, 0xFF, slots_b * k0_item_bytes(), S));   // the stats pass walks the whole list: unused slots read as "no tile"
                 const bool srt = sorts_rest(l);
-                // (sorted: the compacted list goes where the first phase's items were -- K1 has consumed them -- and is sorted into items_sorted)
-                timed("k0b_remaining", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), J, srt ? lw.items.p : lw.items_sorted.p,
-                                                                               lw.prune_cnt.as<uint32_t>(), S); });
-                if (srt) timed("k1_sort_items_rest", (uint32_t)l, [&] { launch_sort_items(L.dev, slots_b, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S,
-                                                                                         lw.prune_cnt.as<uint32_t>()); });
-                timed(X.dense ? "k1_dense_rest" : "k1_sparse_rest", (uint32_t)l, [&] { launch_k1(L.dev, PB, X, lw.items_sorted.p, srt ? lw.sort_start.as<uint32_t>() + L.n_tiles : lw.prune_cnt.as<uint32_t>(),
-                                                                                                 lw.cand.as<float>(), g, S); });
-                if (lanes == 2) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
-                timed("k2_topk_rest", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
-                                                                        0, 0, nullptr, lw.prune_done.as<uint32_t>()); });
-                if (o.stats_out) {
-                    launch_stats(L.dev, P, X, prev, lw.ncand.as<uint32_t>(), lw.items.p, ws.stats.as<double>() + kStatsPerLayer * l, S, (uint64_t)nrows * J * L.max_tiles_per_parent);
-                    launch_stats(L.dev, PB, X, prev, nullptr, lw.items_sorted.p, ws.stats.as<double>() + kStatsPerLayer * l, S, slots_b);
+                for (int st = 1; st < n_stage; ++st) {
+                    const uint32_t r0 = stage_end[st - 1], r1 = stage_end[st];
+                    const bool last = st == n_stage - 1;
+                    const uint64_t slots_s = (uint64_t)nrows * (r1 - r0) * L.max_tiles_per_parent;
+                    LayerPlan PB = P; PB.beam_in = r1 - r0;
+                    PB.tune.wpb = 4;                               // a later stage's grid is sized for "nothing pruned": mostly empty wavefronts, 4 per workgroup to dispatch fewer groups
+                    const char* sfx = last ? "_rest" : "_mid";
+                    // (sorted: the compacted list goes where the first phase's items were -- K1 has consumed them -- and is sorted into items_sorted)
+                    timed(last ? "k0b_remaining" : "k0b_remaining_mid", (uint32_t)l, [&] { launch_k0b_remaining(L.dev, P, X, prev, lw.cand_off.as<uint32_t>(), lw.prune_done.as<uint32_t>(), r0,
+                                                                                                                 srt ? lw.items.p : lw.items_sorted.p, lw.prune_cnt.as<uint32_t>(), S, r1); });
+                    if (srt) timed((std::string("k1_sort_items") + sfx).c_str(), (uint32_t)l, [&] { launch_sort_items(L.dev, slots_s, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(),
+                                                                                                                      lw.sort_start.as<uint32_t>(), S, lw.prune_cnt.as<uint32_t>()); });
+                    timed((std::string(X.dense ? "k1_dense" : "k1_sparse") + sfx).c_str(), (uint32_t)l, [&] {
+                        launch_k1(L.dev, PB, X, lw.items_sorted.p, srt ? lw.sort_start.as<uint32_t>() + L.n_tiles : lw.prune_cnt.as<uint32_t>(), lw.cand.as<float>(), g, S); });
+                    if (lanes == 2 && last) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
+                    // (a middle stage selects among the slots scored so far and renews the done flags; queries finished earlier are skipped: one buffer serves both)
+                    if (last) timed("k2_topk_rest", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
+                                                                                      0, 0, nullptr, lw.prune_done.as<uint32_t>()); });
+                    else timed("k2_topk_mid", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
+                                                                                 r1, (uint32_t)L.cand_bound(r1), lw.prune_done.as<uint32_t>(), lw.prune_done.as<uint32_t>(), lw.x_ok.as<uint32_t>()); });
+                    if (o.stats_out && last) {
+                        launch_stats(L.dev, P, X, prev, lw.ncand.as<uint32_t>(), lw.items.p, ws.stats.as<double>() + kStatsPerLayer * l, S, (uint64_t)nrows * J * L.max_tiles_per_parent);
+                        launch_stats(L.dev, PB, X, prev, nullptr, lw.items_sorted.p, ws.stats.as<double>() + kStatsPerLayer * l, S, slots_b);
+                    }
                 }
                 continue;
             }
