@@ -66,30 +66,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t k1q_row_rsrc(const uint32_t* w
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(wd) + (uint64_t)f * row_bytes), 0, (int)row_bytes, 0x00020000);
 }
 
-// A layer whose whole dense matrix is smaller than 4 GB keeps ONE resource (base = wd) and addresses a row through the instruction's
-// scalar offset, f * row_bytes: one scalar multiply per row instead of the 64-bit base arithmetic (Amazon-670K: levels 0-2; level 3,
-// 4.4 GB, rebuilds the base).  `small` is wavefront-uniform.
-struct K1QRows {
-    const uint32_t* wd; uint32_t row_bytes; bool small; __amdgpu_buffer_rsrc_t whole;
-    __device__ __forceinline__ K1QRows(const uint32_t* wd_, uint64_t d_ld, uint32_t w_rows) : wd(wd_), row_bytes((uint32_t)(d_ld * 4u)) {
-        const uint64_t total = ((uint64_t)w_rows + 1u) * row_bytes;
-        small = total < (1ull << 32);
-        whole = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wd_), 0, (int)(uint32_t)(small ? total : 0u), 0x00020000);
-    }
-};
-template <int N>
-__device__ __forceinline__ void k1q_load_row(const K1QRows& R, uint32_t f, const uint32_t (&voff)[N], uint32_t (&out)[N]) {
-    if (R.small) {
-        const uint32_t so = f * R.row_bytes;
-#pragma unroll
-        for (int r = 0; r < N; ++r) out[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(R.whole, (int)voff[r], (int)so, 0);
-    } else {
-        const __amdgpu_buffer_rsrc_t rs = k1q_row_rsrc(R.wd, R.row_bytes, f);
-#pragma unroll
-        for (int r = 0; r < N; ++r) out[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[r], 0, 0);
-    }
-}
-
+// (Measured and rejected, profiles/r04_k1q_diet.md: ONE resource per layer with the row selected by the instruction's scalar offset --
+//  2 scalar instructions per row instead of 6 for matrices under 4 GB -- needs both forms in the kernel (level 3 is 4.4 GB); the second
+//  code path cost 168 SGPR spills at 8 wavefronts per SIMD: 4.64 vs 4.13 ms on Amazon-670K.)
 #ifndef XRL_K1Q_U1
 #define XRL_K1Q_U1 16
 #endif
@@ -145,7 +124,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     wave_sync_lds();                                                   // the beam has been read: the arrays may be overwritten below
 
     const uint32_t* __restrict__ wd = Ly.wd;
-    const K1QRows rows(wd, Ly.d_ld, Ly.w_rows);
+    const uint32_t ld = (uint32_t)(Ly.d_ld * 4u);                       // bytes per feature row
     const uint32_t w_rows = Ly.w_rows;
     uint32_t xmx = 0u, xn = 0u;                                        // pruning guard: largest |x| bits this lane has seen, features of the query
 
@@ -160,16 +139,15 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     auto pass = [&](auto rb_tag, auto re_tag) {
         constexpr int RB = decltype(rb_tag)::value, RE = decltype(re_tag)::value, NR = RE - RB;
         constexpr int UU = K1QCfg<NR>::U;
-        uint32_t wofs[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) wofs[r] = woff[RB + r];
         auto body = [&](auto exact_tag, const uint32_t (&fs)[UU], const float (&xs)[UU]) {
             constexpr bool EX = decltype(exact_tag)::value;
             uint32_t wb[UU][NR];
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
                 // features outside the layer (and padding slots: fs = w_rows) read the all-missing row the model compiler appends
-                k1q_load_row<NR>(rows, min(fs[u], w_rows), wofs, wb[u]);
+                const __amdgpu_buffer_rsrc_t rs = k1q_row_rsrc(wd, ld, min(fs[u], w_rows));
+#pragma unroll
+                for (int r = 0; r < NR; ++r) wb[u][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)woff[RB + r], 0, 0);
             }
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
@@ -316,7 +294,7 @@ __device__ __forceinline__ uint32_t k1q_layer01(const K1QLayer& L0, const K1QLay
     // ---- one walk over the query's features, UU at a time: 2 * UU loads in flight (scalar feature loads, buffer-resource rows, fast /
     //      exact loops: see k1q_layer's pass)
     const uint32_t* __restrict__ wd0 = L0.wd; const uint32_t* __restrict__ wd1 = L1.wd;
-    const K1QRows rows0(wd0, L0.d_ld, L0.w_rows), rows1(wd1, L1.d_ld, L1.w_rows);
+    const uint32_t ld0 = (uint32_t)(L0.d_ld * 4u), ld1 = (uint32_t)(L1.d_ld * 4u);   // bytes per feature row
     const uint32_t wr0 = L0.w_rows, wr1 = L1.w_rows;
     const uint64_t xb = X.row_ptr[xrow];
     const uint32_t xl = (uint32_t)(X.row_ptr[xrow + 1] - xb);
@@ -328,8 +306,8 @@ __device__ __forceinline__ uint32_t k1q_layer01(const K1QLayer& L0, const K1QLay
         uint32_t w0[UU], w1[UU];
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
-            { const uint32_t vo[1] = {woff0}; uint32_t o[1]; k1q_load_row<1>(rows0, min(fs[u], wr0), vo, o); w0[u] = o[0]; }
-            { const uint32_t vo[1] = {woff1}; uint32_t o[1]; k1q_load_row<1>(rows1, min(fs[u], wr1), vo, o); w1[u] = o[0]; }
+            w0[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(k1q_row_rsrc(wd0, ld0, min(fs[u], wr0)), (int)woff0, 0, 0);
+            w1[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(k1q_row_rsrc(wd1, ld1, min(fs[u], wr1)), (int)woff1, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
