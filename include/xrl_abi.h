@@ -291,6 +291,10 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *   "k1_group"            lanes per (query, tile) item in K1: 0 = auto, else a power of two <= 64
  *   "max_batch_rows"      rows of X per internal batch (0 = auto: candidate buffer <= 6 GiB)
  *   "sort_min_tiles"      tile-sort the items of layers with at least this many tiles (0 = never)
+ *   "adaptive"            1 (default): PRUNING FEEDBACK -- the handle remembers, per layer, what the first stage of the bound pruning achieved on its
+ *                         previous predicts (sampled device counters / the later stage's item count, read back without any synchronisation);
+ *                         a layer whose first stage settled fewer than ~35 % of the queries runs UNSTAGED on the following predicts (every
+ *                         candidate in one pass; tile format: on tile-sorted items) and is probed again every 32nd predict; 0: always staged
  *   "prune_mid"           1 (default): bound-pruned tile-format layers entered with >= 16 beam parents score slots 1..4 in a MIDDLE stage before
  *                         "every remaining slot" (three stages instead of two; Wiki10-31K's beam of 20); 0: two stages
  *   "sort_rest"           1 (default): the second phase of a bound-pruned tile-format layer runs on tile-sorted items (counting sort of the

@@ -44,6 +44,7 @@ struct K1QLayer {
     int has_bias, pp_kind, pp_p, first_layer, implicit_root;
     int prune;                        // exact bound pruning: score the first candidate register before requesting the others' weights
     int bias_first;                   // sparse X, HASH_CHUNKED arithmetic (inference.hpp:705-735): bias before the features, like dense X
+    int layer_id;                     // index in the chain: the layer's slot in the pruning feedback counters
 };
 constexpr int kK1QMaxLayers = 8;
 
@@ -57,6 +58,8 @@ struct K1QArgs {
     uint32_t row0, nrows;
     float prune_wmax;                 // the model's largest |weight| x max(1, |bias|): the pruning guard (prune_guard_ok, xrl_device.h)
     uint32_t* out_xok;                // non-null: the guard flag of every query is also written here (for a pruned tile-format layer that follows)
+    uint32_t* fb_dev; uint32_t* fb_host;   // pruning feedback: sampled counters per layer {staged queries, of them: second pass needed} (device atomics);
+                                      // the first wavefront of a launch copies what earlier launches counted to the host-visible words
 };
 
 // the weight row of feature f as a raw buffer resource: base = wd + f * ld (scalar arithmetic), num_records = the row's bytes (a lane
@@ -85,7 +88,7 @@ template <int NS> struct K1QCfg {
 // last -- a compile-time switch: as a run-time one it cost the widest kernel 8 VGPRs and a wavefront per SIMD
 template <int NS, int PPC, bool DENSEX, bool BIASF>
 __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesDev& X, uint64_t xrow, uint32_t cnt_in,
-                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane, float wmax) {
+                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane, float wmax, uint32_t* fb) {
     // ---- prolongate: which (parent, dense tile, column) does each of this lane's candidates stand for
     const uint32_t gl = Ly.d_gp_log2, gmask = (1u << gl) - 1u, TT = Ly.d_max_tiles;
     const uint32_t cnt = Ly.implicit_root ? 1u : min(cnt_in, Ly.beam_in);
@@ -231,7 +234,9 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         const uint32_t cge = (uint32_t)__popcll(__ballot(valid[0] && v0 >= ps_next));
         // (the guard: a query that could produce a NaN score -- non-finite or huge x, non-finite weights -- is never pruned)
         const bool xok = prune_guard_ok(wave_max_u32(xmx), xn, wmax);
-        if (!prune_all_in_first && (cge < Ly.k || !xok)) {
+        const bool second = !prune_all_in_first && (cge < Ly.k || !xok);
+        if (fb && lane == 0 && !prune_all_in_first) { atomicAdd(&fb[2 * Ly.layer_id], 1u); if (second) atomicAdd(&fb[2 * Ly.layer_id + 1], 1u); }
+        if (second) {
             pass(std::integral_constant<int, (NS > 1 ? 1 : 0)>{}, std::integral_constant<int, NS>{});
 #pragma unroll
             for (int r = 1; r < NS; ++r) finish(r);
@@ -406,20 +411,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI
     }
     wave_sync_lds();
     const uint64_t xrow = (uint64_t)a.row0 + q;
+    // pruning feedback: one query in 64 counts (device atomics); query 0 publishes what the earlier launches counted
+    uint32_t* fb = (a.fb_dev && (q & 63u) == 0u) ? a.fb_dev : nullptr;
+    if (a.fb_dev && a.fb_host && q == 0u && lane < 32) a.fb_host[lane] = a.fb_dev[lane];
     int l_first = 0;
     if (MULTI && !DENSEX && a.fuse01) { cnt = k1q_layer01<PPC, BIASF>(a.layer[0], a.layer[1], a.X, xrow, s_bidx, s_bval, sc, lane); l_first = 2; }
     for (int l = l_first; l < (MULTI ? a.n_layers : 1); ++l) {
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
-        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
-        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
-        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
-        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
-        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
-        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
-        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
-        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax);
+        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
+        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
+        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
+        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
+        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
+        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
+        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
+        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
     }
     if ((uint32_t)lane < cnt) {
         const size_t o = (size_t)q * a.out_stride + (uint32_t)lane;
@@ -478,6 +486,7 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
         y.d_gp_log2 = L.d_gp_log2; y.d_max_tiles = L.d_max_tiles; y.n_parents = L.n_parents; y.w_rows = L.w_rows;
         y.beam_in = P.beam_in; y.k = P.k; y.ns = k1q_bucket(ns);
         y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root; y.bias_first = P.bias_first; y.prune = P.prune;
+        y.layer_id = (P.layer >= 0 && P.layer < 16) ? P.layer : 0;
         nsmax = std::max(nsmax, y.ns); ppc |= pp_class(P.pp);
     }
     a.n_layers = n; a.X = X;
@@ -493,6 +502,7 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     a.out_idx = out_idx; a.out_val = out_val; a.out_cnt = out_cnt; a.out_stride = out_stride;
     a.row0 = Ps[0].row0; a.nrows = Ps[0].nrows;
     a.prune_wmax = prune_wmax; a.out_xok = out_xok;
+    a.fb_dev = Ps[0].fb_dev; a.fb_host = Ps[0].fb_host;
     const dim3 grid((a.nrows + 3u) / 4u), block(256);
     const bool bias_first = Ps[0].bias_first != 0;
 #define XRL_K1Q_M(NN, MM) do { \

@@ -36,8 +36,10 @@ struct LayerPlan {
     int prune;                  // exact bound pruning allowed (Model::prune)
     int bias_first;             // sparse X under weight_matrix_type HASH_CHUNKED: the bias row is applied BEFORE the query's features
                                 // (chunk_ops<csr, hash>, inference.hpp:705-735); dense X is bias-first in every layout
-    int layer;                  // index in the chain (profiling only)
+    int layer;                  // index in the chain (profiling, feedback slot)
     K1Tune tune;
+    uint32_t* fb_host = nullptr;  // pruning feedback (Model::fb_host), or nullptr
+    uint32_t* fb_dev = nullptr;   // K1Q's sampled counters (Model::fb_dev)
 };
 
 // K0  prolongate: per query, offsets of every beam parent's child block + candidate count, and one

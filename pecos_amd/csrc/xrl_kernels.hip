@@ -257,6 +257,7 @@ struct K1Args {
     uint32_t lds_per_wave;       // bytes of dynamic LDS owned by each wavefront of a block
     uint32_t n_vblocks;          // number of wavefront-sized work blocks
     unsigned long long* phase;   // debug (ablate bit 6): per-phase cycle totals [prologue, fill, D1, D3, epilogue, waves]
+    uint32_t* fb_out;            // pruning feedback: the launch's item count (a later stage of a bound-pruned layer) goes to this host-visible word
 };
 
 template <int G, int PPC, class ACC>
@@ -342,6 +343,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XRL_K1
     ItemDesc it = make_item(0u, kNoTile, 0u, 0.f, 0, 0u);
     if (a.n_items) {   // tile-sorted list: every XCD takes a contiguous run of tiles
         const uint32_t n = *a.n_items, nb = (n + W - 1) / W;
+        if (a.fb_out && vblock == 0 && lane == 0) *a.fb_out = n;
         if (vblock >= nb) return;   // a compacted list (second phase of a pruned layer) usually fills a small part of the grid
         { const uint64_t slot = (uint64_t)xcd_remap(vblock, nb) * W + grp; if (slot < n) it = a.items[slot]; }
     } else {
@@ -641,6 +643,7 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
     a.ablate = ablate & 0xFF;
     // debug: bit 6 = per-phase cycle accounting; bits 8.. select one layer (value layer+1, 0 = every layer)
     a.phase = ((ablate & 64) && ((ablate >> 8) == 0 || (ablate >> 8) == P.layer + 1)) ? k1_phase_buffer() : nullptr;
+    a.fb_out = (n_items && P.fb_host && P.layer >= 0 && P.layer < 16) ? P.fb_host + 32 + P.layer : nullptr;
     const int ppc = pp_class(P.pp);
 #define XRL_K1_PP(GG, NN, DD, LL) do { if (ppc) launch_k1_any(&k1_kernel<GG, NN, 1, DD, LL>, a, 64 / GG, lds, P.tune, s); else launch_k1_any(&k1_kernel<GG, NN, 0, DD, LL>, a, 64 / GG, lds, P.tune, s); } while (0)
 #define XRL_K1(GG, NN) do { \

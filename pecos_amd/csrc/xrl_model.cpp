@@ -58,6 +58,7 @@ Model::~Model() {
     if (d2h_stream) (void)hipStreamDestroy(d2h_stream);
     for (hipEvent_t e : d2h_events) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
+    if (fb_host) (void)hipHostFree(fb_host);
 }
 uint64_t Model::device_bytes() const {
     uint64_t b = 0;

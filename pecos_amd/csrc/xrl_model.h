@@ -175,6 +175,19 @@ struct Model {
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
     int k1q_fuse = 3;                       // consecutive dense-format layers of <= this many candidate registers (1..3) share one K1Q launch (the beam stays in LDS); 0: one launch per layer
     int k1g_min_items = 16;                 // dense X: run a dense-format layer as the tiled SGEMM K1G once a parent serves this many queries on average (0 = never)
+    // ---- pruning feedback (xrl_predict.cpp): what the bound pruning of the PREVIOUS predicts of this handle achieved, per layer, so that a
+    // model on which the first stage settles almost nothing (scores that do not saturate, routing spread over the tree) stops paying for
+    // the staging -- the layer then scores every candidate in one pass (tile format: on tile-sorted items).  Results never depend on it.
+    static constexpr int kFbLayers = 16;
+    uint32_t* fb_host = nullptr;            // pinned, device-visible: [0, 2*kFbLayers) K1Q's sampled counters {queries seen, queries that needed the second pass}
+                                            //   per layer (copied from fb_dev by the first wavefront of the next K1Q launch), [2*kFbLayers, 3*kFbLayers) the
+                                            //   second stage's item count of tile-format layers (written by its K1 launch)
+    DevBuf fb_dev;                          // K1Q's counters (device atomics)
+    uint32_t fb_seen[kFbLayers] = {0}, fb_second[kFbLayers] = {0};   // K1Q counters at the last decision
+    uint64_t fb_tile_slots[kFbLayers] = {0};                          // second-stage slots the item count of a tile-format layer refers to
+    uint32_t fb_unstaged_calls[kFbLayers] = {0};                      // predicts in a row a layer has run unstaged (re-probed every kFbReprobe)
+    uint8_t fb_unstaged[kFbLayers] = {0};
+    int adaptive = 1;                       // 0: always stage (xrl_set_option "adaptive")
     int prune_mid = 1;                      // bound-pruned tile-format layers with >= 16 beam parents: a middle stage (slots 1..4) between the first parent and "everything else"
     int sort_rest = 1;                      // bound-pruned tile-format layers: the second phase's compacted items are tile-sorted before K1 runs on them (0: query order)
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)

@@ -149,6 +149,40 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     float prune_wmax = 0.0f;
     for (size_t l = 0; l < T; ++l) prune_wmax = std::max(prune_wmax, m.layers[l]->w_absmax);
     if (!(prune_wmax <= 3.0e38f)) prune_wmax = INFINITY;
+    // ---- pruning feedback (Model::fb_*): which layers run UNSTAGED this time because their first stage settled (almost) no query the last times
+    bool unst[Model::kFbLayers] = {false};
+    if (m.prune && m.adaptive) {
+        constexpr uint32_t kFbReprobe = 32;                             // an unstaged layer is staged again every so many predicts: the data may have changed
+        constexpr uint32_t kPending = 0xFFFFFFFFu;
+        if (!m.fb_host) {
+            XRL_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.fb_host), 3 * Model::kFbLayers * 4, hipHostMallocDefault));
+            for (int i = 0; i < 3 * Model::kFbLayers; ++i) m.fb_host[i] = i < 2 * Model::kFbLayers ? 0u : kPending;
+            m.fb_dev.reserve(2 * Model::kFbLayers * 4);
+            XRL_HIP(hipMemset(m.fb_dev.p, 0, 2 * Model::kFbLayers * 4));
+        }
+        volatile uint32_t* fh = m.fb_host;
+        for (size_t l = 0; l < T && l < (size_t)Model::kFbLayers; ++l) {
+            if (!o.stats_out) {
+                if (m.fb_unstaged[l]) {
+                    if (++m.fb_unstaged_calls[l] >= kFbReprobe) {            // stage it once more and look again
+                        m.fb_unstaged[l] = 0; m.fb_unstaged_calls[l] = 0;
+                        m.fb_seen[l] = fh[2 * l]; m.fb_second[l] = fh[2 * l + 1]; fh[2 * Model::kFbLayers + l] = kPending; m.fb_tile_slots[l] = 0;
+                    }
+                } else {
+                    // query-stationary layers: of the sampled queries that ran staged, how many needed the second pass
+                    const uint32_t seen = fh[2 * l], sec = fh[2 * l + 1], dseen = seen - m.fb_seen[l], dsec = sec - m.fb_second[l];
+                    if (dseen >= 256u) {
+                        if ((double)dsec > 0.7 * (double)dseen) { m.fb_unstaged[l] = 1; m.fb_unstaged_calls[l] = 0; }
+                        m.fb_seen[l] = seen; m.fb_second[l] = sec;
+                    }
+                    // tile-format layers: the item count of the last stage against the slots it was sized for
+                    const uint32_t cnt = fh[2 * Model::kFbLayers + l];
+                    if (cnt != kPending && m.fb_tile_slots[l] > 0 && (double)cnt > 0.6 * (double)m.fb_tile_slots[l]) { m.fb_unstaged[l] = 1; m.fb_unstaged_calls[l] = 0; }
+                }
+            }
+            unst[l] = m.fb_unstaged[l] != 0;
+        }
+    }
 
     uint64_t batch = 0;
     for (uint64_t row0 = row_begin; row0 < row_end; row0 += nb, ++batch) {
@@ -184,7 +218,8 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             P.first_layer = (l == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;   // no_prev_pred
             P.implicit_root = (l == 0 && !has_init) ? 1 : 0;
             P.bias_first = (m.weight_matrix_type == 1 && !X.dense) ? 1 : 0;
-            P.prune = m.prune ? 1 : 0;
+            P.prune = (m.prune && !(l < (size_t)Model::kFbLayers && unst[l])) ? 1 : 0;
+            if (m.prune && m.adaptive && !o.stats_out && l < (size_t)Model::kFbLayers) { P.fb_host = m.fb_host; P.fb_dev = m.fb_dev.as<uint32_t>(); }
             BeamDev prev{};
             if (l == 0 && has_init) {
                 prev = *o.initial;
@@ -254,6 +289,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                     Q.layer = (int)ll; Q.beam_in = beam_in[ll]; Q.k = k[ll]; Q.cand_stride = cstride[ll]; Q.pp = pp[ll];
                     Q.first_layer = (ll == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;
                     Q.implicit_root = (ll == 0 && !has_init) ? 1 : 0;
+                    Q.prune = (m.prune && !(ll < (size_t)Model::kFbLayers && unst[ll])) ? 1 : 0;
                     Ps[ll - l] = Q;
                 }
                 uint32_t *qi, *qc; float* qv; uint32_t qs;
@@ -268,11 +304,13 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 continue;
             }
             int g = m.k1_group > 0 ? m.k1_group : k1_auto_group(L.dev, L, X.dense);
-            const int mode = layer_mode(l, nrows);
+            int mode = layer_mode(l, nrows);
+            const bool fb_unstaged = l < (size_t)Model::kFbLayers && unst[l];
+            if (fb_unstaged && mode == 0 && sorts_rest(l)) mode = 1;    // pruning feedback: everything in one pass, on tile-sorted items
             // ---- exact bound pruning, tile format: score the children of the best beam parent first (K0 -> K1 -> K2 on one slot), then
             //      only the remaining slots of the queries whose top-k is not final yet (see K2Args).  Needs a combiner (a child's score
             //      is then <= its parent's) and the register top-k kernel.
-            bool pruned = m.prune && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P);
+            bool pruned = m.prune && !fb_unstaged && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P);
             uint32_t J = 1;
             if (o.stats_out) {
                 // the stats pass walks the tile format whatever kernel the timed pass runs: stage it the way THAT kernel stages the layer, so
@@ -307,6 +345,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                                                                    J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr, lw.x_ok.as<uint32_t>()); });
                 if (o.stats_out) XRL_HIP(hipMemsetAsync(lw.items_sorted.p, 0xFF, slots_b * k0_item_bytes(), S));   // the stats pass walks the whole list: unused slots read as "no tile"
                 const bool srt = sorts_rest(l);
+                if (P.fb_host && l < (size_t)Model::kFbLayers) m.fb_tile_slots[l] = (uint64_t)nrows * (beam_in[l] - stage_end[n_stage - 2]) * L.max_tiles_per_parent;
                 for (int st = 1; st < n_stage; ++st) {
                     const uint32_t r0 = stage_end[st - 1], r1 = stage_end[st];
                     const bool last = st == n_stage - 1;

@@ -733,6 +733,21 @@ def test_headline_config_full_size_all_rows_vs_reference(workload, XLM, clib, or
     clib.set_option(h, "prune", 0)                    # every candidate of every beam parent scored (no exact bound pruning)
     assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{workload} full size, prune=0")
     clib.set_option(h, "prune", 1)
+    # pruning feedback (option adaptive, default on): after a few predicts the handle runs the layers whose first stage settled nothing
+    # unstaged -- on the hard model the leaf switches to one pass over tile-sorted items and levels 2-3 drop their staged walk; same bits
+    for rep in range(4):
+        clib.profile_enable(h, True); clib.profile_reset(h)
+        got = m.predict(X, **kw)
+        names = {r["name"] for r in clib.profile_get(h)}
+        clib.profile_enable(h, False)
+        assert_same_topk(got, want, exact_scores=True, what=f"{workload} full size, predict #{rep + 4} (pruning feedback)")
+    if workload.endswith("-hard"):
+        assert "k1_sparse_rest" not in names and "k1_sort_items" in names, names      # the leaf runs unstaged by now
+    else:
+        assert "k1_sparse_rest" in names, names                                           # ... and stays staged where pruning works
+    clib.set_option(h, "adaptive", 0)
+    assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{workload} full size, adaptive=0")
+    clib.set_option(h, "adaptive", 1)
 
 
 @pytest.mark.timeout(2400)
