@@ -88,7 +88,7 @@ template <int NS> struct K1QCfg {
 // last -- a compile-time switch: as a run-time one it cost the widest kernel 8 VGPRs and a wavefront per SIMD
 template <int NS, int PPC, bool DENSEX, bool BIASF>
 __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesDev& X, uint64_t xrow, uint32_t cnt_in,
-                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane, float wmax, uint32_t* fb) {
+                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane, float wmax, uint32_t& fbm) {
     // ---- prolongate: which (parent, dense tile, column) does each of this lane's candidates stand for
     const uint32_t gl = Ly.d_gp_log2, gmask = (1u << gl) - 1u, TT = Ly.d_max_tiles;
     const uint32_t cnt = Ly.implicit_root ? 1u : min(cnt_in, Ly.beam_in);
@@ -235,7 +235,9 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         // (the guard: a query that could produce a NaN score -- non-finite or huge x, non-finite weights -- is never pruned)
         const bool xok = prune_guard_ok(wave_max_u32(xmx), xn, wmax);
         const bool second = !prune_all_in_first && (cge < Ly.k || !xok);
-        if (fb && lane == 0 && !prune_all_in_first) { atomicAdd(&fb[2 * Ly.layer_id], 1u); if (second) atomicAdd(&fb[2 * Ly.layer_id + 1], 1u); }
+#ifndef XRL_K1Q_NOFB
+        if (!prune_all_in_first) fbm |= (1u | (second ? 0x10000u : 0u)) << Ly.layer_id;   // pruning feedback: staged here / second pass needed (counted once, at the end of the kernel)
+#endif
         if (second) {
             pass(std::integral_constant<int, (NS > 1 ? 1 : 0)>{}, std::integral_constant<int, NS>{});
 #pragma unroll
@@ -411,23 +413,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI
     }
     wave_sync_lds();
     const uint64_t xrow = (uint64_t)a.row0 + q;
-    // pruning feedback: one query in 64 counts (device atomics); query 0 publishes what the earlier launches counted
-    uint32_t* fb = (a.fb_dev && (q & 63u) == 0u) ? a.fb_dev : nullptr;
-    if (a.fb_dev && a.fb_host && q == 0u && lane < 32) a.fb_host[lane] = a.fb_dev[lane];
+    uint32_t fbm = 0u;                                                 // pruning feedback: bit l = layer l ran staged, bit 16 + l = its second pass was needed
     int l_first = 0;
     if (MULTI && !DENSEX && a.fuse01) { cnt = k1q_layer01<PPC, BIASF>(a.layer[0], a.layer[1], a.X, xrow, s_bidx, s_bval, sc, lane); l_first = 2; }
     for (int l = l_first; l < (MULTI ? a.n_layers : 1); ++l) {
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
-        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
-        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
-        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
-        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
-        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
-        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
-        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
-        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fb);
+        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
     }
     if ((uint32_t)lane < cnt) {
         const size_t o = (size_t)q * a.out_stride + (uint32_t)lane;
@@ -435,6 +435,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI
         a.out_val[o] = s_bval[lane];
     }
     if (lane == 0) a.out_cnt[q] = cnt;
+    // pruning feedback (Model::fb_*): one query in 64 adds its layers' outcomes to the device counters; query 0 publishes what the
+    // EARLIER launches counted to the host-visible words (read by the host at the start of a later predict, without synchronisation)
+#ifndef XRL_K1Q_NOFB
+    if (a.fb_dev && (q & 63u) == 0u) {
+        if (q == 0u && a.fb_host && lane < 32) a.fb_host[lane] = a.fb_dev[lane];
+        if (lane < 16 && ((fbm >> lane) & 1u)) { atomicAdd(&a.fb_dev[2 * lane], 1u); if ((fbm >> (16 + lane)) & 1u) atomicAdd(&a.fb_dev[2 * lane + 1], 1u); }
+    }
+#endif
     if (a.out_xok) {   // the pruning guard of this query, for a bound-pruned tile-format layer that follows (its K2 decides there)
         uint32_t mx = 0u, n;
         if (DENSEX) {

@@ -132,10 +132,12 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
             clib.set_option(m.model.model_chain, "prune", 1)
             assert_same_topk(m.predict(X, **kw), a0, exact_scores=True, what=f"{name} prune on vs off {kw} dense_layers={dl}")
     clib.set_option(m.model.model_chain, "dense_layers", 0)
+    clib.set_option(m.model.model_chain, "adaptive", 0)         # (the pruning feedback may have switched a layer to one unstaged pass by now)
     clib.profile_enable(m.model.model_chain, True); clib.profile_reset(m.model.model_chain)
     m.predict(X, beam_size=cfg["beam"], only_topk=10)
     pnames = {r["name"] for r in clib.profile_get(m.model.model_chain)}
     clib.profile_enable(m.model.model_chain, False)
+    clib.set_option(m.model.model_chain, "adaptive", 1)
     assert {"k0b_remaining", "k1_sparse_rest", "k2_topk_rest"} <= pnames, pnames
     clib.set_option(m.model.model_chain, "dense_layers", 0)     # the remaining checks are about the tile-format kernels
     # two row batches in flight on two streams (default only for large X): same results, also with a ragged tail batch
