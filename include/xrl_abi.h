@@ -295,6 +295,10 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *                         previous predicts (sampled device counters / the later stage's item count, read back without any synchronisation);
  *                         a layer whose first stage settled fewer than ~35 % of the queries runs UNSTAGED on the following predicts (every
  *                         candidate in one pass; tile format: on tile-sorted items) and is probed again every 32nd predict; 0: always staged
+ *   "presence"            1 (default): K1Q on sparse X asks the layer's PRESENCE words (one bit per (feature, 16..32-column parent tile): "holds a weight")
+ *                         before requesting a weight segment, on the layers that run unstaged -- prune = 0, or switched by the pruning feedback:
+ *                         there every beam parent's segments are addressed and a third to a half of them are empty (Amazon-670K-hard: levels 0-3
+ *                         11.9 -> 7.5 ms); 2: on every layer that has the words; 0: never.  XRL_PRESENCE=0 at load builds none.
  *   "prune_mid"           1 (default): bound-pruned tile-format layers entered with >= 16 beam parents score slots 1..4 in a MIDDLE stage before
  *                         "every remaining slot" (three stages instead of two; Wiki10-31K's beam of 20); 0: two stages
  *   "sort_rest"           1 (default): the second phase of a bound-pruned tile-format layer runs on tile-sorted items (counting sort of the

@@ -38,6 +38,7 @@ namespace xrl {
 // what K1Q needs of one layer (a compact copy of LayerDev's dense-format fields + the layer's plan)
 struct K1QLayer {
     const uint32_t* wd; uint64_t d_ld;
+    const uint32_t* pres; uint32_t pres_words;     // presence words (LayerDev::pres) or nullptr
     const uint32_t* d_ptile; const uint32_t* d_tcol; const float* bias_prod; const uint32_t* perm_inv;
     uint32_t d_gp_log2, d_max_tiles, n_parents, w_rows;
     uint32_t beam_in, k, ns;          // ns: candidate registers per lane this layer needs
@@ -86,7 +87,9 @@ template <int NS> struct K1QCfg {
 // One layer for one query (one wavefront): beam in s_bidx / s_bval[0..cnt) -> beam out in the same arrays; returns the new count.
 // BIASF: the accumulators start at the bias product (dense X; sparse X under HASH_CHUNKED, inference.hpp:716-722) instead of receiving it
 // last -- a compile-time switch: as a run-time one it cost the widest kernel 8 VGPRs and a wavefront per SIMD
-template <int NS, int PPC, bool DENSEX, bool BIASF>
+// PRES: the instantiation carries the presence-word path (layers that run UNSTAGED on sparse X -- every beam parent's segments are
+// requested, a third to a half of them empty); the staged default does not pay its registers (4.15 vs 4.49 ms on Amazon-670K)
+template <int NS, int PPC, bool DENSEX, bool BIASF, bool PRES>
 __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesDev& X, uint64_t xrow, uint32_t cnt_in,
                                                uint32_t* s_bidx, float* s_bval, uint2* sc, int lane, float wmax, uint32_t& fbm) {
     // ---- prolongate: which (parent, dense tile, column) does each of this lane's candidates stand for
@@ -129,6 +132,9 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     const uint32_t* __restrict__ wd = Ly.wd;
     const uint32_t ld = (uint32_t)(Ly.d_ld * 4u);                       // bytes per feature row
     const uint32_t w_rows = Ly.w_rows;
+    // presence words: dense tile of a lane's byte offset = woff >> (gl + 2); its word's byte offset in the presence row = (tile >> 5) * 4
+    const uint32_t* __restrict__ pres = Ly.pres;
+    const uint32_t pres_bytes = Ly.pres_words * 4u, dt_shift = gl + 2u, pw_shift = gl + 2u + 5u - 2u;
     uint32_t xmx = 0u, xn = 0u;                                        // pruning guard: largest |x| bits this lane has seen, features of the query
 
     // One pass over the query's features for the candidate registers [RB, RE): U features per batch, their U*(RE-RB) weight loads issued
@@ -145,12 +151,33 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         auto body = [&](auto exact_tag, const uint32_t (&fs)[UU], const float (&xs)[UU]) {
             constexpr bool EX = decltype(exact_tag)::value;
             uint32_t wb[UU][NR];
+            if (PRES && !EX && pres != nullptr) {
+                // PRESENCE: first the word that says whether this lane's dense tile holds any weight at the feature (one small row per
+                // feature, mostly L2-resident), then the weight load with the lane's offset -- or an offset outside the resource for an
+                // empty tile: such lanes read 0.0 without a memory request.  A 64-byte segment none of whose lanes asks is never fetched.
 #pragma unroll
-            for (int u = 0; u < UU; ++u) {
-                // features outside the layer (and padding slots: fs = w_rows) read the all-missing row the model compiler appends
-                const __amdgpu_buffer_rsrc_t rs = k1q_row_rsrc(wd, ld, min(fs[u], w_rows));
+                for (int u = 0; u < UU; ++u) {
+                    const __amdgpu_buffer_rsrc_t ps = k1q_row_rsrc(pres, pres_bytes, min(fs[u], w_rows));
 #pragma unroll
-                for (int r = 0; r < NR; ++r) wb[u][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)woff[RB + r], 0, 0);
+                    for (int r = 0; r < NR; ++r) wb[u][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ps, (int)((woff[RB + r] >> pw_shift) & ~3u), 0, 0);
+                }
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    const __amdgpu_buffer_rsrc_t rs = k1q_row_rsrc(wd, ld, min(fs[u], w_rows));
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        const bool present = ((wb[u][r] >> ((woff[RB + r] >> dt_shift) & 31u)) & 1u) != 0u;
+                        wb[u][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(present ? woff[RB + r] : 0xFFFFFFF0u), 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    // features outside the layer (and padding slots: fs = w_rows) read the all-missing row the model compiler appends
+                    const __amdgpu_buffer_rsrc_t rs = k1q_row_rsrc(wd, ld, min(fs[u], w_rows));
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) wb[u][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)woff[RB + r], 0, 0);
+                }
             }
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
@@ -390,7 +417,7 @@ __device__ __forceinline__ uint32_t k1q_layer01(const K1QLayer& L0, const K1QLay
 // The fused kernel of narrow layers is compiled for 7 wavefronts per SIMD (72 VGPRs instead of the 74 the compiler settles on,
 // no spills; the exp-family post-processors would spill and keep the default): measured 6.57 vs 6.73 ms on Amazon-670K's levels 0-3; 8 (64 VGPRs, 8 spilled) loses, and so does any target
 // on the wide single-layer kernels.
-template <int NSMAX, int PPC, bool DENSEX, bool MULTI, bool BIASF>
+template <int NSMAX, int PPC, bool DENSEX, bool MULTI, bool BIASF, bool PRES>
 #ifndef XRL_K1Q_WPE
 #define XRL_K1Q_WPE 8    // round 4: 8 wavefronts per SIMD (64 VGPRs) -- the buffer-resource loads need no 64-bit vector addresses; 4.42 -> 4.14 ms on Amazon-670K
 #endif
@@ -420,14 +447,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MULTI
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
-        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF, PRES>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF, PRES>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF, PRES>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF, PRES>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF, PRES>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF, PRES>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF, PRES>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF, PRES>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
     }
     if ((uint32_t)lane < cnt) {
         const size_t o = (size_t)q * a.out_stride + (uint32_t)lane;
@@ -490,7 +517,7 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
         const uint32_t ns = k1q_regs(L, P.beam_in, P.k, true);      // capacity check only; whether sparse X SHOULD use the format is the caller's policy
         if (ns == 0) fail("k1q: layer not eligible");
         K1QLayer& y = a.layer[l];
-        y.wd = L.wd; y.d_ld = L.d_ld; y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
+        y.wd = L.wd; y.d_ld = L.d_ld; y.pres = (!X.dense && !P.tune.ablate && (P.tune.pres_mode == 2 || (P.tune.pres_mode == 1 && !P.prune))) ? L.pres : nullptr; y.pres_words = L.pres_words;   // presence words: layers that run unstaged y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
         y.d_gp_log2 = L.d_gp_log2; y.d_max_tiles = L.d_max_tiles; y.n_parents = L.n_parents; y.w_rows = L.w_rows;
         y.beam_in = P.beam_in; y.k = P.k; y.ns = k1q_bucket(ns);
         y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root; y.bias_first = P.bias_first; y.prune = P.prune;
@@ -513,10 +540,17 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     a.fb_dev = Ps[0].fb_dev; a.fb_host = Ps[0].fb_host;
     const dim3 grid((a.nrows + 3u) / 4u), block(256);
     const bool bias_first = Ps[0].bias_first != 0;
+    // PRES instantiations exist for the narrow kernels only (sparse X, <= 3 registers: the layers of 16-children parents the presence
+    // words are built for); a launch takes one when any of its layers carries presence words this time (launch_k1q's caller decides: layers
+    // that run unstaged)
+    bool any_pres = false;
+    for (int l = 0; l < n; ++l) any_pres = any_pres || a.layer[l].pres != nullptr;
+#define XRL_K1Q_P(NN, PP, DX, MM, BF) do { if (any_pres && !(DX) && (NN) <= 3) hipLaunchKernelGGL((k1q_kernel<NN, PP, DX, MM, BF, (!(DX) && (NN) <= 3)>), grid, block, 0, s, a); \
+                                           else hipLaunchKernelGGL((k1q_kernel<NN, PP, DX, MM, BF, false>), grid, block, 0, s, a); } while (0)
 #define XRL_K1Q_M(NN, MM) do { \
-        if (X.dense) { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, true, MM, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, true, MM, true>), grid, block, 0, s, a); } \
-        else if (bias_first) { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, false, MM, true>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, false, MM, true>), grid, block, 0, s, a); } \
-        else { if (ppc) hipLaunchKernelGGL((k1q_kernel<NN, 1, false, MM, false>), grid, block, 0, s, a); else hipLaunchKernelGGL((k1q_kernel<NN, 0, false, MM, false>), grid, block, 0, s, a); } } while (0)
+        if (X.dense) { if (ppc) XRL_K1Q_P(NN, 1, true, MM, true); else XRL_K1Q_P(NN, 0, true, MM, true); } \
+        else if (bias_first) { if (ppc) XRL_K1Q_P(NN, 1, false, MM, true); else XRL_K1Q_P(NN, 0, false, MM, true); } \
+        else { if (ppc) XRL_K1Q_P(NN, 1, false, MM, false); else XRL_K1Q_P(NN, 0, false, MM, false); } } while (0)
 #define XRL_K1Q(NN) do { if (n > 1) XRL_K1Q_M(NN, true); else XRL_K1Q_M(NN, false); } while (0)
     switch (k1q_kernel_bucket(nsmax)) {
     case 1: XRL_K1Q(1); break;
@@ -524,8 +558,39 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     case 6: XRL_K1Q_M(6, false); break;      // only narrow layers (<= 3 registers) are fused (xrl_predict.cpp)
     default: XRL_K1Q_M(16, false); break;
     }
+#undef XRL_K1Q_P
 #undef XRL_K1Q
 #undef XRL_K1Q_M
+    XRL_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Model compiler, device side: presence words of the dense row format (LayerDev::pres).  One wavefront per feature row, 64 columns
+// per step: a ballot of "holds a weight" is folded into one bit per dense tile (a tile = 2^gl <= 32 columns).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+presence_kernel(const uint32_t* __restrict__ wd, uint64_t ld, uint32_t rows, uint32_t gl, uint32_t n_tiles, uint32_t pw, uint32_t* __restrict__ pres) {
+    const uint32_t f = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (f >= rows) return;
+    const uint32_t* __restrict__ row = wd + (uint64_t)f * ld;
+    const uint32_t gp = 1u << gl, tpc = 64u >> gl;                   // tiles per 64-column step
+    uint32_t word = 0u, wi = 0u, filled = 0u;
+    for (uint32_t c0 = 0; c0 < (n_tiles << gl); c0 += 64u) {
+        const uint32_t c = c0 + lane;
+        const bool nz = c < (uint32_t)ld && row[c] != kMissing;
+        const unsigned long long m = __ballot(nz);
+        // lane t < tpc: does tile (c0 >> gl) + t hold a weight
+        const unsigned long long seg = gp == 64u ? m : ((m >> (lane < tpc ? lane * gp : 0u)) & ((1ull << gp) - 1ull));
+        const unsigned long long tb = __ballot(lane < tpc && seg != 0ull);
+        word |= (uint32_t)tb << filled; filled += tpc;
+        if (filled == 32u) { if (lane == 0) pres[(uint64_t)f * pw + wi] = word; word = 0u; filled = 0u; ++wi; }
+    }
+    if (lane == 0) { if (filled) pres[(uint64_t)f * pw + wi++] = word; for (; wi < pw; ++wi) pres[(uint64_t)f * pw + wi] = 0u; }
+}
+
+void launch_presence(const uint32_t* wd, uint64_t ld, uint32_t rows, uint32_t gp_log2, uint32_t n_tiles, uint32_t pres_words, uint32_t* pres, hipStream_t s) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(presence_kernel, dim3((rows + 3u) / 4u), dim3(256), 0, s, wd, ld, rows, gp_log2, n_tiles, pres_words, pres);
     XRL_LAUNCH_CHECK();
 }
 

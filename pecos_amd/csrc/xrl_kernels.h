@@ -23,7 +23,7 @@ struct BeamDev {
     uint32_t stride;
 };
 
-struct K1Tune { int wpb = 1, lds_pad = 0, ablate = 0, k1g_variant = 0; };   // per-model tuning / debug knobs (xrl_set_option k1_wpb, k1_lds_pad, k1_ablate, k1g_variant)
+struct K1Tune { int wpb = 1, lds_pad = 0, ablate = 0, k1g_variant = 0, pres_mode = 1; };   // per-model tuning / debug knobs (xrl_set_option k1_wpb, k1_lds_pad, k1_ablate, k1g_variant)
 
 struct LayerPlan {
     uint32_t row0, nrows;       // query rows [row0, row0+nrows) of the query matrix

@@ -138,6 +138,11 @@ uint64_t layout_tile_rows(const uint32_t* rptr, uint32_t nrows, bool align, uint
     return (cur + 15) & ~15ull;
 }
 
+static bool presence_enabled() {   // XRL_PRESENCE=0: no presence words (A/B, tests)
+    const char* e = std::getenv("XRL_PRESENCE");
+    return !(e && e[0] == '0');
+}
+
 std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, float bias, uint32_t only_topk,
                                      const std::string& post_processor, const std::vector<uint32_t>* perm_inv_override,
                                      uint32_t orig_rows, bool structure_only) {
@@ -421,7 +426,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     //      kept too (it serves beams / top-k sizes K1Q cannot hold in registers).  XRL_DENSE=0 disables it,
     //      XRL_DENSE_MAX_MB caps one layer's matrix (default 64 GiB, and never more than a quarter of the free HBM).
     std::vector<uint32_t> d_ptile, d_tcol;
-    uint32_t d_gp_log2 = 0, d_max_tiles = 0; uint64_t d_ld = 0;
+    uint32_t d_gp_log2 = 0, d_max_tiles = 0, pres_words = 0; uint64_t d_ld = 0;
     bool d_full = false;
     {
         const char* de = std::getenv("XRL_DENSE");
@@ -464,6 +469,13 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
             L->d_wd.reserve(((size_t)W.rows + 1) * d_ld * 4);
             launch_densify(t_ptr.as<uint64_t>(), t_idx.as<uint32_t>(), t_val.as<float>(), t_src.as<uint32_t>(), t_dst.as<uint32_t>(),
                            (uint32_t)c_nnz, W.rows, d_ld, L->d_wd.as<uint32_t>(), nullptr);
+            // presence words (LayerDev::pres): layers of many narrow dense tiles only (XRL_PRESENCE=0: none)
+            const uint64_t n_dtiles = d_tcol.size() - 2;
+            if (n_dtiles >= 16 && d_gp_log2 >= 1 && d_gp_log2 <= 5 && presence_enabled()) {
+                pres_words = 1; while ((uint64_t)pres_words * 32 < n_dtiles) pres_words <<= 1;
+                L->d_pres.reserve(((size_t)W.rows + 1) * pres_words * 4);
+                launch_presence(L->d_wd.as<uint32_t>(), d_ld, W.rows + 1, d_gp_log2, (uint32_t)n_dtiles, pres_words, L->d_pres.as<uint32_t>(), nullptr);
+            }
             XRL_HIP(hipStreamSynchronize(nullptr));
             L->d_dptile.upload(d_ptile); L->d_dtcol.upload(d_tcol);
             L->dense_bytes = L->d_wd.cap;
@@ -507,7 +519,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     }
     L->device_bytes = L->d_tiles.cap + L->d_ptile.cap + L->d_chunk_col.cap + L->d_bitmap.cap + L->d_row_ptr.cap +
                       L->d_row_idx.cap + L->d_entries.cap + L->d_perm_inv.cap + L->d_chunk_alg.cap + L->d_bias_prod.cap +
-                      L->d_bucket.cap + L->d_bitmap64.cap + L->d_wd.cap + L->d_dptile.cap + L->d_dtcol.cap;
+                      L->d_bucket.cap + L->d_bitmap64.cap + L->d_wd.cap + L->d_dptile.cap + L->d_dtcol.cap + L->d_pres.cap;
 
     LayerDev& d = L->dev;
     d.tiles = L->d_tiles.as<TileDesc>(); d.ptile = L->d_ptile.as<uint32_t>(); d.chunk_col = L->d_chunk_col.as<uint32_t>();
@@ -528,6 +540,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
         const double per_segment = (P && W.rows) ? (double)L->nnz / ((double)W.rows * (double)P) : 0.0;   // weights per (feature, parent)
         d.d_sparse_ok = (wp <= 32 || per_segment >= 1.0) ? 1 : 0;
     }
+    d.pres = pres_words ? L->d_pres.as<uint32_t>() : nullptr; d.pres_words = pres_words;
     d.d_full = d_full ? 1 : 0; d.tile_parent = L->dense_bytes ? L->d_tile_parent.as<uint32_t>() : nullptr;
     return L;
 }

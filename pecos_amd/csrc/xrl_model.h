@@ -86,6 +86,10 @@ struct LayerDev {
     int d_sparse_ok;             // sparse X may use the dense format (K1Q): parents of <= 32 padded columns (half a line / one line per
                                  // (feature, parent)), or wider ones whose (feature, parent) segments hold >= 1 weight on average; otherwise the
                                  // tile format's row lookup moves fewer lines (Wiki10-31K's leaf: 0.18 weights per 64-column segment)
+    const uint32_t* pres;        // PRESENCE words of the dense row format, or nullptr: pres[f * pres_words + (dt >> 5)] bit (dt & 31) = "dense tile dt holds
+    uint32_t pres_words;         //   at least one weight at feature row f" ((w_rows + 1) rows like wd).  K1Q (sparse X) requests a (feature, tile) segment
+                                 //   only when its bit is set: on deep trees a third to a half of the segments a query addresses are empty, and the
+                                 //   kernel runs on the number of fabric requests (profiles/r04_hard_config.md)
     int d_full;                  // every (feature, kept child) cell of the dense matrix holds a weight (no kMissing): K1G's 2-op inner loop
     const uint32_t* tile_parent; // [n_tiles] parent of every tile-format tile (K1G walks tile-sorted items)
 };
@@ -112,7 +116,7 @@ struct Layer {
     // device storage
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
     DevBuf d_bucket, d_bitmap64;
-    DevBuf d_wd, d_dptile, d_dtcol, d_tile_parent;   // dense row format (see LayerDev::wd)
+    DevBuf d_wd, d_dptile, d_dtcol, d_tile_parent, d_pres;   // dense row format (see LayerDev::wd)
     uint64_t dense_bytes = 0;
     uint32_t bk_shift = 0, bk_n = 0, bk_levels = 0;
     LayerDev dev{};
@@ -188,6 +192,8 @@ struct Model {
     uint32_t fb_unstaged_calls[kFbLayers] = {0};                      // predicts in a row a layer has run unstaged (re-probed every kFbReprobe)
     uint8_t fb_unstaged[kFbLayers] = {0};
     int adaptive = 1;                       // 0: always stage (xrl_set_option "adaptive")
+    int presence = 1;                       // K1Q, sparse X: 1 = layers that run UNSTAGED (prune off, or switched by the pruning feedback) request a (feature, parent) weight
+                                            // segment only when the layer's presence word says it holds a weight; 2 = every layer that has presence words; 0 = never
     int prune_mid = 1;                      // bound-pruned tile-format layers with >= 16 beam parents: a middle stage (slots 1..4) between the first parent and "everything else"
     int sort_rest = 1;                      // bound-pruned tile-format layers: the second phase's compacted items are tile-sorted before K1 runs on them (0: query order)
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
@@ -223,6 +229,8 @@ std::unique_ptr<Model> load_mmap_model_from_disk(const std::string& path);      
 void compile_mmap_model(const std::string& npz_path, const std::string& mmap_path);   // xrl_mmap.cpp
 void ensure_device_csc(Layer& L);
 // xrl_k1q.hip: memset wd to kMissing and scatter the CSC columns src_col[c] to padded column dst_off[c]
+// xrl_k1q.hip: presence words of a dense-format layer (LayerDev::pres) from its matrix
+void launch_presence(const uint32_t* wd, uint64_t ld, uint32_t rows, uint32_t gp_log2, uint32_t n_tiles, uint32_t pres_words, uint32_t* pres, hipStream_t s);
 void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,
                     const uint32_t* dst_off, uint32_t n_children, uint32_t w_rows, uint64_t ld, uint32_t* wd, hipStream_t s);   // upload W as CSC (original column ids) if not there yet
 

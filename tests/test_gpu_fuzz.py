@@ -103,6 +103,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         clib.set_option(m.model.model_chain, "k1g_min_items", 1 if trial == 0 else 16)   # dense X: tiled SGEMM forced / by batch size
         clib.set_option(m.model.model_chain, "k1g_variant", int(rng.integers(0, 2)))      # its alternative tile shapes
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
+        clib.set_option(m.model.model_chain, "presence", int(rng.choice([0, 1, 2, 2])))           # K1Q presence words: never / unstaged layers / always
         clib.set_option(m.model.model_chain, "sort_min_tiles", int(rng.choice([0, 1, 1])))       # tile-format layers: items in natural order / tile-sorted
         os.environ["XRL_K1Q_FUSE01"] = str(int(rng.choice([0, 1, 1])))                          # levels 0 + 1 in one feature walk (K1Q) / separately
         clib.set_option(m.model.model_chain, "prune", int(rng.choice([0, 1, 1])))                  # exact bound pruning on / off: same bits
@@ -119,6 +120,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
     clib.set_option(m.model.model_chain, "k1g_variant", 0)
     clib.set_option(m.model.model_chain, "dense_layers", 1)
     clib.set_option(m.model.model_chain, "sort_min_tiles", 0)
+    clib.set_option(m.model.model_chain, "presence", 1)
     clib.set_option(m.model.model_chain, "prune", 1)
     os.environ.pop("XRL_K1Q_FUSE01", None)
     clib.set_option(m.model.model_chain, "max_batch_rows", 0)

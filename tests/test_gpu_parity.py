@@ -73,8 +73,11 @@ def test_synthetic_goldens_bit_exact(manifest, XLM, clib):
         assert clib.xlinear_get_int_attr(m.model.model_chain, "nr_dense_layers") > 0
         for dl in (1, 2):                      # default policy / K1Q wherever the candidates fit its registers
             clib.set_option(m.model.model_chain, "dense_layers", dl)
-            P = m.predict(X, **c["kwargs"])
-            assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} dense format (K1Q), dense_layers={dl}")
+            for pres in (1, 2, 0):             # presence words: unstaged layers only (default) / every layer that has them / never
+                clib.set_option(m.model.model_chain, "presence", pres)
+                P = m.predict(X, **c["kwargs"])
+                assert_same_topk(P, G, exact_scores=EXACT_PP(c["kwargs"].get("post_processor")), what=f"{c} dense format (K1Q), dense_layers={dl} presence={pres}")
+            clib.set_option(m.model.model_chain, "presence", 1)
         clib.set_option(m.model.model_chain, "dense_layers", 0)     # tile format: K0 -> K1 -> K2
         for g in (0, 1, 2, 8, 64):
             clib.set_option(m.model.model_chain, "k1_group", g)
