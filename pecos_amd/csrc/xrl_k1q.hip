@@ -8,17 +8,23 @@
 // request from the L2 (profiles/): a probe line per (feature, tile), an extent line and 1..5 entry
 // lines per hit, three dependent loads deep.  For the narrow chunks of the upper tree levels (nr_splits = 16
 // children per parent) the weights of one feature for one chunk are 64 bytes when stored densely --
-//      wd[feature][dense tile * Gp + column]     (f32 bits; kMissing where W has no entry)
+//      wd[feature][dense tile * Gp + column]     (f32 bits; kMissing = -0.0 where W has no entry)
 // -- so ONE independent load per (feature, chunk) replaces probe + extent + entries, half a cache line each,
-// and because lane == column the accumulators live in registers: no LDS traffic, no compaction, 4 VALU
+// and because lane == column the accumulators live in registers: no LDS traffic, no compaction, 2 VALU
 // instructions per (feature, 64 candidates).  It costs rows x padded-columns x 4 bytes of HBM per layer
 // (Amazon-670K level 3: 4.4 GB), which is what 288 GB are for; layers that do not fit (the leaf) stay in
 // the sparse tile format and run K0 -> K1 -> K2.
 //
 // Arithmetic is the reference's, bit for bit: per candidate column, fl32(acc + fl32(x_f * w)) over the
-// query's features in ascending order; a column WITHOUT an entry at feature f is skipped (select on the
-// kMissing bit pattern), so explicit zeros stored in W and non-finite x behave exactly as in the sparse
-// walk; bias last (sparse X) / first (dense X); transform in fp64; combine in fp32.
+// query's features in ascending order.  A column WITHOUT an entry at feature f holds -0.0: for finite x the
+// product is a zero and leaves the accumulator as it is (accumulators are never -0.0), so the fast loop treats
+// it like any weight; a 64-feature chunk holding a non-finite x runs the exact loop, which skips such cells on
+// the marker -- explicit zeros stored in W and non-finite x behave exactly as in the reference's sparse walk.
+// Bias last (sparse X) / first (dense X); transform in fp64; combine in fp32.
+//
+// Round 4: the query's (feature, value) pairs arrive through SCALAR loads, weight rows are buffer resources
+// (no 64-bit vector addressing), 8 wavefronts per SIMD; layers that run UNSTAGED ask the layer's PRESENCE words
+// first and never request an empty (feature, parent) segment; one query in 64 reports to the pruning feedback.
 //
 // Wavefront layout: candidate u = r*64 + lane (r < NS registers) <-> slot u >> log2(Gp) = (beam rank j,
 // dense tile tt of that parent), column u & (Gp-1).  u is also the candidate's POSITION in the reference's
@@ -517,7 +523,8 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
         const uint32_t ns = k1q_regs(L, P.beam_in, P.k, true);      // capacity check only; whether sparse X SHOULD use the format is the caller's policy
         if (ns == 0) fail("k1q: layer not eligible");
         K1QLayer& y = a.layer[l];
-        y.wd = L.wd; y.d_ld = L.d_ld; y.pres = (!X.dense && !P.tune.ablate && (P.tune.pres_mode == 2 || (P.tune.pres_mode == 1 && !P.prune))) ? L.pres : nullptr; y.pres_words = L.pres_words;   // presence words: layers that run unstaged y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
+        y.wd = L.wd; y.d_ld = L.d_ld; y.pres = (!X.dense && !P.tune.ablate && (P.tune.pres_mode == 2 || (P.tune.pres_mode == 1 && !P.prune))) ? L.pres : nullptr; y.pres_words = L.pres_words;   // presence words: layers that run unstaged
+        y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
         y.d_gp_log2 = L.d_gp_log2; y.d_max_tiles = L.d_max_tiles; y.n_parents = L.n_parents; y.w_rows = L.w_rows;
         y.beam_in = P.beam_in; y.k = P.k; y.ns = k1q_bucket(ns);
         y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root; y.bias_first = P.bias_first; y.prune = P.prune;

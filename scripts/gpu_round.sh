@@ -6,7 +6,7 @@
 #   smoke           __graft_entry__.smoke()
 #   bench[:ARGS]    python bench.py ARGS            (ARGS with ',' for spaces; output bench_<n>.json / .err)
 #   pmc[:ARGS]      two rocprofv3 --pmc passes (FETCH_SIZE + SQ counters | WRITE_SIZE + L2 hit / miss / requests) + a --kernel-trace --stats pass over
-#                   `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats ARGS`, reduced to per-kernel CSVs and one pmc_traffic entry
+#                   `bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats ARGS` (last 4 steps counted), reduced to per-kernel CSVs and one pmc_traffic entry
 ulimit -c 0
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=$1; shift
 O=$R/gpurun_out/$TAG; mkdir -p $O
@@ -15,9 +15,9 @@ n=0
 for st in "$@"; do
   name=${st%%:*}; args=""; [ "$st" != "$name" ] && args=$(echo "${st#*:}" | tr ',' ' ')
   case $name in
-    tests) timeout 1500 python -m pytest tests -m gpu -q -x $args 2>&1 | tail -15 > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
+    tests) timeout ${XRL_TESTS_TIMEOUT:-1500} python -m pytest tests -m gpu -q -x $args 2>&1 | tail -15 > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
-    bench) n=$((n+1)); echo "== bench $args"; timeout 1200 python bench.py $args > $O/bench_$n.json 2> $O/bench_$n.err; echo "$args" > $O/bench_$n.args
+    bench) n=$((n+1)); echo "== bench $args"; timeout ${XRL_BENCH_TIMEOUT:-600} python bench.py $args > $O/bench_$n.json 2> $O/bench_$n.err; echo "$args" > $O/bench_$n.args
            grep -E "per-launch|host ABI|xrl host|cpu reference|Error|error" $O/bench_$n.err | cut -c1-1500; python -c "
 import json,sys
 try:
@@ -27,10 +27,10 @@ except Exception as e: print('no json', e)
     pmc) # pmc:BENCHARG,BENCHARG,...   two counter passes (TCC + TCP + SQ blocks have separate slots) + one --kernel-trace --stats pass; writes
          # pmc_<n>_{fetch,write,l2,sq}.csv, kernel_stats_<n>.csv and the pmc_traffic entry pmc_entry_<n>.json (scripts/pmc_traffic.py)
          n=$((n+1)); cd /tmp && export TMPDIR=/tmp
-         B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats --parity-rows 0 $args"
-         timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_a -- $B > $O/pmc_${n}_a.log 2>&1
-         timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $O/pmc_b -- $B > $O/pmc_${n}_b.log 2>&1
-         timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-abi --no-stats --parity-rows 0 $args > $O/ktrace_$n.log 2>&1
+         B="python $R/bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats --parity-rows 0 $args"
+         timeout ${XRL_PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_a -- $B > $O/pmc_${n}_a.log 2>&1
+         timeout ${XRL_PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $O/pmc_b -- $B > $O/pmc_${n}_b.log 2>&1
+         timeout ${XRL_PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python $R/bench.py --steps 10 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats --parity-rows 0 $args > $O/ktrace_$n.log 2>&1
          python - $O $n "$args" <<'PY'
 import csv, glob, os, sys, collections
 O, n, args = sys.argv[1], sys.argv[2], sys.argv[3].split()

@@ -1,6 +1,6 @@
 """Build profiles/pmc_traffic.json from the per-kernel counter CSVs that `scripts/gpu_round.sh <tag> pmc` leaves under
 gpurun_out/<tag>/ (each counter set in its OWN rocprofv3 --pmc pass, --kernel-trace only, over
-`python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats`).
+`python bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats`).
 
 usage: pmc_traffic.py <dir with pmc_fetch.csv pmc_write.csv pmc_l2.csv pmc_sq.csv> <out.json> [fetch_factor] [config] [scale] [opt,opt,...]
        pmc_traffic.py --merge <entry.json> [<entry.json> ...]      add / replace entries of profiles/pmc_traffic.json
@@ -28,18 +28,37 @@ def family(kernel_name):
     return None
 
 
-N_STEPS = 4.0   # the profiled command runs --steps 3 --warmup 1
+N_STEPS = 4.0   # the profiled command runs --steps 4 --warmup 6; only its LAST four steps are counted: the pruning feedback (xrl_set_option
+                # "adaptive") may switch layers to their unstaged kernels during the first steps, and the timed steps of bench.py run in the settled state
+
+
+def last_steps_start(rows):
+    """Start_Timestamp of the first dispatch of the last N_STEPS steps.  A step begins with a k1q_kernel / k0_prolongate / xguard launch that does
+    not directly follow another beam-search kernel of the same step's opening run (K1Q launches may come in pairs: fused levels, then a wide layer)."""
+    disp = sorted({(int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in rows if family(r["Kernel_Name"]) is not None or "xguard" in r["Kernel_Name"]})
+    if not disp:
+        return 0
+    opener = disp[0][1].split("<")[0]
+    starts, prev_open = [], False
+    for t, name in disp:
+        is_open = name.split("<")[0] == opener
+        if is_open and not prev_open:
+            starts.append(t)
+        prev_open = is_open
+    return starts[-int(N_STEPS)] if len(starts) >= int(N_STEPS) else starts[0]
 
 
 def per_family(path, counter):
-    """counter value per STEP of every kernel family: the sum over all launches of the family (both phases of a bound-pruned layer, every
-    layer the family serves) divided by the number of steps the profiled command ran"""
+    """counter value per STEP of every kernel family over the last N_STEPS steps: the sum over all launches of the family (both phases of a
+    bound-pruned layer, every layer the family serves) divided by the number of steps"""
     if not os.path.exists(path):
         return {}
+    rows = list(csv.DictReader(open(path)))
+    t0 = last_steps_start(rows)
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
+    for r in rows:
         fam = family(r["Kernel_Name"])
-        if r["Counter_Name"] != counter or fam is None:
+        if r["Counter_Name"] != counter or fam is None or int(r["Start_Timestamp"]) < t0:
             continue
         agg[fam].append(float(r["Counter_Value"]))
     return {k: {"launches": len(v) / N_STEPS, "mean": sum(v) / N_STEPS} for k, v in agg.items()}
@@ -84,7 +103,7 @@ for fam in f:
 json.dump({
     "key": bench.pmc_key(config, scale, opts), "config": config, "scale": scale, "opts": opts, "n_gpus": 1, "fetch_factor": factor, "csrc_sha16": bench.csrc_sha16(),
     "source": "rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum | SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU ...; "
-              "separate runs, --kernel-trace only) over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-abi --no-stats`; SUM over all "
+              "separate runs, --kernel-trace only) over `python bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats` (the last 4 steps are counted: the pruning feedback has settled); SUM over all "
               "launches of the kernel family in a step (every layer it serves, both phases of a bound-pruned layer), averaged over the 4 steps; bytes = (FETCH_SIZE x fetch_factor + WRITE_SIZE) KiB, fetch_factor from the calibration run on 8..64-byte gathers "
               "(profiles/r02_calib_fetch.md); counts fabric requests, Infinity-Cache hits included",
     "kernels": kernels,
