@@ -15,7 +15,7 @@ from conftest import GOLDEN, REPO, load_X
 def _declared_symbols():
     src = open(os.path.join(REPO, "include", "xrl_abi.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b((?:c_xlinear|c_sparse|xrl)_[a-z0-9_]+)\s*\(", src)
+    names = re.findall(r"\b((?:c_xlinear|c_sparse|c_tfidf|xrl)_[a-z0-9_]+)\s*\(", src)
     return sorted(set(n for n in names if not n.endswith("_t")))
 
 
