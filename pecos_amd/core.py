@@ -14,6 +14,7 @@ with the same names, argument order and meaning, so that code written against
 compute call needs a visible HIP device and raises ``RuntimeError`` otherwise.
 """
 import ctypes
+import sys
 import os
 from ctypes import (CFUNCTYPE, POINTER, byref, c_bool, c_char_p, c_double, c_float, c_int, c_int64,
                     c_uint32, c_uint64, c_void_p, cast)
@@ -143,6 +144,25 @@ class ProfileRec(ctypes.Structure):
                 ("ms", c_double), ("reserved", c_double)]
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  If this library pulls in the
+    system copy first and torch is imported LATER, torch finds "No HIP GPUs"; importing torch first avoided that,
+    but nothing enforced the order.  When a torch installation is present and not imported yet, its copy of the runtime is loaded here
+    (without importing torch), so that libxrl_amd.so binds to the runtime torch will use -- in either import order."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import glob
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        for d in (spec.submodule_search_locations or []) if spec else []:
+            for so in sorted(glob.glob(os.path.join(d, "lib", "libamdhip64.so*"))):
+                ctypes.CDLL(so, mode=ctypes.RTLD_GLOBAL)
+                return
+    except Exception:
+        pass                                     # fall back to the system runtime
+
+
 class corelib(object):
     """The C-ABI library, loaded lazily (so that importing the package works on a CPU-only box)."""
 
@@ -158,6 +178,7 @@ class corelib(object):
                 raise RuntimeError(
                     f"{self.so_path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                     "(hipcc --offload-arch=gfx950).  pecos_amd has no CPU fallback.")
+            _preload_torch_hip_runtime()
             self._lib = ctypes.CDLL(self.so_path)
             self._link(self._lib)
         return self._lib

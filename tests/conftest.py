@@ -6,6 +6,11 @@ import numpy as np
 import pytest
 import scipy.sparse as smat
 
+try:        # one HIP runtime per process: torch's bundled copy must be the one in place before any test loads libxrl_amd.so directly (ctypes.CDLL)
+    import torch  # noqa: F401
+except Exception:
+    pass
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 GOLDEN = os.path.join(REPO, "tests", "golden")

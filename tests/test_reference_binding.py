@@ -40,6 +40,7 @@ def _bind():
     lib.link_mlmodel_methods()
     lib.link_xlinear_methods()
     lib.link_sparse_operations()
+    lib.link_tfidf_vectorizer()
     return pcb, lib, Mixed, ours
 
 
@@ -53,9 +54,11 @@ def test_reference_prototypes_bind_to_this_library():
             "c_xlinear_single_layer_predict_on_selected_outputs_csr_f32", "c_xlinear_single_layer_predict_on_selected_outputs_drm_f32",
             "c_sparse_inner_products_csr2csc_f32", "c_sparse_inner_products_drm2csc_f32", "c_sparse_inner_products_csr2dcm_f32",
             "c_sparse_inner_products_drm2dcm_f32"}
+    need |= {"c_tfidf_load", "c_tfidf_destruct", "c_tfidf_predict"}          # round 4: the vectorizer's predict path (libpecos.cpp:398-445)
     assert need <= Mixed.taken, sorted(need - Mixed.taken)
     # and the training entry points stayed with the reference
     assert "c_xlinear_single_layer_train_csr_f32" not in Mixed.taken
+    assert not {"c_tfidf_train", "c_tfidf_save", "c_tfidf_predict_from_file"} & Mixed.taken
 
 
 @pytest.mark.gpu
@@ -91,3 +94,31 @@ def test_reference_xlinear_model_predicts_through_this_library(manifest):
         assert b"gfx950" in ours.xrl_version()
     finally:
         xb.clib = saved
+
+
+@pytest.mark.gpu
+def test_reference_tfidf_vectorizer_predicts_through_this_library(manifest):
+    # the reference's own Tfidf class (pecos/utils/featurization/text/vectorizers.py:163-308) on its own ctypes prototypes
+    # (corelib.link_tfidf_vectorizer, base.py:1648-1694), with c_tfidf_load / c_tfidf_predict / c_tfidf_destruct resolved to THIS library:
+    # the vectorizers the reference trained and saved (tests/golden/tfidf_models), its own predict() outputs as the expectation
+    import json
+    import scipy.sparse as smat
+    pcb, lib, Mixed, ours = _bind()
+    import pecos.utils.featurization.text.vectorizers as vz
+    saved = vz.clib
+    vz.clib = lib
+    try:
+        for c in manifest["tfidf_models"]:
+            d = os.path.join(GOLDEN, "tfidf_models", c["name"])
+            corpus = json.load(open(os.path.join(d, "corpus.json")))
+            z = np.load(os.path.join(d, "X.npz"))
+            vec = vz.Tfidf.load(os.path.join(d, "model"))
+            P = vec.predict(corpus).tocsr()
+            assert P.shape == tuple(z["shape"]) and np.array_equal(P.indptr, z["indptr"]) and np.array_equal(P.indices, z["indices"]), c
+            if c["sublinear"]:
+                assert np.allclose(P.data, z["data"], rtol=3e-7, atol=0), c
+            else:
+                assert np.array_equal(P.data.astype(np.float32).view(np.uint32), z["data"].astype(np.float32).view(np.uint32)), c
+            del vec
+    finally:
+        vz.clib = saved
