@@ -7,6 +7,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import scipy.sparse as smat
 
 from conftest import REPO
@@ -185,3 +186,50 @@ def test_round3_amazon_line_is_counter_based_and_self_consistent():
     p = j["parity"]
     assert p["timed_output_identical"] and p["timed_output_scores_bit_identical"] and p["scores_bit_identical"] and p["indices_identical"]
     assert j["cpu_baseline"]["kind"] == "reference" and j["cpu_baseline"]["all_cores"]["cores"] >= j["cpu_baseline"]["cores"]
+
+
+def _kernel_stats(name):
+    import csv
+    return list(csv.DictReader(open(os.path.join(REPO, "profiles", name))))
+
+
+def test_round4_lines_agree_with_the_rocprof_summaries():
+    # the contract: `roofline.avg_launch_ms` (hipEvents inside bench.py) must agree with the average duration rocprofv3 --kernel-trace --stats
+    # reports for the same kernel; and `frac` must be achieved / peak with achieved = counter bytes of the kernel per launch / that time
+    for line, stats, kernel in (("r04_bench_amazon670k_n1.json", "r04_bench_amazon670k_kernel_stats.csv", "k1q_kernel<3, 0, false, true, false, false>"),
+                                ("r04_bench_amazon670k_hard_n1.json", "r04_bench_amazon670k_hard_kernel_stats.csv", "k1q_kernel<3, 0, false, true, false, true>")):
+        j = _recorded(line)
+        r = j["roofline"]
+        row = next(x for x in _kernel_stats(stats) if kernel in x["Name"])
+        assert abs(float(row["AverageNs"]) * 1e-6 - r["avg_launch_ms"]) / r["avg_launch_ms"] < 0.03, (line, row["AverageNs"], r["avg_launch_ms"])
+        assert r["basis"].startswith("pmc") and abs(r["achieved"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0
+        assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3 and 0.3 < r["frac"] < 0.6
+        assert j["value_definition"].startswith("DEVICE-RESIDENT") and j["value_host_abi"] < j["value"]
+        assert abs(j["value"] - 490000 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-3
+        p = j["parity"]
+        assert p["timed_output_identical"] and p["scores_bit_identical"] and p["indices_identical"]
+        assert j["value"] / j["cpu_baseline"]["value"] > 10.0                      # north_star's target (>= 10x the reference CPU), both models
+
+
+def test_counter_sets_recompute_from_the_committed_passes():
+    # profiles/pmc_traffic.json is DERIVED data: every entry must follow from the per-launch counter rows committed beside it
+    # (scripts/pmc_traffic.py: sums per kernel over the last four steps / 4)
+    import subprocess
+    import tempfile
+    tj = json.load(open(os.path.join(REPO, "profiles", "pmc_traffic.json")))["entries"]
+    names = {"amazon-670k@1.0": "amazon670k", "amazon-670k-hard@1.0": "amazon670k_hard", "eurlex-4k@1.0": "eurlex4k", "wiki10-31k@1.0": "wiki10",
+             "dense-768@0.25": "dense768_L750k_N250k"}
+    assert set(names) <= set(tj)
+    for key, n in names.items():
+        with tempfile.TemporaryDirectory() as d:
+            for k in ("fetch", "write", "l2", "sq"):
+                os.symlink(os.path.join(REPO, "profiles", f"r04_pmc_{n}_{k}.csv"), os.path.join(d, f"pmc_{k}.csv"))
+            cfg, scale = key.split("@")
+            out = os.path.join(d, "e.json")
+            subprocess.check_call([sys.executable, os.path.join(REPO, "scripts", "pmc_traffic.py"), d, out, "1.0", cfg, scale], stdout=subprocess.DEVNULL)
+            e = json.load(open(out))
+        assert e["key"] == key
+        for fam, want in tj[key]["kernels"].items():
+            got = e["kernels"][fam]
+            for f in ("hbm_bytes_per_step", "fabric_read_req_per_step", "valu_insts_per_step", "launches_per_step"):
+                assert got[f] == pytest.approx(want[f], rel=1e-9), (key, fam, f)
