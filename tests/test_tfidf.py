@@ -43,6 +43,180 @@ def test_term_counts_have_the_reference_pattern(name):
         clib.tfidf_destruct(h)
 
 
+_REFPY = os.path.abspath(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "refpy"))
+
+
+def _live_reference_predict(folder, docs, tmp_path):
+    """The reference's own c_tfidf_load + c_tfidf_predict, run here in a subprocess (oracle/_ref/refpy; never on the GPU box)."""
+    import subprocess
+    import sys
+    json.dump(docs, open(tmp_path / "docs.json", "w"), ensure_ascii=False)
+    code = (f"import sys, json, numpy as np; sys.path.insert(0, {_REFPY!r})\n"
+            "from pecos.utils.featurization.text.vectorizers import Tfidf\n"
+            f"X = Tfidf.load({folder!r}).predict(json.load(open({str(tmp_path / 'docs.json')!r}))).tocsr()\n"
+            f"np.savez({str(tmp_path / 'live.npz')!r}, indptr=X.indptr, indices=X.indices, data=X.data.astype(np.float32), shape=np.asarray(X.shape))\n")
+    subprocess.check_call([sys.executable, "-c", code])
+    return np.load(tmp_path / "live.npz")
+
+
+def _ulp_diff(a, b):
+    ia = a.view(np.int32).astype(np.int64); ib = b.view(np.int32).astype(np.int64)
+    return int(np.max(np.abs(ia - ib))) if len(a) else 0
+
+
+@pytest.mark.parametrize("name", _names())
+def test_oracle_restatement_vs_reference_goldens(name):
+    # the CPU restatement (oracle/tfidf_oracle.py: counts + float32 weighting) against what the REFERENCE produced: pattern identical, values
+    # bit for bit (with sublinear tf numpy's logf may differ from glibc's in the last bit)
+    from oracle.tfidf_oracle import TfidfOracle
+    folder, corpus, X = _case(name)
+    O = TfidfOracle(folder)
+    assert O.nr_features == X.shape[1]
+    indptr, idx, val = O.predict(corpus)
+    assert np.array_equal(indptr, X.indptr.astype(np.uint64)) and np.array_equal(idx, X.indices.astype(np.uint32)), name
+    sub = any(b.sublinear_tf for b in O.base)
+    assert _ulp_diff(val, X.data.astype(np.float32)) <= (1 if sub else 0), name
+
+
+def _fuzz_corpus(rng, tokens, n_docs, max_len):
+    """Documents over `tokens` (bytes) plus unknown ones, runs of spaces, empty documents."""
+    junk = [b"zzq", b"unknown-token-longer-than-eight", "éè".encode(), "日本".encode(), b"a", b"  ", b""]
+    docs = []
+    for _ in range(n_docs):
+        n = int(rng.integers(0, max_len))
+        parts = [tokens[int(i)] if rng.random() < 0.85 else junk[int(rng.integers(len(junk)))] for i in rng.integers(0, len(tokens), size=n)]
+        sep = b" " if rng.random() < 0.8 else b"  "
+        d = sep.join(parts)
+        if rng.random() < 0.2:
+            d = b" " + d + b" "
+        docs.append(d)
+    docs[0] = b""
+    docs[1] = b"     "
+    return docs
+
+
+def _check_counts(clib, h, O, corpus, what):
+    indptr, idx, val = O.counts(corpus)
+    for threads in (1, 4):
+        C = clib.tfidf_counts(h, corpus, threads=threads)
+        assert C.shape == (len(corpus), O.nr_features), what
+        assert np.array_equal(C.indptr.astype(np.uint64), indptr) and np.array_equal(C.indices.astype(np.uint32), idx), what
+        assert np.array_equal(C.data.astype(np.float32), val), what
+
+
+@pytest.mark.parametrize("dense_limit", [None, "0"])
+@pytest.mark.parametrize("name", _names())
+def test_host_half_counts_vs_oracle_fuzz(name, dense_limit, monkeypatch):
+    # the host half's COUNTS (ids and values) against the restatement on fuzzed corpora, on both counting paths: dense counters + bitmap walk
+    # (the default) and the per-document sort (XRL_TFIDF_DENSE_LIMIT=0, what a model of > 16 M features uses)
+    from oracle.tfidf_oracle import TfidfOracle
+    from pecos_amd import clib
+    if dense_limit is not None:
+        monkeypatch.setenv("XRL_TFIDF_DENSE_LIMIT", dense_limit)
+    folder, corpus, X = _case(name)
+    O = TfidfOracle(folder)
+    h = clib.tfidf_load(folder)
+    try:
+        _check_counts(clib, h, O, [c.encode("utf-8") for c in corpus], name)
+        rng = np.random.default_rng(abs(hash(name)) % 1000 + 17)
+        toks = sorted(set().union(*[set(b.vocab) for b in O.base]))
+        if O.base[0].tok_type != 10:          # character vocabularies: build documents from words of those characters
+            toks = [b"".join(toks[int(i)] for i in rng.integers(0, len(toks), size=int(rng.integers(1, 9)))) for _ in range(200)]
+        _check_counts(clib, h, O, _fuzz_corpus(rng, toks, 300, 90), name + " fuzz")
+        long_doc = b" ".join(toks[int(i)] for i in rng.integers(0, min(len(toks), 12), size=6000))     # counts in the hundreds, one very long row
+        _check_counts(clib, h, O, [long_doc, b"", long_doc[:50]], name + " long")
+    finally:
+        clib.tfidf_destruct(h)
+
+
+def _write_base(folder, tok_type, vocab_lines, kwargs, features):
+    os.makedirs(os.path.join(folder, "tokenizer")); os.makedirs(os.path.join(folder, "vectorizer"))
+    json.dump({"token_type": tok_type}, open(os.path.join(folder, "tokenizer", "config.json"), "w"))
+    with open(os.path.join(folder, "tokenizer", "vocab.txt"), "wb") as f:
+        f.write(f"{len(vocab_lines)}\n".encode())
+        for idx, tok in vocab_lines:
+            f.write(f"{idx}\t".encode() + tok + b"\n")
+    json.dump({"type": "tfidf", "kwargs": kwargs}, open(os.path.join(folder, "vectorizer", "config.json"), "w"))
+    with open(os.path.join(folder, "vectorizer", "tfidf-model.txt"), "w") as f:
+        f.write(f"{len(features)}\n")
+        for fid, idf, toks in features:
+            f.write(f"{fid} {idf!r} {len(toks)}" + "".join(f" {t}" for t in toks) + "\n")
+
+
+@pytest.mark.parametrize("dense_limit", [None, "0"])
+def test_host_half_handmade_models(tmp_path, dense_limit, monkeypatch):
+    # model files written by hand to reach what a trained model seldom holds: tokens of exactly 8, 9 and 40 bytes, a token listed twice
+    # (the last index wins), unigrams whose token index lies far outside the vocabulary, an n-gram that names the UNKNOWN token (-1),
+    # 3- / 4- / 5-grams, an n-gram listed twice (the last feature id wins), truncation in the middle of an n-gram
+    from oracle.tfidf_oracle import TfidfOracle
+    from pecos_amd import clib
+    if dense_limit is not None:
+        monkeypatch.setenv("XRL_TFIDF_DENSE_LIMIT", dense_limit)
+    rng = np.random.default_rng(3)
+    words = [b"a", b"bb", b"ccc", b"12345678", b"123456789", b"x" * 40, b"x" * 41, "日本語".encode(), b"dup", b"e", b"f", b"g"]
+    vocab = [(i, w) for i, w in enumerate(words)] + [(77, b"dup"), (5000000, b"far")]
+    kw = dict(ngram_range=[1, 5], max_length=-1, binary=False, use_idf=True, sublinear_tf=False, norm_p="l2", min_df_ratio=0.0, max_df_ratio=1.0,
+              min_df_cnt=0, max_df_cnt=-1, add_one_idf=False, keep_frequent_feature=True, smooth_idf=True, max_feature=0)
+    grams = [(0,), (1,), (2,), (3,), (4,), (5,), (6,), (7,), (77,), (5000000,), (0, 1), (1, 0), (3, 4), (77, 0), (0, -1), (-1,), (-1, -1, 2),
+             (0, 1, 2), (2, 1, 0), (0, 0, 0, 0), (1, 2, 3, 4, 5), (9, 10, 11), (0, 1)]
+    feats = [(i, 1.0 + 0.25 * i, g) for i, g in enumerate(grams)]
+    # ("small": without the far token index every n-gram up to 9 tokens packs into one u64, and the ones naming -1 still need the general table)
+    for case, over in (("neg", {}), ("trunc", dict(max_length=7)), ("noneg", None), ("small", {})):
+        d = str(tmp_path / f"{case}_{dense_limit}")
+        fs = feats if over is not None else [(i, f[1], f[2]) for i, f in enumerate(f for f in feats if all(t >= 0 for t in f[2]))]
+        if case == "small":
+            fs = [(i, f[1], f[2]) for i, f in enumerate(f for f in feats if 5000000 not in f[2])]
+        _write_base(d, 10, vocab, dict(kw, **(over or {})), fs)
+        O = TfidfOracle(d)
+        h = clib.tfidf_load(d)
+        try:
+            pool = words + [b"far", b"unk", b"another-unknown-token"]
+            docs = [b" ".join(pool[int(i)] for i in rng.integers(0, len(pool), size=int(rng.integers(0, 40)))) for _ in range(400)]
+            docs += [b"a bb ccc", b"a a a a a a a a", b"unk ccc", b"unk unk ccc", b"a unk", b"dup a", b"far", b"bb ccc 12345678 123456789 " + b"x" * 40]
+            _check_counts(clib, h, O, docs, case)
+        finally:
+            clib.tfidf_destruct(h)
+        if dense_limit is None and os.path.isdir(_REFPY):      # the restatement itself on this odd model, against the live reference
+            z = _live_reference_predict(d, [x.decode("utf-8") for x in docs], tmp_path)
+            ip, ix, v = O.predict(docs)
+            assert np.array_equal(z["indptr"], ip) and np.array_equal(z["indices"], ix) and np.array_equal(z["data"].view(np.uint32), v.view(np.uint32)), case
+
+
+def test_host_half_vs_live_reference_pattern(oracle_mod, tmp_path):
+    # where the reference is built here (oracle/_ref/refpy): a larger random corpus through the reference's own c_tfidf_predict; the host
+    # half must produce exactly its rows and feature ids (the weights are the device kernel's half: -m gpu tests)
+    refpy = os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "refpy")
+    if not (oracle_mod.ref_available() and os.path.isdir(refpy)):
+        pytest.skip("oracle/_ref/refpy not built")
+    import subprocess
+    import sys
+    from oracle.tfidf_oracle import TfidfOracle
+    from pecos_amd import clib
+    for name in ("ensemble_word_char", "charwb_bigram", "word_sublinear_addone"):
+        folder, corpus, _ = _case(name)
+        rng = np.random.default_rng(11)
+        words = [f"w{i}" for i in range(250)] + ["naïve", "日本", "語", "café", "x", "unk1", "unk2"]
+        big = [" ".join(rng.choice(words, size=int(rng.integers(0, 150)))) for _ in range(1500)]
+        json.dump(big, open(tmp_path / "big.json", "w"), ensure_ascii=False)
+        code = (f"import sys, json, numpy as np; sys.path.insert(0, {os.path.abspath(refpy)!r})\n"
+                "from pecos.utils.featurization.text.vectorizers import Tfidf\n"
+                f"X = Tfidf.load({folder!r}).predict(json.load(open({str(tmp_path / 'big.json')!r}))).tocsr()\n"
+                f"np.savez({str(tmp_path / 'ref.npz')!r}, indptr=X.indptr, indices=X.indices, data=X.data.astype(np.float32), shape=np.asarray(X.shape))\n")
+        subprocess.check_call([sys.executable, "-c", code])
+        z = np.load(tmp_path / "ref.npz")
+        h = clib.tfidf_load(folder)
+        try:
+            C = clib.tfidf_counts(h, big, threads=4)
+        finally:
+            clib.tfidf_destruct(h)
+        assert tuple(z["shape"]) == C.shape and np.array_equal(C.indptr, z["indptr"]) and np.array_equal(C.indices, z["indices"]), name
+        # and the restatement's weighting of THESE counts reproduces the reference's values
+        O = TfidfOracle(folder)
+        _, _, val = O.predict(big[:300])
+        n = int(z["indptr"][300])
+        assert _ulp_diff(val, z["data"][:n]) <= (1 if any(b.sublinear_tf for b in O.base) else 0), name
+
+
 def test_tfidf_load_errors(tmp_path):
     from pecos_amd import clib
     from pecos_amd.features import Tfidf
