@@ -217,6 +217,32 @@ def test_host_half_vs_live_reference_pattern(oracle_mod, tmp_path):
         assert _ulp_diff(val, z["data"][:n]) <= (1 if any(b.sublinear_tf for b in O.base) else 0), name
 
 
+def test_corpus_packing_forms():
+    # the Python side packs the corpus into one buffer + a pointer table (pecos_amd.core._corpus_arrays): str (ASCII fast path and not),
+    # bytes, mixed lists, an empty corpus, an embedded NUL (the old c_char_p array cut documents there) all give the same matrix
+    from pecos_amd import clib
+    folder, corpus, X = _case("ensemble_word_char")
+    h = clib.tfidf_load(folder)
+    try:
+        A = clib.tfidf_counts(h, corpus)
+        B = clib.tfidf_counts(h, [c.encode("utf-8") for c in corpus])
+        M = clib.tfidf_counts(h, [c.encode("utf-8") if i % 2 else c for i, c in enumerate(corpus)])
+        ascii_only = [c for c in corpus if c.isascii()]
+        S = clib.tfidf_counts(h, ascii_only)
+        for other in (B, M):
+            assert np.array_equal(A.indptr, other.indptr) and np.array_equal(A.indices, other.indices) and np.array_equal(A.data, other.data)
+        keep = np.array([i for i, c in enumerate(corpus) if c.isascii()])
+        assert (S != A[keep]).nnz == 0 and len(ascii_only) < len(corpus)
+        E = clib.tfidf_counts(h, [])
+        assert E.shape == (0, X.shape[1]) and E.nnz == 0
+        two = clib.tfidf_counts(h, ["w1 w2", "w1\x00w2 w3"])
+        assert two.shape[0] == 2 and two.indptr[2] >= two.indptr[1]          # the NUL is an ordinary (unknown) byte inside a token, not the end of the document
+        ref = clib.tfidf_counts(h, ["w1 w2", "w3"])
+        assert set(ref[1].indices) <= set(two[1].indices)
+    finally:
+        clib.tfidf_destruct(h)
+
+
 def test_tfidf_load_errors(tmp_path):
     from pecos_amd import clib
     from pecos_amd.features import Tfidf
