@@ -576,9 +576,18 @@ void TfidfVectorizer::load(const std::string& dir) {
 }
 
 // Documents go to the threads in small dynamic chunks (document lengths are far from uniform); every thread appends to its own arrays and
-// notes where each chunk's output starts; after the prefix sum over chunks the same threads copy their pieces to the final position.
+// notes where each chunk's output starts; after the prefix sum over chunks the caller provides the destination and the threads copy their
+// pieces to their final position in it.
 void TfidfVectorizer::count_corpus(const char* const* corpus, const size_t* doc_lens, size_t nr_doc, int threads, std::vector<uint64_t>& seg_ptr,
                                    std::vector<uint32_t>& col_idx, std::vector<float>& cnt) const {
+    count_corpus(corpus, doc_lens, nr_doc, threads, seg_ptr, [&](uint64_t n, uint32_t*& c, float*& v) {
+        col_idx.resize(n); cnt.resize(n);
+        c = col_idx.data(); v = cnt.data();
+    });
+}
+
+void TfidfVectorizer::count_corpus(const char* const* corpus, const size_t* doc_lens, size_t nr_doc, int threads, std::vector<uint64_t>& seg_ptr,
+                                   const Provide& provide) const {
     // XRL_TFIDF_TIMING=1: one line per call on stderr (count | prefix sum + result pages | copy)
     const bool timing = std::getenv("XRL_TFIDF_TIMING") != nullptr;
     auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -631,7 +640,9 @@ void TfidfVectorizer::count_corpus(const char* const* corpus, const size_t* doc_
     for (const auto& P : parts) if (!P.err.empty()) fail(P.err);
     for (size_t i = 1; i < seg_ptr.size(); ++i) seg_ptr[i] += seg_ptr[i - 1];
     const uint64_t total = seg_ptr.back();
-    col_idx.resize(total); cnt.resize(total);
+    uint32_t* dst_col = nullptr; float* dst_cnt = nullptr;
+    provide(total, dst_col, dst_cnt);
+    if (total && (!dst_col || !dst_cnt)) fail("tfidf: no destination for the term counts");
     std::vector<uint64_t> at(n_chunks + 1, 0);
     for (size_t c = 0; c < n_chunks; ++c) at[c + 1] = at[c] + piece[c].n;
     if (at[n_chunks] != total) fail("tfidf: internal error (chunk sizes)");
@@ -643,12 +654,12 @@ void TfidfVectorizer::count_corpus(const char* const* corpus, const size_t* doc_
             if (c >= n_chunks) break;
             const Piece& pc = piece[c];
             if (!pc.n) continue;
-            std::memcpy(col_idx.data() + at[c], parts[pc.thread].out.col + pc.begin, pc.n * 4);
-            std::memcpy(cnt.data() + at[c], parts[pc.thread].out.val + pc.begin, pc.n * 4);
+            std::memcpy(dst_col + at[c], parts[pc.thread].out.col + pc.begin, pc.n * 4);
+            std::memcpy(dst_cnt + at[c], parts[pc.thread].out.val + pc.begin, pc.n * 4);
         }
     });
     if (timing)
-        std::fprintf(stderr, "[xrl tfidf] %zu documents, %u threads, %zu chunks: count %.2f ms, prefix + result pages %.2f ms, copy %.2f ms (nnz %llu)\n", nr_doc, nt, n_chunks,
+        std::fprintf(stderr, "[xrl tfidf] %zu documents, %u threads, %zu chunks: count %.2f ms, prefix + destination %.2f ms, copy %.2f ms (nnz %llu)\n", nr_doc, nt, n_chunks,
                      t_counted - t_begin, t_sized - t_counted, now_ms() - t_sized, (unsigned long long)total);
 }
 

@@ -10,6 +10,7 @@
 // the threads in small dynamic chunks (profiles/r04_tfidf_host.md).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -160,6 +161,13 @@ struct TfidfVectorizer {
     void load(const std::string& dir);       // Vectorizer::load, tfidf.hpp:1247-1266
     // Host half for a corpus: per (document, base vectorizer) SEGMENT the term counts, laid out as the hstacked CSR (document-major,
     // base vectorizers side by side, column ids offset).  seg_ptr has nr_doc * base.size() + 1 entries.
+    // The CALLER owns the destination: once the total is known `provide(nnz, col, cnt)` is called (on the calling thread) and must hand back
+    // two arrays of nnz elements; the worker threads then write their pieces into them in parallel -- first touch included, which is what
+    // made a std::vector result the slowest phase of the call (17 of 25 ms for 200 k documents: zero fill of fresh pages on one thread).
+    // The allocator callback's numpy arrays and a pinned staging buffer for the H2D copy are such destinations.
+    using Provide = std::function<void(uint64_t nnz, uint32_t*& col, float*& cnt)>;
+    void count_corpus(const char* const* corpus, const size_t* doc_lens, size_t nr_doc, int threads, std::vector<uint64_t>& seg_ptr, const Provide& provide) const;
+    // (the same into vectors: tests, small corpora)
     void count_corpus(const char* const* corpus, const size_t* doc_lens, size_t nr_doc, int threads, std::vector<uint64_t>& seg_ptr,
                       std::vector<uint32_t>& col_idx, std::vector<float>& cnt) const;
 };
