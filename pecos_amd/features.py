@@ -161,6 +161,46 @@ class Tfidf:
         return clib.tfidf_predict_device(self.model, xlinear_model.model.model_chain, corpus, threads)
 
 
+class Preprocessor:
+    """The PREDICT half of ``pecos.utils.featurization.text.preprocess.Preprocessor`` (preprocess.py:22-88), the object ``Text2Text`` keeps as
+    ``self.preprocessor``: ``load`` the folder its ``save`` wrote (``config.json`` = {"type": ..., "kwargs": ...} beside the vectorizer's own
+    files; a folder without it is a tfidf one, vectorizers.py:75-79) and ``predict`` texts.  Only the ``tfidf`` type has a device path; ``hashing``
+    and ``sklearntfidf`` folders raise -- they stay the reference's."""
+
+    def __init__(self, vectorizer=None, config=None):
+        self.vectorizer = vectorizer
+        self.config = config
+
+    @classmethod
+    def load(cls, preprocessor_folder):
+        import json
+        import os
+        cfg_path = os.path.join(preprocessor_folder, "config.json")
+        config = {"type": "tfidf", "kwargs": {}}
+        if os.path.exists(cfg_path):
+            with open(cfg_path, "r", encoding="utf-8") as fin:
+                config = json.loads(fin.read())
+        vtype = config.get("type", None)
+        if vtype is None:
+            raise ValueError(f"{preprocessor_folder} is not a valid vectorizer folder")
+        if vtype != "tfidf":
+            raise NotImplementedError(f"vectorizer type {vtype!r}: only 'tfidf' has a device-resident predict path; use the reference's Preprocessor")
+        return cls(Tfidf.load(preprocessor_folder), config)
+
+    @property
+    def nr_features(self):
+        return self.vectorizer.nr_features
+
+    def predict(self, corpus, **kwargs):
+        """Texts -> scipy CSR (the reference's result, bit for bit)."""
+        if isinstance(corpus, str):
+            raise NotImplementedError("predict from a corpus FILE is not offered by pecos_amd: read the lines and pass a list")
+        return self.vectorizer.predict(corpus, **kwargs)
+
+    def predict_device(self, xlinear_model, corpus, threads=-1):
+        return self.vectorizer.predict_device(xlinear_model, corpus, threads=threads)
+
+
 def _predict_handle_to_csr(model, q, rows, beam_size=None, only_topk=None, post_processor=None):
     import torch
     from .distributed import rows_to_csr
@@ -187,6 +227,8 @@ def predict_text(vectorizer, models, corpus, X_emb=None, normalize_emb=True, thr
 
     kwargs: beam_size, only_topk, post_processor.  Returns the predicted label matrix as scipy CSR (rows score-sorted)."""
     models = list(models) if isinstance(models, (list, tuple)) else [models]
+    if isinstance(vectorizer, Preprocessor):
+        vectorizer = vectorizer.vectorizer
     outs = []
     for m in models:
         q = vectorizer.predict_device(m, corpus, threads=threads)
