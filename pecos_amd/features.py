@@ -252,3 +252,84 @@ def predict_text(vectorizer, models, corpus, X_emb=None, normalize_emb=True, thr
         acc = acc + o
     acc.data /= len(outs)                         # CsrEnsembler.average (pecos/utils/smat_util.py): the mean of the prediction matrices
     return acc.tocsr()
+
+
+def sorted_csr(csr, only_topk=None):
+    """``pecos.utils.smat_util.sorted_csr`` (smat_util.py:174-272): every row ordered by value, descending, ties by ascending column (the
+    reference sorts the columns, then mergesorts -value: stable), optionally cut to the first ``only_topk``; duplicates summed like its
+    ``csr_matrix((val, (row, col)))``.  One lexsort instead of the reference's Python loop over rows."""
+    if not isinstance(csr, smat.csr_matrix):
+        raise ValueError("the input matrix must be a csr_matrix.")
+    c = smat.csr_matrix(csr, copy=True)
+    c.sum_duplicates()                                       # (also sorts the columns inside every row)
+    n = c.shape[0]
+    counts = np.diff(c.indptr)
+    rows = np.repeat(np.arange(n, dtype=np.int64), counts)
+    order = np.lexsort((c.indices, -c.data, rows))           # by row, then -value, then column; NaN last like argsort
+    idx, val = c.indices[order], c.data[order]
+    indptr = c.indptr.astype(np.int64)
+    if only_topk is not None:
+        assert isinstance(only_topk, int), f"Wrong type: type(only_topk) = {type(only_topk)}"
+        only_topk = max(min(1, only_topk), only_topk)        # (the reference's own expression, smat_util.py:198)
+        keep = (np.arange(len(val), dtype=np.int64) - indptr[rows]) < only_topk
+        idx, val = idx[keep], val[keep]
+        indptr = np.concatenate([[0], np.cumsum(np.minimum(counts, only_topk))]).astype(np.int64)
+    return smat.csr_matrix((val, idx.astype(np.int64), indptr), shape=c.shape)
+
+
+def ensemble_average(mats):
+    """``CsrEnsembler.average`` (smat_util.py:828-842): sum, ``sorted_csr``, divide by the number of matrices."""
+    assert all(m.shape == mats[0].shape for m in mats)
+    ret = sorted_csr(sum(mats).tocsr())
+    ret.data /= len(mats)
+    return ret
+
+
+class Text2Text:
+    """The PREDICT half of ``pecos.apps.text2text.model.Text2Text`` (model.py:136-190 load, :389-427 predict) over the device-resident
+    pipeline: ``load`` the folder its ``save`` wrote (``preprocessor/``, ``xlinear_ensemble/{config.json, 0, 1, ...}``, ``output_items.json``),
+    ``predict`` a list of strings -- texts -> term counts (host threads) -> X in HBM -> beam search in place, per model; ensemble average,
+    threshold and the final ``sorted_csr(only_topk)`` as the reference does them.  Training, saving and ``set_output_constraint`` stay the
+    reference's."""
+
+    def __init__(self, preprocessor, xlinear_models, output_items):
+        self.preprocessor = preprocessor
+        self.xlinear_models = xlinear_models
+        self.output_items = output_items
+
+    @classmethod
+    def load(cls, model_folder, is_predict_only=True, **kwargs):
+        import json
+        import os
+        from .xlinear import XLinearModel
+        preprocessor = Preprocessor.load(os.path.join(model_folder, "preprocessor"))
+        xlinear_folder = os.path.join(model_folder, "xlinear_ensemble")
+        with open(os.path.join(xlinear_folder, "config.json"), "r", encoding="utf-8") as fin:
+            ensemble_config = json.loads(fin.read())
+        xlinear_models = []
+        for i, model_kwargs in enumerate(ensemble_config["kwargs"]):
+            xlinear_models += [(XLinearModel.load(os.path.join(xlinear_folder, str(i)), is_predict_only, **kwargs), model_kwargs)]
+        with open(os.path.join(model_folder, "output_items.json"), "r", encoding="utf-8") as fin:
+            output_items = json.load(fin)
+        if not output_items:
+            raise ValueError("Could not read output items saved in json format")
+        return cls(preprocessor, xlinear_models, output_items)
+
+    @staticmethod
+    def finish(Y_pred, threshold=None, only_topk=None):
+        """model.py:418-427 after the per-model predictions: ensemble average, threshold, ``sorted_csr``."""
+        Y = ensemble_average(Y_pred) if len(Y_pred) > 1 else Y_pred[0].tocsr()
+        if threshold is not None:
+            Y = Y.copy()
+            Y.data[Y.data <= threshold] = 0
+            Y.eliminate_zeros()
+        return sorted_csr(Y, only_topk=only_topk)
+
+    def predict(self, corpus, threshold=None, **kwargs):
+        """Same arguments and result as the reference's ``Text2Text.predict`` (``threads`` applies to the tokenizer's host threads)."""
+        threads = kwargs.pop("threads", -1)
+        Y_pred = [predict_text(self.preprocessor, m, corpus, threads=threads, **kwargs) for m, _ in self.xlinear_models]
+        return self.finish(Y_pred, threshold=threshold, only_topk=kwargs.get("only_topk", None))
+
+    def get_output_item(self, output_id):
+        return self.output_items[output_id]
