@@ -320,6 +320,33 @@ def test_text2text_finish_matches_the_reference_semantics():
     assert rng is not None
 
 
+def test_sorted_csr_and_average_vs_live_reference(tmp_path):
+    # where the reference's python package is at hand (oracle/_ref/refpy, this container only): smat_util.sorted_csr / CsrEnsembler.average
+    # themselves on random matrices full of ties, with NaN, -0.0 and 0.0 among the values
+    if not os.path.isdir(_REFPY):
+        pytest.skip("oracle/_ref/refpy not built")
+    import subprocess
+    import sys
+    code = f"""
+import sys, numpy as np, scipy.sparse as smat
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {_REFPY!r})
+from pecos.utils import smat_util
+from pecos_amd.features import sorted_csr, ensemble_average
+bad = 0
+for t in range(25):
+    M = smat.random(50, 30, density=0.3, format='csr', dtype=np.float32, random_state=t); M.data = np.round(M.data, 1).astype(np.float32)
+    if t % 5 == 0 and M.nnz > 3: M.data[:3] = [np.nan, -0.0, 0.0]
+    for k in (None, 1, 5):
+        a = sorted_csr(M, only_topk=k); b = smat_util.sorted_csr(M, only_topk=k)
+        bad += not (np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data, equal_nan=True))
+    N = smat.random(50, 30, density=0.3, format='csr', dtype=np.float32, random_state=100 + t); N.data = np.round(N.data, 1).astype(np.float32)
+    a = ensemble_average([M, N]); b = smat_util.CsrEnsembler.average(M, N)
+    bad += not (np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data, equal_nan=True))
+sys.exit(1 if bad else 0)
+"""
+    assert subprocess.run([sys.executable, "-c", code]).returncode == 0
+
+
 def test_tfidf_load_errors(tmp_path):
     from pecos_amd import clib
     from pecos_amd.features import Tfidf
