@@ -347,6 +347,50 @@ sys.exit(1 if bad else 0)
     assert subprocess.run([sys.executable, "-c", code]).returncode == 0
 
 
+def test_host_half_properties_at_scale(tmp_path, monkeypatch):
+    # size-independent properties on a corpus far beyond what the Python restatement can check (60 k documents, 4.5 M tokens, a 40 k-word
+    # vectorizer written here in the reference's file format): (1) the result does not depend on the thread count or on the counting path;
+    # (2) LINEARITY of a unigram vectorizer: counts("a b") = counts("a") + counts("b"); (3) every row's counts sum to the number of known tokens;
+    # (4) a permutation of the documents permutes the rows
+    from pecos_amd import clib
+    rng = np.random.default_rng(5)
+    V, n = 40000, 60000
+    words = [f"t{i:x}".encode() for i in range(V)]
+    d = str(tmp_path / "uni")
+    kw = dict(ngram_range=[1, 1], max_length=-1, binary=False, use_idf=True, sublinear_tf=False, norm_p="l2", min_df_ratio=0.0, max_df_ratio=1.0,
+              min_df_cnt=0, max_df_cnt=-1, add_one_idf=False, keep_frequent_feature=True, smooth_idf=True, max_feature=0)
+    perm = rng.permutation(V)
+    _write_base(d, 10, [(i, w) for i, w in enumerate(words)], kw, [(int(perm[i]), 1.0 + (i % 7), (i,)) for i in range(V)])
+    p = 1.0 / np.arange(1, V + 1) ** 1.07; p /= p.sum()
+    lens = np.maximum(1, rng.poisson(75, size=n))
+    ids = rng.choice(V, size=int(lens.sum()), p=p)
+    unk = rng.random(len(ids)) < 0.02                                   # 2 % unknown tokens
+    toks = np.array(words + [b"zz-unknown"], dtype=object)[np.where(unk, V, ids)]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    docs = [b" ".join(toks[off[i]:off[i + 1]]) for i in range(n)]
+    h = clib.tfidf_load(d)
+    try:
+        A = clib.tfidf_counts(h, docs, threads=1)
+        B = clib.tfidf_counts(h, docs, threads=7)
+        monkeypatch.setenv("XRL_TFIDF_DENSE_LIMIT", "0")
+        S = clib.tfidf_counts(h, docs, threads=3)
+        monkeypatch.delenv("XRL_TFIDF_DENSE_LIMIT")
+        for other in (B, S):
+            assert np.array_equal(A.indptr, other.indptr) and np.array_equal(A.indices, other.indices) and np.array_equal(A.data, other.data)
+        known = np.add.reduceat((~unk).astype(np.int64), off[:-1])
+        assert np.array_equal(np.asarray(A.sum(axis=1)).ravel().astype(np.int64), known)
+        half = n // 2
+        joined = [docs[i] + b" " + docs[half + i] for i in range(half)]
+        J = clib.tfidf_counts(h, joined, threads=4)
+        want = (A[:half] + A[half:2 * half]).tocsr(); want.sort_indices()
+        assert np.array_equal(J.indptr, want.indptr) and np.array_equal(J.indices, want.indices) and np.array_equal(J.data, want.data)
+        order = rng.permutation(n)
+        P = clib.tfidf_counts(h, [docs[i] for i in order], threads=5)
+        assert (P != A[order]).nnz == 0
+    finally:
+        clib.tfidf_destruct(h)
+
+
 def test_tfidf_load_errors(tmp_path):
     from pecos_amd import clib
     from pecos_amd.features import Tfidf
