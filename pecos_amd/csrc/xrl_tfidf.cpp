@@ -342,28 +342,27 @@ void sort_ids(uint32_t* src, size_t n, uint32_t* dst, unsigned shift) {
 inline void grow(std::vector<uint64_t>& v, size_t n) { if (v.size() < n) v.resize(n + n / 2 + 64); }
 inline void grow(std::vector<uint32_t>& v, size_t n) { if (v.size() < n) v.resize(n + n / 2 + 64); }
 inline void grow(std::vector<int32_t>& v, size_t n) { if (v.size() < n) v.resize(n + n / 2 + 64); }
-inline void grow(std::vector<const char*>& v, size_t n) { if (v.size() < n) v.resize(n + n / 2 + 64); }
 }  // namespace
 
 size_t TfidfBase::count(const char* doc, size_t len, TfidfScratch& S, uint32_t col_off, TfidfOut& O) const {
     const char* p = doc; const char* const last = doc + len;
     // the scratch arrays only ever grow (no per-document clearing): a word document has at most (len + 1) / 2 tokens, a character one len
     const size_t tok_bound = std::min<size_t>(max_length > 0 ? (size_t)max_length : ~(size_t)0, tok_type == 10 ? (len + 1) / 2 : len);
-    grow(S.key, tok_bound + 1); grow(S.len, tok_bound + 1); grow(S.ptr, tok_bound + 1); grow(S.tok, tok_bound + 1); grow(S.run, tok_bound + 2);
-    uint64_t* const K = S.key.data(); uint32_t* const L = S.len.data(); const char** const P = S.ptr.data();
+    grow(S.key, tok_bound + 1); grow(S.len, tok_bound + 1); grow(S.aux, tok_bound + 1); grow(S.tok, tok_bound + 1); grow(S.run, tok_bound + 2);
+    uint64_t* const K = S.key.data(); uint32_t* const L = S.len.data(); uint64_t* const A = S.aux.data();
     size_t T = 0;
     const TokenTable::Short* const vs = vocab.s.data();
-    // pass 1: token boundaries, the lookup key of every token, its table slot on the way into the cache.  L keeps the byte length of a long
-    // token (> 8) and, for a short one, the slot (the length travels in the top byte).
+    // pass 1: token boundaries, the lookup key of every token, its table slot on the way into the cache.  A keeps a short token's table slot,
+    // a long token's offset in the document.
     auto note_short = [&](uint64_t k, size_t n) {
         const size_t slot = vocab.short_slot(k, (uint32_t)n);
         __builtin_prefetch(vs + slot);
-        K[T] = k; L[T] = (uint32_t)n; P[T] = reinterpret_cast<const char*>(slot); ++T;
+        K[T] = k; L[T] = (uint32_t)n; A[T] = (uint64_t)slot; ++T;
     };
     auto note_long = [&](const char* b, size_t n) {
         const uint64_t h = TokenTable::hash_long(b, n);
         if (!vocab.l.empty()) __builtin_prefetch(&vocab.l[(size_t)(h >> vocab.l_shift)]);
-        K[T] = h; L[T] = (uint32_t)std::min<size_t>(n, 0xFFFFFFFFu); P[T] = b; ++T;
+        K[T] = h; L[T] = (uint32_t)std::min<size_t>(n, 0xFFFFFFFFu); A[T] = (uint64_t)(b - doc); ++T;
     };
     if (tok_type == 10) {
         while (p < last) {
@@ -403,7 +402,7 @@ size_t TfidfBase::count(const char* doc, size_t len, TfidfScratch& S, uint32_t c
     // pass 2: token indices (unknown -> -1)
     int32_t* const tok = S.tok.data();
     for (size_t i = 0; i < T; ++i)
-        tok[i] = L[i] <= 8 ? vocab.find_short(K[i], L[i], reinterpret_cast<size_t>(P[i])) : vocab.find_long(P[i], L[i], K[i]);
+        tok[i] = L[i] <= 8 ? vocab.find_short(K[i], L[i], (size_t)A[i]) : vocab.find_long(doc + A[i], L[i], K[i]);
     // run[i] = tokens in a row from i that the model's n-grams name at all (0 <= index <= max_tok): an n-gram with any other token in it can
     // only be a feature through the general table, and only when the model file names negative token indices
     const NgramTable& G = features;

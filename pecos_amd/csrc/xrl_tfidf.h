@@ -116,7 +116,7 @@ struct TfidfScratch {
     // (sized for the longest document seen so far, never cleared)
     std::vector<uint64_t> key;      // per token: inline key or hash; per n-gram: key / hash
     std::vector<uint32_t> len;      // per token: byte length
-    std::vector<const char*> ptr;   // per token: first byte (long tokens) or the table slot (short ones)
+    std::vector<uint64_t> aux;      // per token: the table slot (tokens of <= 8 bytes) or the offset of its first byte in the document (longer ones)
     std::vector<int32_t> tok;       // token indices
     std::vector<int32_t> run;       // tokens in a row from here on that some n-gram of the model names (0 <= index <= max_tok)
     std::vector<uint32_t> feat;     // feature ids found (one per occurrence), then the same sorted
