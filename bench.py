@@ -57,24 +57,20 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-# host-only sources that no kernel launch of the bench path depends on (the TF-IDF producer's tokenizer / n-gram tables): editing them cannot
-# change a counter, so they are not part of the stamp
-_NOT_ON_THE_KERNEL_PATH = ("xrl_tfidf.cpp", "xrl_tfidf.h")
+# the sources a kernel launch of the bench path is built from: a counter set is valid for exactly these (host-only files -- the C ABI glue, the
+# folder readers, the TF-IDF producer's host half -- cannot change a counter, so editing them does not mark the sets stale)
+_KERNEL_PATH = ("xrl_device.h", "xrl_kernels.h", "xrl_items.h", "xrl_common.h", "xrl_predict.cpp", "xrl_predict.h", "xrl_model.cpp", "xrl_model.h", "Makefile")
 
 
 def csrc_sha16():
-    """First 16 hex digits of the SHA-256 over the kernel / host sources the beam search is built from (file names and contents, sorted;
-    pecos_amd/csrc/*.{hip,cpp,h} + Makefile, minus _NOT_ON_THE_KERNEL_PATH): profiles/pmc_traffic.json records it with every counter set,
-    and a line only quotes counters taken on the SAME sources.  (Round-4 lines quote the stamp over ALL files, fc616626fe74faad; the
-    counter file keeps it as csrc_sha16_all_files -- same commit, same kernels.)"""
+    """First 16 hex digits of the SHA-256 over the KERNEL-PATH sources (file names and contents, sorted: pecos_amd/csrc/*.hip + _KERNEL_PATH):
+    profiles/pmc_traffic.json records it with every counter set, and a line only quotes counters taken on the SAME sources."""
     import hashlib
     h = hashlib.sha256()
     root = os.path.join(REPO, "pecos_amd", "csrc")
     for name in sorted(os.listdir(root)):
         path = os.path.join(root, name)
-        if name in _NOT_ON_THE_KERNEL_PATH:
-            continue
-        if os.path.isfile(path) and name.rsplit(".", 1)[-1] in ("hip", "cpp", "h") or name == "Makefile":
+        if os.path.isfile(path) and (name.endswith(".hip") or name in _KERNEL_PATH):
             h.update(name.encode()); h.update(b"\0"); h.update(open(path, "rb").read()); h.update(b"\0")
     return h.hexdigest()[:16]
 

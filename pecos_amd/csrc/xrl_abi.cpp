@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <thread>
 
 #include "xrl_predict.h"
@@ -1339,23 +1340,71 @@ uint64_t xrl_model_device_bytes(void* model) {
 }  // extern "C"
 
 namespace {
+// pinned staging for the H2D copy of the term counts: the worker threads of the host half write straight into it (no intermediate, no page
+// faults -- pinned memory is resident), and the copy runs at link speed instead of through the runtime's pageable path.  Grows, never shrinks;
+// one producer call per handle at a time uses it.
+struct PinnedStage {
+    void* p = nullptr; size_t cap = 0; std::mutex mu;
+    ~PinnedStage() { if (p) (void)hipHostFree(p); }
+    void* need(size_t bytes) {
+        if (bytes > cap) {
+            if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+            const size_t want = bytes + bytes / 4 + (1u << 20);
+            XRL_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+            cap = want;
+        }
+        return p;
+    }
+};
+
+// dst <- src on host threads, 1 MiB pieces
+void parallel_copy(void* dst, const void* src, size_t bytes, int threads) {
+    const size_t piece = (size_t)1 << 20, n = (bytes + piece - 1) / piece;
+    unsigned nt = threads > 0 ? (unsigned)threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = (unsigned)std::max<size_t>(1, std::min<size_t>(nt, n));
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= n) break;
+            std::memcpy(static_cast<char*>(dst) + i * piece, static_cast<const char*>(src) + i * piece, std::min(piece, bytes - i * piece));
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+
 struct TfidfHandle {
     TfidfVectorizer v;
     std::vector<float> idf_all;                  // the base vectorizers' idf side by side (hstack column order)
+    mutable PinnedStage stage;
 };
 
-// texts -> term counts (host threads) -> device -> weighting + normalisation (K5): a query handle that owns its three arrays
+// texts -> term counts (host threads, into pinned staging) -> device -> weighting + normalisation (K5): a query handle that owns its three arrays
 std::unique_ptr<Queries> tfidf_to_device(const TfidfHandle& H, const char* const* corpus, const size_t* doc_lens, size_t nr_doc, int threads, int device, hipStream_t s) {
     if (nr_doc > 0xFFFFFFFFull) fail("tfidf: too many documents");
     const TfidfVectorizer& V = H.v;
     const uint32_t nb = (uint32_t)V.base.size(), rows = (uint32_t)nr_doc;
-    std::vector<uint64_t> seg_ptr; std::vector<uint32_t> col; std::vector<float> cnt;
-    V.count_corpus(corpus, doc_lens, nr_doc, threads, seg_ptr, col, cnt);
     use_device(device);
+    std::lock_guard<std::mutex> stage_lock(H.stage.mu);          // held until the stream has consumed the staging buffer (the synchronize below)
+    std::vector<uint64_t> seg_ptr;
+    uint32_t* h_col = nullptr; float* h_cnt = nullptr; uint64_t nnz = 0;
+    V.count_corpus(corpus, doc_lens, nr_doc, threads, seg_ptr, [&](uint64_t n, uint32_t*& c, float*& v) {
+        char* base = static_cast<char*>(H.stage.need((size_t)n * 8 + 16));
+        c = h_col = reinterpret_cast<uint32_t*>(base); v = h_cnt = reinterpret_cast<float*>(base + (size_t)n * 4);
+        nnz = n;
+    });
     auto q = std::make_unique<Queries>();
-    q->device = device; q->nnz = col.size();
+    q->device = device; q->nnz = nnz;
     DevBuf d_seg, d_idf, d_err;
-    d_seg.upload(seg_ptr); q->idx.upload(col); q->val.upload(cnt);
+    d_seg.upload(seg_ptr);
+    q->idx.reserve((size_t)nnz * 4); q->val.reserve((size_t)nnz * 4);
+    if (nnz) {
+        XRL_HIP(hipMemcpyAsync(q->idx.p, h_col, (size_t)nnz * 4, hipMemcpyHostToDevice, s));
+        XRL_HIP(hipMemcpyAsync(q->val.p, h_cnt, (size_t)nnz * 4, hipMemcpyHostToDevice, s));
+    }
     d_idf.upload(H.idf_all);
     d_err.reserve(4); XRL_HIP(hipMemsetAsync(d_err.p, 0, 4, s));
     for (uint32_t b = 0; b < nb; ++b) {
@@ -1423,8 +1472,15 @@ void c_tfidf_predict(void* ptr, void* corpus_ptr, const size_t* doc_lens, size_t
         if (!indptr || (q->nnz && (!indices || !data))) fail("allocator returned null");
         XRL_HIP(hipMemcpy(indptr, q->dev.row_ptr, ((size_t)q->dev.rows + 1) * 8, hipMemcpyDeviceToHost));
         if (q->nnz) {
-            XRL_HIP(hipMemcpy(indices, q->dev.col_idx, q->nnz * 4, hipMemcpyDeviceToHost));
-            XRL_HIP(hipMemcpy(data, q->dev.val, q->nnz * 4, hipMemcpyDeviceToHost));
+            // D2H into the pinned staging buffer (link speed), then host threads spread it over the allocator's fresh arrays: their first touch
+            // in parallel, instead of the runtime's single-threaded pageable path
+            std::lock_guard<std::mutex> stage_lock(H.stage.mu);
+            const size_t nb4 = (size_t)q->nnz * 4;
+            char* st = static_cast<char*>(H.stage.need(2 * nb4));
+            XRL_HIP(hipMemcpy(st, q->dev.col_idx, nb4, hipMemcpyDeviceToHost));
+            XRL_HIP(hipMemcpy(st + nb4, q->dev.val, nb4, hipMemcpyDeviceToHost));
+            parallel_copy(indices, st, nb4, threads);
+            parallel_copy(data, st + nb4, nb4, threads);
         }
     });
 }
@@ -1453,14 +1509,16 @@ void xrl_tfidf_counts(void* ptr, void* corpus_ptr, const size_t* doc_lens, size_
     guarded([&] {
         if (!ptr || !alloc || (nr_doc && (!corpus_ptr || !doc_lens))) fail("xrl_tfidf_counts: null argument");
         const TfidfVectorizer& V = static_cast<TfidfHandle*>(ptr)->v;
-        std::vector<uint64_t> seg_ptr; std::vector<uint32_t> col; std::vector<float> cnt;
-        V.count_corpus(static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, seg_ptr, col, cnt);
+        std::vector<uint64_t> seg_ptr;
         uint32_t* indices = nullptr; uint64_t* indptr = nullptr; float* data = nullptr;
-        alloc(false, nr_doc, V.nr_features, col.size(), &indices, &indptr, &data);
-        if (!indptr || (!col.empty() && (!indices || !data))) fail("allocator returned null");
+        // the allocator's arrays ARE the destination: the worker threads fill (and first-touch) them in parallel
+        V.count_corpus(static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, seg_ptr, [&](uint64_t n, uint32_t*& c, float*& v) {
+            alloc(false, nr_doc, V.nr_features, n, &indices, &indptr, &data);
+            if (!indptr || (n && (!indices || !data))) fail("allocator returned null");
+            c = indices; v = data;
+        });
         const size_t nb = V.base.size();
         for (size_t r = 0; r <= nr_doc; ++r) indptr[r] = seg_ptr[r * nb];
-        if (!col.empty()) { std::memcpy(indices, col.data(), col.size() * 4); std::memcpy(data, cnt.data(), cnt.size() * 4); }
     });
 }
 

@@ -326,20 +326,3 @@ def test_tfidf_weighting_mirror_vs_reference_goldens(manifest):
             assert np.array_equal(got.data.view(np.uint32), want.data.view(np.uint32)), c
         empty_rows += int((np.diff(want.indptr) == 0).sum())
     assert empty_rows > 0                                 # documents without any known feature are covered
-
-
-def test_pending_patches_apply():
-    # patches/ holds changes that are validated and measured but not applied (they would invalidate the counter stamps, patches/README.md):
-    # they must keep applying to the tree they wait for
-    import glob
-    import subprocess
-    pats = sorted(glob.glob(os.path.join(REPO, "patches", "*.patch")))
-    if not pats:
-        pytest.skip("no pending patches")
-    try:
-        subprocess.check_output(["git", "rev-parse", "--git-dir"], cwd=REPO, stderr=subprocess.DEVNULL)
-    except Exception:
-        pytest.skip("no git here")
-    for p in pats:
-        r = subprocess.run(["git", "apply", "--check", p], cwd=REPO, capture_output=True, text=True)
-        assert r.returncode == 0, (p, r.stderr)
