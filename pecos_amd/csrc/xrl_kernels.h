@@ -58,6 +58,10 @@ void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const
 void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, void* sorted, uint32_t* H,
                        uint32_t* start, hipStream_t s,
                        const uint32_t* n_dev = nullptr);   // n_dev: device count of a compacted list (<= n_slots)
+// counting sort of the QUERIES of a row batch by the best parent of their beam (slot 0), as a permutation: perm[slot] = query (K1Q's sorted launch)
+void launch_sort_queries(BeamDev prev, uint32_t nrows, uint32_t n_keys, uint32_t* H, uint32_t* start, uint32_t* perm, hipStream_t s);
+uint32_t qsort_max_keys();
+size_t qsort_hist_bytes(uint32_t nrows, uint32_t n_keys);
 uint32_t sort_max_tiles();
 size_t sort_hist_bytes(uint64_t n_slots, uint32_t n_tiles);
 // K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.
@@ -106,7 +110,8 @@ int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
 uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k, bool dense_x);   // 0: the layer / beam / k cannot (or should not) be served by K1Q
 // n consecutive dense-format layers in ONE launch (the beam stays in LDS between them); n <= 8
 void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const QueriesDev& X, BeamDev prev, uint32_t* out_idx, float* out_val,
-                uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, float prune_wmax, uint32_t* out_xok = nullptr);
+                uint32_t* out_cnt, uint32_t out_stride, hipStream_t s, float prune_wmax, uint32_t* out_xok = nullptr,
+                const uint32_t* qperm = nullptr /* launch slot -> query (launch_sort_queries); every XCD then takes a contiguous range of slots */);
                 // prune_wmax / out_xok: the bound-pruning guard (prune_guard_ok, xrl_device.h); out_xok[q] receives every query's flag
 size_t k2_max_k();
 

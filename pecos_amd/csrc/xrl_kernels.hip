@@ -232,6 +232,58 @@ void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, v
     XRL_LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Query ordering for a query-stationary layer (K1Q): counting sort of the QUERIES by the best parent of their beam
+// (beam slot 0 = the parent whose children a query most likely keeps), written as a permutation.  K1Q then runs query perm[i] in
+// launch slot i and hands every XCD a CONTIGUOUS range of slots (xrl_k1q.hip), so that the queries of one region of the tree -- which
+// share most of their beam parents and, on topical data, many of their features -- request their (feature, parent) weight segments
+// through the same L2 at about the same time.  The reference orders its (query, chunk) work by chunk for the same reason
+// (inference.hpp:969-993).  Results do not depend on the order: every query writes to its own row of the output.
+// Same scheme as the item sort: per-block LDS histograms, per-(block, key) offsets, LDS-ranked scatter.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kQSortChunk = 2048;   // queries per block
+
+__device__ __forceinline__ uint32_t qsort_key(const uint32_t* __restrict__ p_idx, const uint32_t* __restrict__ p_cnt, uint32_t p_stride, uint32_t q, uint32_t T) {
+    return p_cnt[q] ? min(p_idx[(size_t)q * p_stride], T - 1u) : T - 1u;
+}
+
+__global__ void __launch_bounds__(256)
+qsort_hist_kernel(const uint32_t* __restrict__ p_idx, const uint32_t* __restrict__ p_cnt, uint32_t p_stride, uint32_t nrows, uint32_t T, uint32_t* __restrict__ H) {
+    extern __shared__ uint32_t hist[];
+    for (uint32_t t = threadIdx.x; t < T; t += 256) hist[t] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kQSortChunk;
+    for (uint32_t i = threadIdx.x; i < kQSortChunk && base + i < nrows; i += 256) atomicAdd(&hist[qsort_key(p_idx, p_cnt, p_stride, base + i, T)], 1u);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < T; t += 256) H[(size_t)blockIdx.x * T + t] = hist[t];
+}
+
+__global__ void __launch_bounds__(256)
+qsort_scatter_kernel(const uint32_t* __restrict__ p_idx, const uint32_t* __restrict__ p_cnt, uint32_t p_stride, uint32_t nrows, uint32_t T,
+                     const uint32_t* __restrict__ H, const uint32_t* __restrict__ start, uint32_t* __restrict__ perm) {
+    extern __shared__ uint32_t pos[];
+    for (uint32_t t = threadIdx.x; t < T; t += 256) pos[t] = start[t] + H[(size_t)blockIdx.x * T + t];
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kQSortChunk;
+    for (uint32_t i = threadIdx.x; i < kQSortChunk && base + i < nrows; i += 256)
+        perm[atomicAdd(&pos[qsort_key(p_idx, p_cnt, p_stride, base + i, T)], 1u)] = base + i;
+}
+
+uint32_t qsort_max_keys() { return 12288; }   // LDS histogram of 4 B per key: 48 KiB, no opt-in needed
+size_t qsort_hist_bytes(uint32_t nrows, uint32_t T) { return ((size_t)(nrows + kQSortChunk - 1) / kQSortChunk) * (size_t)T * 4; }
+
+void launch_sort_queries(BeamDev prev, uint32_t nrows, uint32_t n_keys, uint32_t* H, uint32_t* start /*[n_keys+1]*/, uint32_t* perm, hipStream_t s) {
+    if (nrows == 0) return;
+    if (n_keys == 0 || n_keys > qsort_max_keys()) fail("sort_queries: key range outside the LDS histogram");
+    const uint32_t B = (nrows + kQSortChunk - 1) / kQSortChunk;
+    const size_t lds = (size_t)n_keys * 4;
+    hipLaunchKernelGGL(qsort_hist_kernel, dim3(B), dim3(256), lds, s, prev.idx, prev.cnt, prev.stride, nrows, n_keys, H);
+    hipLaunchKernelGGL(sort_colsum_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, s, H, B, nullptr, n_keys, start);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, s, start, n_keys);
+    hipLaunchKernelGGL(qsort_scatter_kernel, dim3(B), dim3(256), lds, s, prev.idx, prev.cnt, prev.stride, nrows, n_keys, H, start, perm);
+    XRL_LAUNCH_CHECK();
+}
+
 // XCD-aware block remap (blocks b, b+8, b+16, ... run on one XCD): give every XCD a CONTIGUOUS
 // range of the tile-sorted work so a tile's data is fetched into one L2 only.  Bijective on [0, nb).
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {

@@ -473,6 +473,9 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
             const uint64_t n_dtiles = d_tcol.size() - 2;
             if (n_dtiles >= 16 && d_gp_log2 >= 1 && d_gp_log2 <= 5 && presence_enabled()) {
                 pres_words = 1; while ((uint64_t)pres_words * 32 < n_dtiles) pres_words <<= 1;
+                if (((uint64_t)W.rows + 1) * pres_words * 4 >= (1ull << 31)) pres_words = 0;   // K1Q addresses the whole array through ONE buffer resource
+            }
+            if (pres_words) {
                 L->d_pres.reserve(((size_t)W.rows + 1) * pres_words * 4);
                 launch_presence(L->d_wd.as<uint32_t>(), d_ld, W.rows + 1, d_gp_log2, (uint32_t)n_dtiles, pres_words, L->d_pres.as<uint32_t>(), nullptr);
             }

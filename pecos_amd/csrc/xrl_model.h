@@ -134,6 +134,7 @@ struct LaneWs {      // scratch of one row batch in flight
     DevBuf cand_off, ncand, cand;
     DevBuf items, items_sorted, sort_hist, sort_start;   // item descriptors (K0) and their tile-sorted copy
     DevBuf blk_start, x_ok;                              // K1G: first workgroup of every tile; per-row "all x finite" flags
+    DevBuf qperm, qsort_hist, qsort_start;               // K1Q's sorted launch: launch slot -> query, and the counting sort's scratch
     DevBuf prune_done, prune_cnt;                        // bound-pruned layers: per-query "first phase was final" flags; item count of the second phase
 };
 struct Workspace {
@@ -196,6 +197,9 @@ struct Model {
                                             // segment only when the layer's presence word says it holds a weight; 2 = every layer that has presence words; 0 = never
     int prune_mid = 1;                      // bound-pruned tile-format layers with >= 16 beam parents: a middle stage (slots 1..4) between the first parent and "everything else"
     int sort_rest = 1;                      // bound-pruned tile-format layers: the second phase's compacted items are tile-sorted before K1 runs on them (0: query order)
+    int qsort = 1;                          // K1Q, sparse X: the last layer of a run of dense-format layers runs on queries SORTED by the best parent of their beam,
+                                            // every XCD on a contiguous range of them (xrl_predict.cpp), when it has >= qsort_min_parents parents and the batch >= qsort_min_rows rows
+    int qsort_min_parents = 64, qsort_min_rows = 16384;
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
     // multi-GPU behind the drop-in entry points (xrl_set_option "devices"): further copies of the compiled model on other devices; the
     // host-ABI predict shards the rows over this handle's device and the replicas' (xrl_abi.cpp predict_host)

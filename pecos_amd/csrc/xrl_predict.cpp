@@ -292,14 +292,44 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                     Q.prune = (m.prune && !(ll < (size_t)Model::kFbLayers && unst[ll])) ? 1 : 0;
                     Ps[ll - l] = Q;
                 }
-                uint32_t *qi, *qc; float* qv; uint32_t qs;
-                if (l1 == T - 1) { qi = d_out_idx + row0 * out_stride; qv = d_out_val + row0 * out_stride; qc = d_out_cnt + row0; qs = out_stride; }
-                else { const int b = (int)(l1 & 1); qi = lw.beam_idx[b].as<uint32_t>(); qv = lw.beam_val[b].as<float>(); qc = lw.beam_cnt[b].as<uint32_t>(); qs = beam_stride; }
-                const std::string nm = (l1 > l) ? std::string(X.dense ? "k1q_fused_x_" : "k1q_fused_") + std::to_string(l) + "_" + std::to_string(l1) : std::string(X.dense ? "k1q_dense_x" : "k1q_dense");
+                auto beam_out = [&](size_t ll, uint32_t*& qi, float*& qv, uint32_t*& qc, uint32_t& qs) {
+                    if (ll == T - 1) { qi = d_out_idx + row0 * out_stride; qv = d_out_val + row0 * out_stride; qc = d_out_cnt + row0; qs = out_stride; }
+                    else { const int b = (int)(ll & 1); qi = lw.beam_idx[b].as<uint32_t>(); qv = lw.beam_val[b].as<float>(); qc = lw.beam_cnt[b].as<uint32_t>(); qs = beam_stride; }
+                };
+                auto launch_name = [&](size_t a, size_t b) {
+                    return (b > a) ? std::string(X.dense ? "k1q_fused_x_" : "k1q_fused_") + std::to_string(a) + "_" + std::to_string(b) : std::string(X.dense ? "k1q_dense_x" : "k1q_dense");
+                };
                 // (a later layer of this batch that is NOT served by K1Q decides its pruning in K2 and needs the guard flags: this launch writes them)
                 uint32_t* xok_out = nullptr;
                 if (!x_ok_done && m.prune && l1 + 1 < T) { lw.x_ok.reserve((size_t)nb * 4); xok_out = lw.x_ok.as<uint32_t>(); x_ok_done = true; }
-                timed(nm.c_str(), (uint32_t)l, [&] { launch_k1q(Ls, Ps, (int)(l1 - l + 1), X, prev, qi, qv, qc, qs, S, prune_wmax, xok_out); });
+                // SORTED launch of the group's last layer (option qsort): a layer of many parents whose matrix is far larger than the L2s is
+                // request-bound -- one 64-byte fabric request per (feature, beam parent) and query -- and the queries that share beam
+                // parents are scattered over the batch.  The layers before it run as usual; the queries are then counting-sorted by the best
+                // parent of the beam they produced and the last layer runs in that order, every XCD on a contiguous range of it.
+                const size_t ls = l1;
+                const bool sorted_last = m.qsort != 0 && !X.dense && ls > 0 && !(ls == 0 && has_init) && nrows >= (uint32_t)std::max(1, m.qsort_min_rows) &&
+                                         m.layers[ls]->dev.n_parents >= (uint32_t)std::max(2, m.qsort_min_parents) && m.layers[ls]->dev.n_parents <= qsort_max_keys();
+                if (sorted_last) {
+                    BeamDev pv = prev;
+                    if (ls > l) {
+                        uint32_t *qi, *qc; float* qv; uint32_t qs;
+                        beam_out(ls - 1, qi, qv, qc, qs);
+                        timed(launch_name(l, ls - 1).c_str(), (uint32_t)l, [&] { launch_k1q(Ls, Ps, (int)(ls - l), X, prev, qi, qv, qc, qs, S, prune_wmax, xok_out); });
+                        xok_out = nullptr;
+                        pv = BeamDev{qi, qv, qc, qs};
+                    }
+                    const uint32_t nk = m.layers[ls]->dev.n_parents;
+                    lw.qperm.reserve((size_t)nb * 4); lw.qsort_hist.reserve(qsort_hist_bytes((uint32_t)nb, nk)); lw.qsort_start.reserve(((size_t)nk + 1) * 4);
+                    timed("k1_sort_queries", (uint32_t)ls, [&] { launch_sort_queries(pv, nrows, nk, lw.qsort_hist.as<uint32_t>(), lw.qsort_start.as<uint32_t>(), lw.qperm.as<uint32_t>(), S); });
+                    uint32_t *qi, *qc; float* qv; uint32_t qs;
+                    beam_out(ls, qi, qv, qc, qs);
+                    timed(X.dense ? "k1q_dense_x" : "k1q_dense", (uint32_t)ls, [&] { launch_k1q(Ls + (ls - l), Ps + (ls - l), 1, X, pv, qi, qv, qc, qs, S, prune_wmax, xok_out, lw.qperm.as<uint32_t>()); });
+                    l = l1;
+                    continue;
+                }
+                uint32_t *qi, *qc; float* qv; uint32_t qs;
+                beam_out(l1, qi, qv, qc, qs);
+                timed(launch_name(l, l1).c_str(), (uint32_t)l, [&] { launch_k1q(Ls, Ps, (int)(l1 - l + 1), X, prev, qi, qv, qc, qs, S, prune_wmax, xok_out); });
                 l = l1;
                 continue;
             }

@@ -10,8 +10,9 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 sys.path.insert(0, REPO)
 import test_kernel_resources as T  # noqa: E402
 
-HOT = ["k1q_kernel<3, 0, false, true, false, false>", "k1q_kernel<3, 0, false, true, false, true>", "k1q_kernel<1, 0, false, true, false, false>",
-       "k1q_kernel<6, 0, false, false, false, false>", "k1q_kernel<16, 0, false, false, true, false>",
+HOT = ["k1q_kernel<3, 0, false, true, false, false, false>", "k1q_kernel<3, 0, false, false, false, false, true>", "k1q_kernel<3, 0, false, true, false, true, false>",
+       "k1q_kernel<3, 0, false, false, false, true, true>", "k1q_kernel<3, 0, false, true, false, false, true>", "k1q_kernel<1, 0, false, true, false, false, false>",
+       "k1q_kernel<6, 0, false, false, false, false, false>", "k1q_kernel<16, 0, false, false, false, false, false>",
        "k1_kernel<32, 3, 0, false, 2>", "k1_kernel<16, 1, 0, false, 0>", "k1_kernel<32, 1, 0, false, 0>", "k1g_kernel<2, 12, 1, 64, 0>", "k1g_kernel<2, 8, 1, 64, 0>",
        "k2_topk_wave<13>", "k2_topk_wave<2>", "k2_topk_reg", "tfidf_weight_kernel", "sort_scatter_kernel", "k0b_remaining"]
 

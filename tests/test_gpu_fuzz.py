@@ -105,6 +105,10 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
         clib.set_option(m.model.model_chain, "presence", int(rng.choice([0, 1, 2, 2])))           # K1Q presence words: never / unstaged layers / always
         clib.set_option(m.model.model_chain, "sort_min_tiles", int(rng.choice([0, 1, 1])))       # tile-format layers: items in natural order / tile-sorted
+        # K1Q's sorted launch (queries counting-sorted by the best parent of their beam, XCD-contiguous): forced on these small batches / off
+        qs = int(rng.choice([0, 1, 1]))
+        clib.set_option(m.model.model_chain, "qsort", qs)
+        clib.set_option(m.model.model_chain, "qsort_min_rows", 1); clib.set_option(m.model.model_chain, "qsort_min_parents", 2)
         os.environ["XRL_K1Q_FUSE01"] = str(int(rng.choice([0, 1, 1])))                          # levels 0 + 1 in one feature walk (K1Q) / separately
         clib.set_option(m.model.model_chain, "prune", int(rng.choice([0, 1, 1])))                  # exact bound pruning on / off: same bits
         # one or two row batches in flight (two streams), whole or ragged batches
