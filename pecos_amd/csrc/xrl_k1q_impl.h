@@ -75,21 +75,22 @@ struct K1QArgs {
                                       // the first wavefront of a launch copies what earlier launches counted to the host-visible words
 };
 
-// Weight rows as raw buffer loads (round 5).  A layer's matrix is ONE buffer resource whose num_records is a single row's bytes; the
-// feature's row is selected by the instruction's SCALAR offset f * row_bytes, which the hardware adds to the address but leaves out of
-// the range check (llvm.amdgcn.raw.buffer.load: "soffset ... excluded from bounds checking"): a lane offset past the row still reads 0,
-// never memory.  BIGW = false (every matrix of the launch < 4 GiB): the descriptor is loop-invariant and a row costs ONE scalar
-// instruction (s_mul_i32).  BIGW = true: the product's high half goes into the descriptor's base (s_mul_hi, s_add, s_and + s_mul_i32).
-// Round 4 rebuilt a 64-bit row base per feature (6 scalar instructions with the clamp): the kernel issued 6 scalar instructions per
-// weight load against 2 vector ones, and a CU has ONE scalar unit (profiles/r05_k1q_scalar.md).
+// Weight rows as raw buffer loads.
+// BIGW = false (every matrix of the launch < 4 GiB; round 5): the layer's whole matrix is ONE loop-invariant buffer resource and the
+// feature's row is selected by the instruction's SCALAR offset f * row_bytes -- one scalar instruction (s_mul_i32) per row.  gfx9-class
+// hardware range-checks a raw buffer access as  voffset >= num_records - soffset,  so num_records is the MATRIX's bytes: a lane offset of
+// 0xFFFFFFF0 (how the presence path switches a lane off) still reads 0 without a memory request, any other lane offset used here stays
+// inside its row.
+// BIGW = true: the row's 64-bit base is rebuilt per feature (s_mul_hi, s_mul, s_add, s_addc, s_and), num_records = one row.
+// Round 4 used the second form everywhere, with a clamp: 6 scalar instructions per weight load against 2 vector ones -- and a CU has ONE
+// scalar unit (profiles/r05_k1q_scalar.md).
 template <bool BIGW>
-__device__ __forceinline__ uint32_t k1q_load_w(const uint32_t* wd, uint32_t row_bytes, uint32_t f, uint32_t voff) {
+__device__ __forceinline__ uint32_t k1q_load_w(const uint32_t* wd, uint32_t row_bytes, uint32_t rows, uint32_t f, uint32_t voff) {
     if (BIGW) {
-        const uint64_t base = (uint64_t)reinterpret_cast<uintptr_t>(wd) + ((uint64_t)__umulhi(f, row_bytes) << 32);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(base), 0, (int)row_bytes, 0x00020000);
-        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)(f * row_bytes), 0);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(wd) + (uint64_t)f * row_bytes), 0, (int)row_bytes, 0x00020000);
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0);
     }
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wd), 0, (int)row_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(wd), 0, (int)(rows * row_bytes), 0x00020000);
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)(f * row_bytes), 0);
 }
 
@@ -176,8 +177,9 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                 // PRESENCE: first the word that says whether this lane's dense tile holds any weight at the feature (one small row per
                 // feature, mostly L2-resident), then the weight load with the lane's offset -- or an offset outside the resource for an
                 // empty tile: such lanes read 0.0 without a memory request.  A 64-byte segment none of whose lanes asks is never fetched.
-                // (the whole presence array is ONE resource -- it is < 2 GiB, xrl_model.cpp -- and the feature's row is the instruction's SCALAR
-                //  offset: one SGPR per feature in flight instead of a 4-SGPR descriptor)
+                // (the whole presence array is ONE resource -- it is < 2 GiB, xrl_model.cpp -- and the feature's row is the instruction's SCALAR offset.
+                //  Round 5 also tried staging a chunk's presence rows in LDS with buffer_load ... lds, to replace this dependent trip to the L2 by
+                //  an LDS read: slower, 5.9 + 3.8 ms against 4.45 + 3.0 ms on the hard workload -- profiles/r05_k1q_experiments.md)
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
                     const uint32_t prow = fs[u] * pres_bytes;
@@ -189,7 +191,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         const bool present = ((wb[u][r] >> ((woff[RB + r] >> dt_shift) & 31u)) & 1u) != 0u;
-                        wb[u][r] = k1q_load_w<BIGW>(wd, ld, fs[u], present ? woff[RB + r] : 0xFFFFFFF0u);
+                        wb[u][r] = k1q_load_w<BIGW>(wd, ld, w_rows + 1u, fs[u], present ? woff[RB + r] : 0xFFFFFFF0u);
                     }
                 }
             } else {
@@ -197,7 +199,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                 for (int u = 0; u < UU; ++u) {
                     // (fs[u] <= w_rows here: padding slots and features outside the layer name the all-missing row the model compiler appends)
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) wb[u][r] = k1q_load_w<BIGW>(wd, ld, fs[u], woff[RB + r]);
+                    for (int r = 0; r < NR; ++r) wb[u][r] = k1q_load_w<BIGW>(wd, ld, w_rows + 1u, fs[u], woff[RB + r]);
                 }
             }
 #pragma unroll
@@ -224,8 +226,9 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
             room = X.nnz - xb;
         }
         xn = n;
-        for (uint32_t t0 = 0; t0 < n; t0 += 64u) {
-            const uint32_t nc = min(64u, n - t0);
+        constexpr uint32_t CH = 64u;
+        for (uint32_t t0 = 0; t0 < n; t0 += CH) {
+            const uint32_t nc = min(CH, n - t0);
             // the chunk's values once per lane: the pruning guard's maximum, and "is every value finite"
             const uint32_t vb = (uint32_t)lane < nc ? (__float_as_uint(vsrc[t0 + (uint32_t)lane]) & 0x7FFFFFFFu) : 0u;
             xmx = max(xmx, vb);
@@ -364,8 +367,8 @@ __device__ __forceinline__ uint32_t k1q_layer01(const K1QLayer& L0, const K1QLay
         uint32_t w0[UU], w1[UU];
 #pragma unroll
         for (int u = 0; u < UU; ++u) {
-            w0[u] = k1q_load_w<BIGW>(wd0, ld0, fs[u], woff0);
-            w1[u] = k1q_load_w<BIGW>(wd1, ld1, fs[u], woff1);
+            w0[u] = k1q_load_w<BIGW>(wd0, ld0, wr + 1u, fs[u], woff0);
+            w1[u] = k1q_load_w<BIGW>(wd1, ld1, wr + 1u, fs[u], woff1);
         }
 #pragma unroll
         for (int u = 0; u < UU; ++u) {

@@ -199,7 +199,7 @@ struct Model {
     int sort_rest = 1;                      // bound-pruned tile-format layers: the second phase's compacted items are tile-sorted before K1 runs on them (0: query order)
     int qsort = 1;                          // K1Q, sparse X: the last layer of a run of dense-format layers runs on queries SORTED by the best parent of their beam,
                                             // every XCD on a contiguous range of them (xrl_predict.cpp), when it has >= qsort_min_parents parents and the batch >= qsort_min_rows rows
-    int qsort_min_parents = 64, qsort_min_rows = 16384;
+    int qsort_min_parents = 64, qsort_min_rows = 131072;
     int sort_min_tiles = 0;                 // tile-sort a layer's items once it has this many tiles (0 = never; measured: cuts HBM fetch 15x at the leaf but K1 is issue-bound, not HBM-bound, so it does not pay yet)
     // multi-GPU behind the drop-in entry points (xrl_set_option "devices"): further copies of the compiled model on other devices; the
     // host-ABI predict shards the rows over this handle's device and the replicas' (xrl_abi.cpp predict_host)

@@ -2,7 +2,6 @@
     python scripts/ab.py <config> <scale> <steps> "<opt=val,opt=val>" "<...>" ...        ("" = the defaults)
 Per option set: options reset to the defaults, then the set applied; 6 untimed predicts (the pruning feedback settles), `steps` profiled
 predicts; prints ms per step, per-kernel ms per step, and whether the outputs (indices, score bits, counts) equal the FIRST set's."""
-import ctypes
 import json
 import os
 import sys
@@ -18,7 +17,7 @@ from pecos_amd import XLinearModel, clib  # noqa: E402
 name, scale, steps = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
 sets = sys.argv[4:] or [""]
 rows_limit = int(os.environ.get("AB_ROWS", "0"))
-DEFAULTS = dict(qsort=1, qsort_min_parents=64, qsort_min_rows=16384, prune=1, adaptive=1, presence=1, sort_rest=1, prune_mid=1, k1q_fuse=3, dense_layers=1, k1_group=0, sort_min_tiles=0)
+DEFAULTS = dict(qsort=1, qsort_min_parents=64, qsort_min_rows=131072, prune=1, adaptive=1, presence=1, sort_rest=1, prune_mid=1, k1q_fuse=3, dense_layers=1, k1_group=0, sort_min_tiles=0)
 folder = f"/tmp/xrl_bench/{name}_{scale}"
 if not os.path.exists(folder + "/.done"):
     t0 = time.time()
@@ -32,18 +31,16 @@ cfg = xrl_synth.CONFIGS[name]
 m = XLinearModel.load(folder); h = m.model.model_chain
 q = clib.queries_upload(h, X)
 k, N = 10, X.shape[0]
-hip = ctypes.CDLL("libamdhip64.so")
+import torch  # noqa: E402  (device buffers only)
+t_idx = torch.zeros(N * k, dtype=torch.int32, device="cuda"); t_val = torch.zeros(N * k, dtype=torch.int32, device="cuda"); t_cnt = torch.zeros(N, dtype=torch.int32, device="cuda")
+di, dv, dc = t_idx.data_ptr(), t_val.data_ptr(), t_cnt.data_ptr()
 
 
-def dmalloc(n):
-    p = ctypes.c_void_p(); assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n)) == 0; return p.value
+def fetch(t):
+    torch.cuda.synchronize()
+    return t.cpu().numpy().view(np.uint32)
 
 
-def fetch(p, n, dt):
-    a = np.empty(n, dt); assert hip.hipMemcpy(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(p), ctypes.c_size_t(a.nbytes), 2) == 0; return a
-
-
-di, dv, dc = dmalloc(N * k * 4), dmalloc(N * k * 4), dmalloc(N * 4)
 ref = None
 for st in sets:
     for kk, vv in DEFAULTS.items():
@@ -61,7 +58,7 @@ for st in sets:
     dt = (time.perf_counter() - t0) / steps
     clib.profile_enable(h, False)
     prof = clib.profile_get(h)
-    out = (fetch(di, N * k, np.uint32), fetch(dv, N * k, np.uint32), fetch(dc, N, np.uint32))
+    out = (fetch(t_idx), fetch(t_val), fetch(t_cnt))
     if ref is None:
         ref = out
     mask = (np.arange(k)[None, :] < out[2][:, None]).ravel()

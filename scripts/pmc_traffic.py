@@ -38,10 +38,10 @@ def last_steps_start(rows):
     disp = sorted({(int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in rows if family(r["Kernel_Name"]) is not None or "xguard" in r["Kernel_Name"]})
     if not disp:
         return 0
-    opener = disp[0][1].split("<")[0]
+    opener = disp[0][1]
     starts, prev_open = [], False
     for t, name in disp:
-        is_open = name.split("<")[0] == opener
+        is_open = name == opener
         if is_open and not prev_open:
             starts.append(t)
         prev_open = is_open
