@@ -22,6 +22,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: only the entry points declared here are exported */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ------------------------------------------------------------------------------------------
  * Matrix views handed over by the caller (read-only, valid for the duration of the call).
@@ -361,6 +365,9 @@ uint32_t xrl_layer_info(void* model, uint32_t layer, uint64_t* out, uint32_t cap
 /* Bytes of HBM held by the compiled model. */
 uint64_t xrl_model_device_bytes(void* model);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,7 @@ void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, v
 void launch_sort_queries(BeamDev prev, uint32_t nrows, uint32_t n_keys, uint32_t* H, uint32_t* start, uint32_t* perm, hipStream_t s);
 uint32_t qsort_max_keys();
 size_t qsort_hist_bytes(uint32_t nrows, uint32_t n_keys);
+void launch_step_marker(hipStream_t s);   // XRL_STEP_MARKER=1: an empty kernel at the start of every predict (step boundaries in kernel traces)
 uint32_t sort_max_tiles();
 size_t sort_hist_bytes(uint64_t n_slots, uint32_t n_tiles);
 // K2  per-query top-k with (value desc, position asc) order; maps positions to original child ids.

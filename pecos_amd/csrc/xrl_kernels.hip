@@ -232,6 +232,14 @@ void launch_sort_items(const LayerDev& L, uint64_t n_slots, const void* items, v
     XRL_LAUNCH_CHECK();
 }
 
+// Profiling aid: with XRL_STEP_MARKER=1 every predict_device call opens with this empty kernel, so that a rocprofv3 kernel trace can be
+// cut into steps whatever kernels the layers run (scripts/pmc_traffic.py).  Never launched otherwise.
+__global__ void step_marker_kernel() {}
+void launch_step_marker(hipStream_t s) {
+    hipLaunchKernelGGL(step_marker_kernel, dim3(1), dim3(64), 0, s);
+    XRL_LAUNCH_CHECK();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Query ordering for a query-stationary layer (K1Q): counting sort of the QUERIES by the best parent of their beam
 // (beam slot 0 = the parent whose children a query most likely keeps), written as a permutation.  K1Q then runs query perm[i] in

@@ -6,6 +6,7 @@
 #include "xrl_predict.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace xrl {
 
@@ -40,6 +41,8 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     if (!stream) stream = m.stream;
     // the scratch buffers are shared by every predict of the handle: an asynchronous predict still running on another stream must finish first
     if (m.ws_done && m.ws_stream != stream) XRL_HIP(hipStreamWaitEvent(stream, m.ws_done, 0));
+    static const bool step_marker = [] { const char* e = std::getenv("XRL_STEP_MARKER"); return e && e[0] == '1'; }();
+    if (step_marker && !o.stats_out) launch_step_marker(stream);
 
     // MLModel::predict_internal's shape checks live in Python for the reference
     // (xmc/base.py:1603-1607); here a mismatch is a loud error instead of UB.

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <system_error>
 #include <thread>
 
 #include <sys/mman.h>
@@ -628,11 +629,20 @@ void TfidfVectorizer::count_corpus(const char* const* corpus, const size_t* doc_
             }
         } catch (const std::exception& e) { P.err = e.what(); stop.store(true); }
     };
+    // (chunks are handed out dynamically, so the work gets done by however many threads could be started: when the process is at its
+    //  thread limit -- std::system_error from the constructor -- the ones that exist, at least the caller's, share it; nothing unwinds
+    //  past a joinable thread)
     auto run_all = [&](auto&& fn) {
         std::vector<std::thread> th;
-        for (unsigned t = 1; t < nt; ++t) th.emplace_back(fn, t);
-        fn(0u);
+        th.reserve(nt);
+        try {
+            for (unsigned t = 1; t < nt; ++t) th.emplace_back(fn, t);
+        } catch (const std::system_error&) {
+        }
+        std::exception_ptr ep;
+        try { fn(0u); } catch (...) { ep = std::current_exception(); stop.store(true); }
         for (auto& x : th) x.join();
+        if (ep) std::rethrow_exception(ep);
     };
     run_all(work);
     const double t_counted = timing ? now_ms() : 0.0;

@@ -247,11 +247,7 @@ def predict_text(vectorizer, models, corpus, X_emb=None, normalize_emb=True, thr
                 clib.queries_free(q2)
     if len(outs) == 1:
         return outs[0]
-    acc = outs[0].tocsr().copy()
-    for o in outs[1:]:
-        acc = acc + o
-    acc.data /= len(outs)                         # CsrEnsembler.average (pecos/utils/smat_util.py): the mean of the prediction matrices
-    return acc.tocsr()
+    return ensemble_average(outs)                 # CsrEnsembler.average (smat_util.py:828-842): sum, sorted_csr, divide -- rows score-sorted like the reference's
 
 
 def sorted_csr(csr, only_topk=None):

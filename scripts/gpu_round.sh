@@ -26,7 +26,7 @@ except Exception as e: print('no json', e)
 " ;;
     pmc) # pmc:BENCHARG,BENCHARG,...   two counter passes (TCC + TCP + SQ blocks have separate slots) + one --kernel-trace --stats pass; writes
          # pmc_<n>_{fetch,write,l2,sq}.csv, kernel_stats_<n>.csv and the pmc_traffic entry pmc_entry_<n>.json (scripts/pmc_traffic.py)
-         n=$((n+1)); cd /tmp && export TMPDIR=/tmp
+         n=$((n+1)); cd /tmp && export TMPDIR=/tmp XRL_STEP_MARKER=1
          B="python $R/bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats --parity-rows 0 $args"
          timeout ${XRL_PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_a -- $B > $O/pmc_${n}_a.log 2>&1
          timeout ${XRL_PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $O/pmc_b -- $B > $O/pmc_${n}_b.log 2>&1
@@ -37,7 +37,7 @@ O, n, args = sys.argv[1], sys.argv[2], sys.argv[3].split()
 rows = []
 for d in ("pmc_a", "pmc_b"):
     for f in glob.glob(f"{O}/{d}/**/*counter_collection.csv", recursive=True):
-        rows += [r for r in csv.DictReader(open(f)) if "xrl::" in r["Kernel_Name"]]
+        rows += [r for r in csv.DictReader(open(f)) if "xrl::" in r["Kernel_Name"] or "step_marker" in r["Kernel_Name"]]
     os.system(f"rm -rf {O}/{d}")
 split = {"fetch": ("FETCH_SIZE",), "write": ("WRITE_SIZE",), "l2": ("TCC_HIT_sum", "TCC_MISS_sum", "TCP_TCC_READ_REQ_sum")}
 for name, ctrs in list(split.items()) + [("sq", None)]:

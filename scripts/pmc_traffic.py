@@ -38,10 +38,14 @@ def last_steps_start(rows):
     disp = sorted({(int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in rows if family(r["Kernel_Name"]) is not None or "xguard" in r["Kernel_Name"]})
     if not disp:
         return 0
-    opener = disp[0][1]
+    markers = sorted(int(r["Start_Timestamp"]) for r in rows if "step_marker_kernel" in r["Kernel_Name"])
+    if markers:            # round 5: the library marks every predict (XRL_STEP_MARKER=1, set by scripts/gpu_round.sh pmc)
+        markers = sorted(set(markers))
+        return markers[-int(N_STEPS)] if len(markers) >= int(N_STEPS) else markers[0]
+    opener = disp[0][1].split("<")[0]
     starts, prev_open = [], False
     for t, name in disp:
-        is_open = name == opener
+        is_open = name.split("<")[0] == opener
         if is_open and not prev_open:
             starts.append(t)
         prev_open = is_open

@@ -27,6 +27,16 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/xrl_abi.h but not exported"
+    # ... and nothing else: the library is built with -fvisibility=hidden, so that it can be dlopen'ed next to libpecos_float32.so without
+    # leaking its internal C++ symbols.  Defined dynamic symbols = the C ABI (c_* / xrl_*) + the HIP runtime's registration hooks.
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    exported = [ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in ("T", "W", "B", "D", "V")]
+    foreign = [e for e in exported if not (e.startswith("c_") or e.startswith("xrl_") or e.startswith("__hip_") or e in ("_init", "_fini"))]
+    assert not foreign, foreign[:10]
+    assert set(names) <= set(exported)
 
 
 def test_binding_links_and_reports_no_gpu_loudly():
