@@ -106,7 +106,10 @@ def _pipeline_worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     k = 3
-    for sizes in ([5, 2], [0, 4], [3, 3]):                      # uneven and empty shards
+    cases = ([5, 2], [0, 4], [3, 3]) if world == 2 else \
+            ([7, 0, 3, 5, 1, 0, 9, 2], [0, 0, 0, 4, 0, 0, 0, 0], [6] * 8, [61250] * 7 + [61251])   # N = 8: uneven, empty, even, and the driver's Amazon-670K shard sizes
+    cases = [c for c in cases if len(c) == world]
+    for sizes in cases:                                         # uneven and empty shards
         bounds = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         n_all, lo, hi = int(bounds[-1]), int(bounds[rank]), int(bounds[rank + 1])
         pipe = GatherPipeline(bounds, rank, k, torch.device("cpu"), n_buf=2)       # CPU: no streams, the gather runs inside end()
@@ -138,3 +141,14 @@ def test_gather_pipeline_world2_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_pipeline_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "pipe_ok0") and os.path.exists(tmp_path / "pipe_ok1")
+
+
+@pytest.mark.timeout(600)
+def test_gather_pipeline_world8_gloo(tmp_path):
+    # the exact collective sequence of `bench.py --gpus 8` (SCALE's last point): 8 ranks, nnz-balanced shard bounds of unequal sizes (some
+    # empty), double-buffered PackedTopk, one all-gather per step issued in step order on every rank -- executed once here under gloo, since
+    # no 8-GPU node is available to the builder (RCCL itself has only run with one rank: DESIGN.md section 6, "unmeasured")
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert all(os.path.exists(tmp_path / f"pipe_ok{r}") for r in range(8))
