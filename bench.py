@@ -115,6 +115,9 @@ def main():
                          "D2H, host CSR out); value = all queries / max-over-ranks time (what a caller that shards by process gets, PCIe included)")
     ap.add_argument("--parity-rows", type=int, default=4096, help="rows per shard of the TIMED output compared with the reference after the timed loop (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra lines of the default run (extra.hard: the same shape on the model that does not flatter "
+                                                             "bound pruning; extra.text_to_labels: texts -> labels with X never on the host)")
+    ap.add_argument("--text-docs", type=int, default=100000, help="documents of the text -> labels line")
     ap.add_argument("--k1-group", type=int, default=0)
     ap.add_argument("--opt", action="append", default=[], help="library option key=int (xrl_set_option), repeatable")
     args = ap.parse_args()
@@ -373,9 +376,22 @@ def main():
             out["cpu_baseline"], out["parity"] = cpu_baseline(folder, Xs, model, beam, args.topk, args.cpu_seconds, log)
         if timed_parity is not None:
             out["parity"] = dict(out.get("parity") or {}, **timed_parity)
+        # ---- extra lines of the DEFAULT run: the honest model and the text -> labels pipeline, under the driver's eyes
+        if world == 1 and not args.no_extra and not args.include_upload and args.config == "amazon-670k" and args.scale == 1.0 and not args.rows and not args.opt:
+            out["extra"] = {}
+            try:
+                out["extra"]["text_to_labels"] = text_to_labels(clib, model, folder, Xs, beam, args.topk, args.text_docs, log)
+            except Exception as e:   # never let an extra line break the bench
+                log(f"extra.text_to_labels skipped: {e!r}")
+            clib.queries_free(q); q = None
+            try:
+                out["extra"]["hard"] = hard_line(args, log)
+            except Exception as e:
+                log(f"extra.hard skipped: {e!r}")
         print(json.dumps(out), flush=True)
 
-    clib.queries_free(q)
+    if q is not None:
+        clib.queries_free(q)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -567,6 +583,101 @@ def timed_output_parity(folder, Xpar, G, beam, topk, world, rows_per_shard, log)
     log(f"timed output vs {kind}: {n} rows ({rows_per_shard} per shard x {world}): indices identical={same_idx} scores bit-identical={bit}")
     return dict(timed_output_identical=bool(same_idx and bit), timed_output_sample=f"first {rows_per_shard} rows of each of the {world} shard(s) = {n} rows, "
                 f"read back from the buffers the timed steps wrote, vs {kind}", timed_output_indices_identical=same_idx, timed_output_scores_bit_identical=bit)
+
+
+def hard_line(args, log):
+    """extra.hard: this same benchmark on `amazon-670k-hard` (same shape; query-dependent routing, unsaturated hinge: bound pruning settles
+    ~nothing -- profiles/r04_hard_config.md), run as a child process with the same steps / warm-up, its timed output compared with the
+    reference on --parity-rows rows.  The headline `value` stays on the BASELINE configuration."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", "amazon-670k-hard", "--steps", str(args.steps), "--warmup", str(max(args.warmup, 6)),
+           "--no-cpu-baseline", "--no-host-abi", "--no-extra", "--cache", args.cache, "--parity-rows", str(args.parity_rows)]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
+    line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+    if r.returncode != 0 or line is None:
+        raise RuntimeError(f"child bench failed rc={r.returncode}: {r.stderr[-400:]}")
+    j = json.loads(line)
+    rf = j.get("roofline") or {}
+    log(f"extra.hard: {j['ms_per_step']} ms per step = {j['value'] / 1e6:.1f} M q/s ({time.time() - t0:.0f} s incl. generating the workload)")
+    return dict(config="amazon-670k-hard", value=j["value"], unit=j["unit"], ms_per_step=j["ms_per_step"], steps=j["steps"], warmup=j["warmup"],
+                roofline=dict(kernel=rf.get("kernel"), frac=rf.get("frac"), achieved=rf.get("achieved"), basis=rf.get("basis"), traffic=rf.get("traffic"),
+                              requests=rf.get("requests"), issue=rf.get("issue"), per_kernel_ms_per_step=rf.get("per_kernel_ms_per_step")),
+                parity=j.get("parity"), workload=j["config"]["workload"])
+
+
+def text_to_labels(clib, model, folder, X, beam, topk, n_docs, log):
+    """extra.text_to_labels: documents/s of texts -> labels with X never on the host -- pecos_amd.features.predict_text:
+    tokenise + n-gram lookup on host threads, term counts uploaded once, tf-idf weighting + l2 norm on the device (K5), beam search in
+    place -- beside the reference's own pipeline on the same corpus and host cores: its compiled c_tfidf_predict (host CSR out) followed by
+    its XLinearModel predict on that CSR (oracle/_ref).  The corpus is SYNTHETIC: document i holds the word of every feature of query row i
+    (a unigram vectorizer over the model's feature dimension, written here in the reference's file format), so the beam search sees this
+    workload's sparsity pattern; both pipelines' labels are compared on the reference's sample."""
+    import ctypes as C
+    import tempfile
+    import numpy as np
+    from pecos_amd import features
+    sys.path.insert(0, os.path.join(REPO, "scripts"))
+    import n4_producer_bench as N4
+    n_docs = int(min(n_docs, X.shape[0]))
+    D = X.shape[1]
+    rng = np.random.default_rng(5)
+    words = np.array([f"t{i:x}" for i in range(D)])
+    Xd = X[:n_docs]
+    tok = words[Xd.indices]
+    corpus = [" ".join(tok[Xd.indptr[i]:Xd.indptr[i + 1]]) for i in range(n_docs)]
+    tmp = tempfile.mkdtemp(prefix="t2l_")
+    vdir = os.path.join(tmp, "vectorizer")
+    os.makedirs(vdir)
+    N4.write_vectorizer(vdir, list(words), [(i,) for i in range(D)], rng)
+    vec = features.Tfidf.load(vdir)
+    kw = dict(beam_size=beam, only_topk=topk)
+    features.predict_text(vec, model, corpus[:4096], **kw)            # warm-up (tables, pinned buffers)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); Y = features.predict_text(vec, model, corpus, **kw); ts.append(time.perf_counter() - t0)
+    t_gpu = float(np.median(ts))
+    res = dict(docs=n_docs, tokens_per_doc=round(float(Xd.nnz) / n_docs, 1), vectorizer=f"synthetic unigram tf-idf, {D} words, l2 norm",
+               value=round(n_docs / t_gpu, 1), unit="documents/s", ms=round(t_gpu * 1e3, 2),
+               includes="Python call, tokeniser + n-gram lookup on host threads, H2D of the term counts, tf-idf weighting + norm on the device, beam search, D2H of the top-k, CSR assembly")
+    log(f"extra.text_to_labels: {n_docs} documents in {t_gpu * 1e3:.1f} ms = {n_docs / t_gpu / 1e6:.2f} M docs/s")
+    # the reference's two calls on a bounded sample
+    from oracle import xrl_oracle as O
+    ref_so = os.path.join(REPO, "oracle", "_ref", "libpecos_float32.so")
+    if O.ref_available() and os.path.exists(ref_so):
+        import scipy.sparse as smat
+        ref = C.CDLL(ref_so)
+        ref.c_tfidf_load.restype = C.c_void_p; ref.c_tfidf_load.argtypes = [C.c_char_p]
+        ref.c_tfidf_predict.restype = None; ref.c_tfidf_predict.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint64, C.c_int, N4.ALLOC]
+        ref.c_tfidf_destruct.argtypes = [C.c_void_p]
+        ns = min(n_docs, 20000)
+        arr, dl, n = clib._corpus_arrays(corpus[:ns])
+        dlp = dl.ctypes.data_as(C.POINTER(C.c_uint64))
+        rh = ref.c_tfidf_load(vdir.encode())
+        rm = O.RefModel(folder, "HASH_CHUNKED")
+        ncpu = os.cpu_count() or 1
+        best = None
+        for th in sorted({t for t in (16, 32, 64, ncpu) if t <= ncpu}):
+            w = N4.Warm(); f = N4.ALLOC(w)
+            t0 = time.perf_counter()
+            ref.c_tfidf_predict(C.c_void_p(rh), arr, dlp, n, th, f)
+            Xr = smat.csr_matrix((w.a[2], w.a[0].astype(np.int32), w.a[1].astype(np.int64)), shape=(n, D))
+            P = rm.predict(Xr, beam_size=beam, only_topk=topk, threads=th)
+            t1 = time.perf_counter() - t0
+            if best is None or t1 < best[0]:
+                best = (t1, th, P)
+        ref.c_tfidf_destruct(C.c_void_p(rh))
+        t_ref, th, P = best
+        G = Y[:ns]
+        same = bool(np.array_equal(G.indptr, P.indptr) and np.array_equal(G.indices, P.indices))
+        rel = float(np.max(np.abs(G.data - P.data) / np.maximum(np.abs(P.data), 1e-30))) if same and P.nnz else None
+        res["reference"] = dict(value=round(ns / t_ref, 1), unit="documents/s", sample=ns, threads=th, cores=ncpu,
+                                what="the reference's compiled library on this host: c_tfidf_predict (host CSR) + c_xlinear_predict_csr_f32 (HASH_CHUNKED), best thread count of a sweep")
+        res["labels_identical_to_reference"] = same
+        res["max_rel_err_scores"] = rel
+        res["speedup"] = round((n_docs / t_gpu) / (ns / t_ref), 1)
+        log(f"extra.text_to_labels: reference pipeline {ns / t_ref:.0f} docs/s with {th} threads; labels identical: {same}, max rel err {rel}")
+    return res
 
 
 def cpu_baseline(folder, X, model, beam, topk, budget_s, log):
