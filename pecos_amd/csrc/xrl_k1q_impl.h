@@ -100,9 +100,15 @@ __device__ __forceinline__ uint32_t k1q_load_w(const uint32_t* wd, uint32_t row_
 #ifndef XRL_K1Q_U3
 #define XRL_K1Q_U3 8
 #endif
+#ifndef XRL_K1Q_U2
+#define XRL_K1Q_U2 XRL_K1Q_U3
+#endif
+#ifndef XRL_K1Q_RL
+#define XRL_K1Q_RL 0     // 1: a batch's (feature id, value) pairs come from the chunk's per-lane registers (v_readlane) instead of scalar loads
+#endif
 template <int NS> struct K1QCfg {
     // weight rows (features) whose loads are in flight together: U * NS loads per lane
-    static constexpr int U = NS <= 1 ? XRL_K1Q_U1 : NS <= 3 ? XRL_K1Q_U3 : NS <= 12 ? 4 : 2;
+    static constexpr int U = NS <= 1 ? XRL_K1Q_U1 : NS <= 2 ? XRL_K1Q_U2 : NS <= 3 ? XRL_K1Q_U3 : NS <= 12 ? 4 : 2;
 };
 
 // One layer for one query (one wavefront): beam in s_bidx / s_bval[0..cnt) -> beam out in the same arrays; returns the new count.
@@ -170,7 +176,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     auto pass = [&](auto rb_tag, auto re_tag) {
         constexpr int RB = decltype(rb_tag)::value, RE = decltype(re_tag)::value, NR = RE - RB;
         constexpr int UU = K1QCfg<NR>::U;
-        auto body = [&](auto exact_tag, const uint32_t (&fs)[UU], const float (&xs)[UU]) {
+        auto body_f = [&](auto exact_tag, auto&& getf, auto&& getx) {   // getf(u) / getx(u): feature id and value of the batch's u-th feature
             constexpr bool EX = decltype(exact_tag)::value;
             uint32_t wb[UU][NR];
             if (PRES && !EX && pres != nullptr) {
@@ -182,35 +188,41 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                 //  an LDS read: slower, 5.9 + 3.8 ms against 4.45 + 3.0 ms on the hard workload -- profiles/r05_k1q_experiments.md)
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
-                    const uint32_t prow = fs[u] * pres_bytes;
+                    const uint32_t prow = getf(u) * pres_bytes;
 #pragma unroll
                     for (int r = 0; r < NR; ++r) wb[u][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pres_rs, (int)((woff[RB + r] >> pw_shift) & ~3u), (int)prow, 0);
                 }
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
+                    const uint32_t fu = getf(u);
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         const bool present = ((wb[u][r] >> ((woff[RB + r] >> dt_shift) & 31u)) & 1u) != 0u;
-                        wb[u][r] = k1q_load_w<BIGW>(wd, ld, w_rows + 1u, fs[u], present ? woff[RB + r] : 0xFFFFFFF0u);
+                        wb[u][r] = k1q_load_w<BIGW>(wd, ld, w_rows + 1u, fu, present ? woff[RB + r] : 0xFFFFFFF0u);
                     }
                 }
             } else {
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
-                    // (fs[u] <= w_rows here: padding slots and features outside the layer name the all-missing row the model compiler appends)
+                    // (the feature id is <= w_rows here: padding slots and features outside the layer name the all-missing row the model compiler appends)
+                    const uint32_t fu = getf(u);
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) wb[u][r] = k1q_load_w<BIGW>(wd, ld, w_rows + 1u, fs[u], woff[RB + r]);
+                    for (int r = 0; r < NR; ++r) wb[u][r] = k1q_load_w<BIGW>(wd, ld, w_rows + 1u, fu, woff[RB + r]);
                 }
             }
 #pragma unroll
             for (int u = 0; u < UU; ++u) {
+                const float xu = getx(u);
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
                     // scalar * val, then add: no fma (inference.hpp:512-517); no entry -> no operation
-                    const float sm = __fadd_rn(acc[RB + r], __fmul_rn(xs[u], __uint_as_float(wb[u][r])));
+                    const float sm = __fadd_rn(acc[RB + r], __fmul_rn(xu, __uint_as_float(wb[u][r])));
                     acc[RB + r] = (EX && wb[u][r] == kMissing) ? acc[RB + r] : sm;
                 }
             }
+        };
+        auto body = [&](auto exact_tag, const uint32_t (&fs)[UU], const float (&xs)[UU]) {
+            body_f(exact_tag, [&](int u) { return fs[u]; }, [&](int u) { return xs[u]; });
         };
         // the query's (feature, value) pairs: its CSR row (chunk_ops<csr, bin_search>, inference.hpp:769-813: ascending features), or every
         // chunk row except the bias row with x gathered by row id (chunk_ops<drm, bin_search>, :815-839)
@@ -230,7 +242,8 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         for (uint32_t t0 = 0; t0 < n; t0 += CH) {
             const uint32_t nc = min(CH, n - t0);
             // the chunk's values once per lane: the pruning guard's maximum, and "is every value finite"
-            const uint32_t vb = (uint32_t)lane < nc ? (__float_as_uint(vsrc[t0 + (uint32_t)lane]) & 0x7FFFFFFFu) : 0u;
+            const uint32_t xraw = (uint32_t)lane < nc ? __float_as_uint(vsrc[t0 + (uint32_t)lane]) : 0u;
+            const uint32_t vb = xraw & 0x7FFFFFFFu;
             xmx = max(xmx, vb);
             // the fast loops take a feature id as it is (no clamp per feature): a chunk that holds an id beyond the layer's rows takes the exact
             // loop below, which sends such features to the all-missing row like the reference's row lookup finds nothing for them
@@ -239,9 +252,17 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
             for (uint32_t t = t0; t < t0 + nc; t += (uint32_t)UU) {
                 uint32_t fs[UU]; float xs[UU];
                 if (!nonfinite && t + (uint32_t)UU <= t0 + nc) {             // a full batch: plain uniform loads
+                    if (XRL_K1Q_RL && !DENSEX) {
+                        // the batch's (feature id, value) pairs straight from the chunk's per-lane registers, each at its point of use: no
+                        // scalar-load round trip per batch and no SGPR arrays alive across the loads
+                        const int tl = (int)(t - t0);
+                        body_f(std::false_type{}, [&](int u) { return (uint32_t)__builtin_amdgcn_readlane((int)ib, tl + u); },
+                               [&](int u) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)xraw, tl + u)); });
+                    } else {
 #pragma unroll
-                    for (int u = 0; u < UU; ++u) { fs[u] = DENSEX ? t + (uint32_t)u : fsrc[t + (uint32_t)u]; xs[u] = vsrc[t + (uint32_t)u]; }
-                    body(std::false_type{}, fs, xs);
+                        for (int u = 0; u < UU; ++u) { fs[u] = DENSEX ? t + (uint32_t)u : fsrc[t + (uint32_t)u]; xs[u] = vsrc[t + (uint32_t)u]; }
+                        body(std::false_type{}, fs, xs);
+                    }
                 } else if (!nonfinite && (uint64_t)t + (uint32_t)UU <= room) {  // the row's tail: the loads run on into the next row, the slots past the end are neutralised
 #pragma unroll
                     for (int u = 0; u < UU; ++u) {
@@ -327,7 +348,10 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
 template <int PPC, bool BIASF, bool BIGW>
 __device__ __forceinline__ uint32_t k1q_layer01(const K1QLayer& L0, const K1QLayer& L1, const QueriesDev& X, uint64_t xrow,
                                                  uint32_t* s_bidx, float* s_bval, uint2* sc, int lane) {
-    constexpr int UU = 8;
+#ifndef XRL_K1Q_U01
+#define XRL_K1Q_U01 8
+#endif
+    constexpr int UU = XRL_K1Q_U01;
     // ---- level 0: lane c < K0 <-> child c of the root (one dense tile at offset 0)
     const uint32_t K0 = L0.d_tcol[1] - L0.d_tcol[0];
     const bool v0 = (uint32_t)lane < K0;

@@ -24,8 +24,9 @@ def waves(vgpr):
 
 
 def main():
+    so = os.environ.get("PECOS_XRL_AMD_SO")     # another build of the library (kernel-tuning variants)
     frags = sys.argv[1:] or HOT
-    notes = T.kernel_notes(pathlib.Path(tempfile.mkdtemp()))
+    notes = T.kernel_notes(pathlib.Path(tempfile.mkdtemp()), so)
     nice = T.demangle(sorted(notes))
     print("| kernel | VGPRs | wavefronts / SIMD | SGPRs | SGPR spills (to VGPR lanes) | VGPR spills | scratch B | static LDS B |")
     print("|---|---:|---:|---:|---:|---:|---:|---:|")

@@ -13,15 +13,15 @@ from conftest import REPO
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def kernel_notes(tmp_path):
-    so = os.path.join(REPO, "pecos_amd", "lib", "libxrl_amd.so")
+def kernel_notes(tmp_path, so=None):
+    so = so or os.path.join(REPO, "pecos_amd", "lib", "libxrl_amd.so")
     objdump, readelf = os.path.join(LLVM, "llvm-objdump"), os.path.join(LLVM, "llvm-readelf")
     if not (os.path.exists(so) and os.path.exists(objdump) and os.path.exists(readelf)):
         pytest.skip("library or llvm tools not present")
     work = str(tmp_path / "co")
     os.makedirs(work)
     shutil.copy(so, work)                                   # --offloading writes the bundles next to its input
-    subprocess.check_call([objdump, "--offloading", os.path.join(work, "libxrl_amd.so")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    subprocess.check_call([objdump, "--offloading", os.path.join(work, os.path.basename(so))], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     out = {}
     for f in sorted(os.listdir(work)):
         if "amdgcn" not in f:
