@@ -59,7 +59,7 @@ def log(*a):
 
 # the sources a kernel launch of the bench path is built from: a counter set is valid for exactly these (host-only files -- the C ABI glue, the
 # folder readers, the TF-IDF producer's host half -- cannot change a counter, so editing them does not mark the sets stale)
-_KERNEL_PATH = ("xrl_device.h", "xrl_kernels.h", "xrl_items.h", "xrl_common.h", "xrl_predict.cpp", "xrl_predict.h", "xrl_model.cpp", "xrl_model.h", "Makefile")
+_KERNEL_PATH = ("xrl_device.h", "xrl_kernels.h", "xrl_k1q_impl.h", "xrl_items.h", "xrl_common.h", "xrl_predict.cpp", "xrl_predict.h", "xrl_model.cpp", "xrl_model.h", "Makefile")
 
 
 def csrc_sha16():
@@ -654,7 +654,7 @@ def text_to_labels(clib, model, folder, X, beam, topk, n_docs, log):
         arr, dl, n = clib._corpus_arrays(corpus[:ns])
         dlp = dl.ctypes.data_as(C.POINTER(C.c_uint64))
         rh = ref.c_tfidf_load(vdir.encode())
-        rm = O.RefModel(folder, "HASH_CHUNKED")
+        rm = O.RefModel(folder, "BINARY_SEARCH_CHUNKED")     # (the layout whose arithmetic order the GPU path reproduces bit for bit)
         ncpu = os.cpu_count() or 1
         best = None
         for th in sorted({t for t in (16, 32, 64, ncpu) if t <= ncpu}):
@@ -672,8 +672,9 @@ def text_to_labels(clib, model, folder, X, beam, topk, n_docs, log):
         same = bool(np.array_equal(G.indptr, P.indptr) and np.array_equal(G.indices, P.indices))
         rel = float(np.max(np.abs(G.data - P.data) / np.maximum(np.abs(P.data), 1e-30))) if same and P.nnz else None
         res["reference"] = dict(value=round(ns / t_ref, 1), unit="documents/s", sample=ns, threads=th, cores=ncpu,
-                                what="the reference's compiled library on this host: c_tfidf_predict (host CSR) + c_xlinear_predict_csr_f32 (HASH_CHUNKED), best thread count of a sweep")
+                                what="the reference's compiled library on this host: c_tfidf_predict (host CSR) + c_xlinear_predict_csr_f32 (BINARY_SEARCH_CHUNKED), best thread count of a sweep")
         res["labels_identical_to_reference"] = same
+        res["scores_bit_identical_to_reference"] = bool(same and np.array_equal(G.data.view(np.uint32), P.data.view(np.uint32)))
         res["max_rel_err_scores"] = rel
         res["speedup"] = round((n_docs / t_gpu) / (ns / t_ref), 1)
         log(f"extra.text_to_labels: reference pipeline {ns / t_ref:.0f} docs/s with {th} threads; labels identical: {same}, max rel err {rel}")
