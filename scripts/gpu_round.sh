@@ -27,10 +27,10 @@ except Exception as e: print('no json', e)
     pmc) # pmc:BENCHARG,BENCHARG,...   two counter passes (TCC + TCP + SQ blocks have separate slots) + one --kernel-trace --stats pass; writes
          # pmc_<n>_{fetch,write,l2,sq}.csv, kernel_stats_<n>.csv and the pmc_traffic entry pmc_entry_<n>.json (scripts/pmc_traffic.py)
          n=$((n+1)); cd /tmp && export TMPDIR=/tmp XRL_STEP_MARKER=1
-         B="python $R/bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats --parity-rows 0 $args"
+         B="python $R/bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats --no-extra --parity-rows 0 $args"
          timeout ${XRL_PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d $O/pmc_a -- $B > $O/pmc_${n}_a.log 2>&1
          timeout ${XRL_PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum --output-format csv -d $O/pmc_b -- $B > $O/pmc_${n}_b.log 2>&1
-         timeout ${XRL_PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python $R/bench.py --steps 10 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats --parity-rows 0 $args > $O/ktrace_$n.log 2>&1
+         timeout ${XRL_PMC_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktrace -- python $R/bench.py --steps 10 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats --no-extra --parity-rows 0 $args > $O/ktrace_$n.log 2>&1
          python - $O $n "$args" <<'PY'
 import csv, glob, os, sys, collections
 O, n, args = sys.argv[1], sys.argv[2], sys.argv[3].split()
