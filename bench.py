@@ -547,7 +547,13 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
                         "exact bound pruning is on: the matched-work figures count the items the kernels EVALUATE (the untimed stats pass stages every layer "
                         "like its timed kernel does); frac_ref_layout prices the UNPRUNED reference (every active chunk of every beam parent streamed) "
                         "against this step's time and is far above 1 -- `frac` (counter bytes) is what moved",
-                alg_bytes_per_launch=per_launch, avg_launch_ms=round(avg_ms, 4), launches_per_step=launches_per_step,
+                alg_bytes_per_launch=per_launch,
+                # counter-based block: the launches priced are ALL launches of the kernel the counters belong to (K1Q: the fused narrow levels +
+                # the sorted launch of the last dense-format level; both stages of a pruned layer) -- `achieved` = `traffic` / `avg_launch_ms`
+                avg_launch_ms=round(pmc_avg_ms if traffic is not None else avg_ms, 4),
+                launches_per_step=pf_launches_step if traffic is not None else launches_per_step,
+                launches_priced=sorted(n_ for n_ in fam if pmc_family(n_) == pfam) if traffic is not None else [dom],
+                dominant_family_avg_launch_ms=round(avg_ms, 4),
                 model="frac: counter bytes; frac_matched: matched work, no inter-query reuse (compulsory bytes for cache-resident structures); "
                       "frac_ref_layout: SURVEY 8(d) chunk streaming (see bench.py docstring / DESIGN.md section 4)",
                 step_alg_bytes=step_bytes, step_gbps=round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1),

@@ -12,6 +12,7 @@
 #include <mutex>
 #include <atomic>
 #include <thread>
+#include <unordered_map>
 
 #include "xrl_predict.h"
 #include "xrl_tfidf.h"
@@ -253,6 +254,21 @@ void run_and_emit(Model& m, const QueriesDev& X, const PredictOpts& o, py_sparse
 // Runs the whole host-ABI pipeline of ONE device for the rows of `input_x` and leaves the fixed-stride results in the handle's
 // pinned host buffers (ws.h_idx / h_val / h_cnt, stride k); the caller holds m.mu and emits the CSR afterwards.
 constexpr int kStageSlots = 3;   // == the length of Workspace::stage
+
+// Round 5: the row batches of one call ALTERNATE between two compute streams (the handle's own and its auxiliary one), each with its own
+// set of per-batch scratch buffers (Workspace::lane[0] / lane[1], swapped into place around the predict_device call) and its own
+// "scratch in use until" event.  A row batch of 30-60 k queries ends in a tail of latency-bound wavefronts (the query-stationary kernel runs
+// ~8 rounds of 67 us at that size); on one stream the next batch's first kernel waits for that tail, on two it fills the CUs the tail
+// leaves idle.  Batches write disjoint rows of the result buffers; the uploads they wait for are ordered by the copy stream's events as
+// before.  XRL_HOST_STREAMS=1 restores the single compute stream.
+struct HostLanes { hipEvent_t done[2] = {nullptr, nullptr}; hipStream_t strm[2] = {nullptr, nullptr}; hipEvent_t join = nullptr; };
+static std::mutex g_host_lanes_mu;
+static std::unordered_map<const Model*, HostLanes> g_host_lanes;      // (entries die with the process: two events per handle)
+static int host_streams() {
+    static const int n = [] { const char* e = std::getenv("XRL_HOST_STREAMS"); return (e && e[0] == '1') ? 1 : 2; }();
+    return n;
+}
+
 template <class XT>
 void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     use_device(m.device);
@@ -346,6 +362,18 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
         if (reg_val) (void)hipHostUnregister(const_cast<float*>(is_csr ? Xs->val : Xd->val));
         reg_idx = reg_val = false;
     };
+    // two compute lanes for the row batches (see HostLanes above); the handle's lock is held by the caller
+    const bool two = host_streams() == 2 && n_batch >= 3 && !m.profiling;
+    HostLanes* hl = nullptr;
+    if (two) {
+        if (!m.aux_stream) XRL_HIP(hipStreamCreateWithFlags(&m.aux_stream, hipStreamNonBlocking));
+        { std::lock_guard<std::mutex> g(g_host_lanes_mu); hl = &g_host_lanes[&m]; }
+        if (!hl->join) XRL_HIP(hipEventCreateWithFlags(&hl->join, hipEventDisableTiming));
+        hl->done[0] = m.ws_done; hl->strm[0] = m.ws_stream;              // lane 0 = the handle's own bookkeeping; lane 1 keeps its event between calls
+        // the auxiliary lane starts after everything queued on the handle's stream so far (an earlier asynchronous predict may still use the scratch)
+        XRL_HIP(hipEventRecord(hl->join, m.stream));
+        XRL_HIP(hipStreamWaitEvent(m.aux_stream, hl->join, 0));
+    }
     g_ht.prep += now_ms() - t_ph;
     try {
         uint64_t chunk = 0;                                                 // staged chunks so far: slot = chunk & 1
@@ -383,22 +411,50 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
                 g_ht.stage += now_ms() - t_ph;
             }
             t_ph = now_ms();
-            if (last_slot >= 0) XRL_HIP(hipStreamWaitEvent(m.stream, up[last_slot], 0));   // batch b's kernels start when its rows have arrived (the copy stream is in order)
-            if (rb[b + 1] > rb[b])
-                predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, false,
-                               rb[b], rb[b + 1] - rb[b]);
+            const int L = two ? (int)(b & 1u) : 0;
+            hipStream_t S = L ? m.aux_stream : m.stream;
+            if (last_slot >= 0) XRL_HIP(hipStreamWaitEvent(S, up[last_slot], 0));   // batch b's kernels start when its rows have arrived (the copy stream is in order)
+            if (rb[b + 1] > rb[b]) {
+                if (two) {                                               // this lane's scratch and its "in use until" event into place
+                    if (L) std::swap(ws.lane[0], ws.lane[1]);
+                    m.ws_done = hl->done[L]; m.ws_stream = hl->strm[L];
+                }
+                try {
+                    predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, S, false,
+                                   rb[b], rb[b + 1] - rb[b]);
+                } catch (...) {
+                    if (two) { hl->done[L] = m.ws_done; hl->strm[L] = m.ws_stream; if (L) std::swap(ws.lane[0], ws.lane[1]); m.ws_done = hl->done[0]; m.ws_stream = hl->strm[0]; }
+                    throw;
+                }
+                if (two) { hl->done[L] = m.ws_done; hl->strm[L] = m.ws_stream; if (L) std::swap(ws.lane[0], ws.lane[1]); }
+            }
             // results: everything but the last batch goes back in ONE set of copies on the D2H stream, queued before the last batch's
             // kernels (per-batch copies are blit kernels that held up the next batch's launch: 12 x 0.15 ms); the last batch follows
-            // on the compute stream
-            if (b + 2 == n_batch) download_rows(m, 0, rb[b + 1], k, 0);
-            else if (b + 1 == n_batch) download_rows(m, n_batch > 1 ? rb[b] : 0, rb[b + 1], k, -1);
+            // on its compute stream
+            if (b + 2 == n_batch) {
+                if (two) {                                               // the copies wait for BOTH lanes' batches (download_rows adds the handle's stream)
+                    if (!m.d2h_stream) XRL_HIP(hipStreamCreateWithFlags(&m.d2h_stream, hipStreamNonBlocking));
+                    XRL_HIP(hipEventRecord(hl->join, m.aux_stream));
+                    XRL_HIP(hipStreamWaitEvent(m.d2h_stream, hl->join, 0));
+                }
+                download_rows(m, 0, rb[b + 1], k, 0);
+            } else if (b + 1 == n_batch) {
+                if (two && L) {                                          // the last batch ran on the auxiliary stream: its copies follow on the handle's stream
+                    XRL_HIP(hipEventRecord(hl->join, m.aux_stream));
+                    XRL_HIP(hipStreamWaitEvent(m.stream, hl->join, 0));
+                }
+                download_rows(m, n_batch > 1 ? rb[b] : 0, rb[b + 1], k, -1);
+            }
             g_ht.enqueue += now_ms() - t_ph;
         }
         t_ph = now_ms();
+        if (two) XRL_HIP(hipStreamSynchronize(m.aux_stream));
         sync_downloads(m);
+        if (two) { m.ws_done = hl->done[0]; m.ws_stream = hl->strm[0]; }
         g_ht.final_sync += now_ms() - t_ph;
     } catch (...) {
         (void)hipStreamSynchronize(m.copy_stream); (void)hipStreamSynchronize(m.stream);
+        if (two) { (void)hipStreamSynchronize(m.aux_stream); m.ws_done = hl->done[0]; m.ws_stream = hl->strm[0]; }
         if (m.d2h_stream) (void)hipStreamSynchronize(m.d2h_stream);
         for (auto& e : up) (void)hipEventDestroy(e);
         unregister();
@@ -843,6 +899,17 @@ void c_xlinear_destruct_model(void* ptr) {
         if (!ptr) return;
         Model* m = static_cast<Model*>(ptr);
         (void)hipSetDevice(m->device);
+        auto drop_lanes = [](const Model* mm) {      // the host pipeline's second compute lane (HostLanes): lane 1's event and the join event are its own
+            std::lock_guard<std::mutex> g(g_host_lanes_mu);
+            auto it = g_host_lanes.find(mm);
+            if (it == g_host_lanes.end()) return;
+            if (it->second.done[1]) (void)hipEventDestroy(it->second.done[1]);
+            if (it->second.join) (void)hipEventDestroy(it->second.join);
+            g_host_lanes.erase(it);
+        };
+        for (auto& r : m->replicas) { (void)hipSetDevice(r->device); drop_lanes(r.get()); }
+        (void)hipSetDevice(m->device);
+        drop_lanes(m);
         delete m;
     });
 }
