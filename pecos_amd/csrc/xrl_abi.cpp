@@ -296,6 +296,9 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
             const double cap = 3.0 * std::max(1, m.host_batch_mb);
             while (pos + cur * mb < (double)elems && share.size() < 31) { pos += cur * mb; share.push_back((uint64_t)pos); cur = std::min(cap, cur * 1.6); }
             // a short last batch joins the previous one (the tail after the upload ends is one launch either way)
+            // (round 5 tried a TAPERED end -- last two batches of host_batch_mb and half of it, to shorten the tail after the last byte of X has
+            //  arrived: 9.57 -> 9.06 ms on Amazon-670K but 18.5 -> 19.2 ms on the hard workload, and the extra batches shift the pruning feedback's
+            //  re-probe cadence; not kept: profiles/r05_host_abi.md)
             if (!share.empty() && (double)elems - (double)share.back() < 0.25 * cur * mb) share.pop_back();
         } else {
             const uint32_t nb = (uint32_t)std::min<uint64_t>(8, std::max<uint64_t>(1, rows / 65536u));

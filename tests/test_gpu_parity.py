@@ -745,11 +745,17 @@ def test_headline_config_full_size_all_rows_vs_reference(workload, XLM, clib, or
     for rep in range(4):
         clib.profile_enable(h, True); clib.profile_reset(h)
         got = m.predict(X, **kw)
-        names = {r["name"] for r in clib.profile_get(h)}
+        prof = clib.profile_get(h)
+        names = {r["name"] for r in prof}
         clib.profile_enable(h, False)
         assert_same_topk(got, want, exact_scores=True, what=f"{workload} full size, predict #{rep + 4} (pruning feedback)")
     if workload.endswith("-hard"):
-        assert "k1_sparse_rest" not in names and "k1_sort_items" in names, names      # the leaf runs unstaged by now
+        # the leaf runs unstaged by now -- in (nearly) every row batch of the call: the feedback stages a layer again once in 32 predict_device
+        # calls to look whether the data has changed, and a host-ABI call is ~10 of them, so a single re-probed batch may show up
+        launches = {}
+        for r in prof:
+            launches[r["name"]] = launches.get(r["name"], 0) + r["launches"]
+        assert "k1_sort_items" in names and launches.get("k1_sparse_rest", 0) <= 2 <= launches["k1_sort_items"], launches
     else:
         assert "k1_sparse_rest" in names, names                                           # ... and stays staged where pruning works
     clib.set_option(h, "adaptive", 0)
