@@ -1453,6 +1453,17 @@ struct TfidfHandle {
     TfidfVectorizer v;
     std::vector<float> idf_all;                  // the base vectorizers' idf side by side (hstack column order)
     mutable PinnedStage stage;
+    // c_tfidf_predict's stream, created once per (handle, device) instead of per call
+    mutable std::mutex stream_mu;
+    mutable hipStream_t stream = nullptr;
+    mutable int stream_device = -1;
+    hipStream_t stream_on(int device) const {
+        std::lock_guard<std::mutex> g(stream_mu);
+        if (stream && stream_device != device) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (!stream) { XRL_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); stream_device = device; }
+        return stream;
+    }
+    ~TfidfHandle() { if (stream) (void)hipStreamDestroy(stream); }
 };
 
 // texts -> term counts (host threads, into pinned staging) -> device -> weighting + normalisation (K5): a query handle that owns its three arrays
@@ -1533,13 +1544,9 @@ void c_tfidf_predict(void* ptr, void* corpus_ptr, const size_t* doc_lens, size_t
         if (!corpus_ptr || !doc_lens) fail("c_tfidf_predict: null corpus");
         require_gpu();
         const TfidfHandle& H = *static_cast<TfidfHandle*>(ptr);
-        hipStream_t s = nullptr;
         use_device(g_device);
-        XRL_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        std::unique_ptr<Queries> q;
-        try { q = tfidf_to_device(H, static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, g_device, s); }
-        catch (...) { (void)hipStreamDestroy(s); throw; }
-        (void)hipStreamDestroy(s);
+        hipStream_t s = H.stream_on(g_device);        // (tfidf_to_device holds the handle's staging lock from its first use of the stream to its synchronize)
+        std::unique_ptr<Queries> q = tfidf_to_device(H, static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, g_device, s);
         uint32_t* indices = nullptr; uint64_t* indptr = nullptr; float* data = nullptr;
         pred_alloc(false, q->dev.rows, q->dev.cols, q->nnz, &indices, &indptr, &data);
         if (!indptr || (q->nnz && (!indices || !data))) fail("allocator returned null");
