@@ -308,6 +308,10 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *   "sort_rest"           1 (default): the second phase of a bound-pruned tile-format layer runs on tile-sorted items (counting sort of the
  *                         compacted list by tile: the items of a tile run back to back on one XCD and share its lookup words and entries in
  *                         that XCD's L2); 0: in query order
+ *   "qsort"               1 (default): K1Q, sparse X -- the LAST layer of a run of dense-format layers is launched on its own, on queries counting-sorted
+ *                         by the best parent of their beam, every XCD taking a contiguous eighth of the sorted order (queries of one region of the
+ *                         tree share (feature, parent) segments in that XCD's L2), when the layer has >= "qsort_min_parents" (64) parents and the
+ *                         row batch >= "qsort_min_rows" (131072) rows; 0: never.  Results do not depend on it (round 5: L2 misses -27 %, time unchanged).
  *   "host_register"       host ABI: 1 = page-lock the caller's X arrays in place for the duration of the call (hipHostRegister) and let
  *                         the copy engine read them directly, instead of staging them through two pinned buffers with host threads
  *   "devices"             MULTI-GPU BEHIND THE DROP-IN ENTRY POINTS: the handle serves c_xlinear_predict_{csr,drm}_f32 from this many
