@@ -16,6 +16,7 @@ from pecos_amd.core import ScipyCompressedSparseAllocator, ScipyCsrF32
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="amazon-670k"); ap.add_argument("--calls", type=int, default=12)
 ap.add_argument("--cache", default="/tmp/xrl_bench"); ap.add_argument("--opt", action="append", default=[])
+ap.add_argument("--check", action="store_true", help="compare every call's CSR with the first call's, bit for bit (stress test of the pipelined path)")
 ap.add_argument("--reuse-alloc", action="store_true", help="hand the SAME output arrays to every call (takes the allocator's page faults out of the picture)")
 a = ap.parse_args()
 folder = os.path.join(a.cache, f"{a.config}_1.0")
@@ -55,4 +56,10 @@ for c in range(a.calls):
     clib.xlinear_predict(h, view, 10, None, 10, -1, alloc)
     times.append((time.perf_counter() - t0) * 1e3)
     print(f"[probe] call {c}: {times[-1]:.2f} ms", file=sys.stderr, flush=True)
+    if a.check:
+        cur = (np.array(alloc.indptr, copy=True), np.array(alloc.indices, copy=True), np.array(alloc.data, copy=True).view(np.uint32))
+        if c == 0:
+            first = cur
+        elif not all(np.array_equal(x, y) for x, y in zip(cur, first)):
+            print(json.dumps(dict(config=a.config, MISMATCH_at_call=c))); sys.exit(1)
 print(json.dumps(dict(config=a.config, calls=a.calls, ms=[round(t, 3) for t in times], median=round(float(np.median(times[1:])), 3), reuse_alloc=a.reuse_alloc, opts=a.opt)))

@@ -531,3 +531,30 @@ def test_c_tfidf_predict_vs_live_reference(oracle_mod, tmp_path):
     P = Tfidf.load(folder).predict(big)
     assert tuple(z["shape"]) == P.shape and np.array_equal(P.indptr, z["indptr"]) and np.array_equal(P.indices, z["indices"])
     assert np.array_equal(P.data.view(np.uint32), z["data"].view(np.uint32))
+
+
+def test_bench_text_to_labels_corpus_reproduces_the_query_pattern(tmp_path):
+    # bench.py's extra.text_to_labels builds a corpus whose document i names every feature of query row i once and a unigram vectorizer over
+    # the model's feature dimension (scripts/n4_producer_bench.write_vectorizer, the reference's file format): the host half's term counts
+    # must then have exactly X's sparsity pattern, every count 1 -- so the beam search of that line sees the benchmark's own queries
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(repo, "scripts")); sys.path.insert(0, repo)
+    import n4_producer_bench as N4
+    import xrl_synth
+    from pecos_amd import clib
+    D, N = 3000, 400
+    X = xrl_synth.make_queries(N, D, 40, seed=3, relabel_seed=0)
+    words = np.array([f"t{i:x}" for i in range(D)])
+    tok = words[X.indices]
+    corpus = [" ".join(tok[X.indptr[i]:X.indptr[i + 1]]) for i in range(N)]
+    vdir = str(tmp_path / "vec")
+    os.makedirs(vdir)
+    N4.write_vectorizer(vdir, list(words), [(i,) for i in range(D)], np.random.default_rng(5))
+    h = clib.tfidf_load(vdir)
+    try:
+        C = clib.tfidf_counts(h, corpus, threads=2)
+    finally:
+        clib.tfidf_destruct(h)
+    # feature ids are a permutation of the word ids in that synthetic model file: compare per-row counts and totals
+    assert C.shape == (N, D) and np.array_equal(np.diff(C.indptr), np.diff(X.indptr)) and np.all(C.data == 1.0)
