@@ -113,7 +113,8 @@ def main():
     ap.add_argument("--include-upload", action="store_true",
                     help="time the drop-in entry point instead: every rank calls c_xlinear_predict_* on ITS shard (pageable host X in, H2D, kernels, "
                          "D2H, host CSR out); value = all queries / max-over-ranks time (what a caller that shards by process gets, PCIe included)")
-    ap.add_argument("--parity-rows", type=int, default=4096, help="rows per shard of the TIMED output compared with the reference after the timed loop (0 = skip)")
+    ap.add_argument("--parity-rows", type=int, default=-1, help="rows per shard of the TIMED output compared with the reference after the timed loop "
+                                                               "(0 = skip; -1, the default = EVERY row when oracle/_ref is built, else 4096)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-extra", action="store_true", help="skip the extra lines of the default run (extra.hard: the same shape on the model that does not flatter "
                                                              "bound pruning; extra.text_to_labels: texts -> labels with X never on the host)")
@@ -184,6 +185,11 @@ def main():
         X = np.ascontiguousarray(X)
     n_total = X.shape[0]
     sparse = smat.issparse(X)
+    if args.parity_rows < 0:
+        # every row of the timed output against the compiled reference (~10 s of host time for 490 000 Amazon-shape rows); the
+        # single-threaded restatement and the dense-768 reference path (1 M multiply-adds per query) get a bounded sample
+        ref_built = os.path.exists(os.path.join(REPO, "oracle", "_ref", "libpecos_float32.so"))   # (the checker itself is only loaded after the timed region)
+        args.parity_rows = n_total if (ref_built and sparse) else 4096
     nnz_row = (X.nnz if sparse else X.size) / max(1, n_total)
     if rank == 0:
         log(f"workload {args.config} scale={args.scale}: layers={ks} X={X.shape} nnz/row={nnz_row:.1f} ({time.time() - t0:.1f}s)")
@@ -587,7 +593,8 @@ def timed_output_parity(folder, Xpar, G, beam, topk, world, rows_per_shard, log)
     same_idx = bool(same_rows and np.array_equal(G.indices, P.indices))
     bit = bool(same_idx and np.array_equal(G.data.astype(np.float32).view(np.uint32), P.data.astype(np.float32).view(np.uint32)))
     log(f"timed output vs {kind}: {n} rows ({rows_per_shard} per shard x {world}): indices identical={same_idx} scores bit-identical={bit}")
-    return dict(timed_output_identical=bool(same_idx and bit), timed_output_sample=f"first {rows_per_shard} rows of each of the {world} shard(s) = {n} rows, "
+    return dict(timed_output_identical=bool(same_idx and bit), timed_output_rows=int(n),
+                timed_output_sample=f"first {rows_per_shard} rows of each of the {world} shard(s) = {n} rows, "
                 f"read back from the buffers the timed steps wrote, vs {kind}", timed_output_indices_identical=same_idx, timed_output_scores_bit_identical=bit)
 
 

@@ -261,9 +261,7 @@ constexpr int kStageSlots = 3;   // == the length of Workspace::stage
 // ~8 rounds of 67 us at that size); on one stream the next batch's first kernel waits for that tail, on two it fills the CUs the tail
 // leaves idle.  Batches write disjoint rows of the result buffers; the uploads they wait for are ordered by the copy stream's events as
 // before.  XRL_HOST_STREAMS=1 restores the single compute stream.
-struct HostLanes { hipEvent_t done[2] = {nullptr, nullptr}; hipStream_t strm[2] = {nullptr, nullptr}; hipEvent_t join = nullptr; };
-static std::mutex g_host_lanes_mu;
-static std::unordered_map<const Model*, HostLanes> g_host_lanes;      // (entries die with the process: two events per handle)
+// The lanes' events live in the handle (Model::host_lanes): they are destroyed with it, on its device.
 static int host_streams() {
     static const int n = [] { const char* e = std::getenv("XRL_HOST_STREAMS"); return (e && e[0] == '1') ? 1 : 2; }();
     return n;
@@ -366,19 +364,20 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
         reg_idx = reg_val = false;
     };
     // two compute lanes for the row batches (see HostLanes above); the handle's lock is held by the caller
-    const bool two = host_streams() == 2 && n_batch >= 3 && !m.profiling;
-    HostLanes* hl = nullptr;
-    if (two) {
-        if (!m.aux_stream) XRL_HIP(hipStreamCreateWithFlags(&m.aux_stream, hipStreamNonBlocking));
-        { std::lock_guard<std::mutex> g(g_host_lanes_mu); hl = &g_host_lanes[&m]; }
-        if (!hl->join) XRL_HIP(hipEventCreateWithFlags(&hl->join, hipEventDisableTiming));
-        hl->done[0] = m.ws_done; hl->strm[0] = m.ws_stream;              // lane 0 = the handle's own bookkeeping; lane 1 keeps its event between calls
-        // the auxiliary lane starts after everything queued on the handle's stream so far (an earlier asynchronous predict may still use the scratch)
-        XRL_HIP(hipEventRecord(hl->join, m.stream));
-        XRL_HIP(hipStreamWaitEvent(m.aux_stream, hl->join, 0));
-    }
+    // (overlap_min_rows > 0 makes predict_device itself run two lanes over ws.lane[0 / 1] and the auxiliary stream: the two schemes would share
+    //  scratch and stream without an ordering between them, so the host lanes stand down -- ADVICE r5)
+    const bool two = host_streams() == 2 && n_batch >= 3 && !m.profiling && m.overlap_min_rows == 0;
+    Model::HostLanes* hl = &m.host_lanes;
     g_ht.prep += now_ms() - t_ph;
     try {
+        if (two) {
+            if (!m.aux_stream) XRL_HIP(hipStreamCreateWithFlags(&m.aux_stream, hipStreamNonBlocking));
+            if (!hl->join) XRL_HIP(hipEventCreateWithFlags(&hl->join, hipEventDisableTiming));
+            hl->done[0] = m.ws_done; hl->strm[0] = m.ws_stream;              // lane 0 = the handle's own bookkeeping; lane 1 keeps its event between calls
+            // the auxiliary lane starts after everything queued on the handle's stream so far (an earlier asynchronous predict may still use the scratch)
+            XRL_HIP(hipEventRecord(hl->join, m.stream));
+            XRL_HIP(hipStreamWaitEvent(m.aux_stream, hl->join, 0));
+        }
         uint64_t chunk = 0;                                                 // staged chunks so far: slot = chunk & 1
         for (uint32_t b = 0; b < n_batch; ++b) {
             const uint64_t e0 = elem_at(rb[b]), e1 = elem_at(rb[b + 1]);
@@ -902,18 +901,7 @@ void c_xlinear_destruct_model(void* ptr) {
         if (!ptr) return;
         Model* m = static_cast<Model*>(ptr);
         (void)hipSetDevice(m->device);
-        auto drop_lanes = [](const Model* mm) {      // the host pipeline's second compute lane (HostLanes): lane 1's event and the join event are its own
-            std::lock_guard<std::mutex> g(g_host_lanes_mu);
-            auto it = g_host_lanes.find(mm);
-            if (it == g_host_lanes.end()) return;
-            if (it->second.done[1]) (void)hipEventDestroy(it->second.done[1]);
-            if (it->second.join) (void)hipEventDestroy(it->second.join);
-            g_host_lanes.erase(it);
-        };
-        for (auto& r : m->replicas) { (void)hipSetDevice(r->device); drop_lanes(r.get()); }
-        (void)hipSetDevice(m->device);
-        drop_lanes(m);
-        delete m;
+        delete m;                                     // (~Model releases the replicas, streams and events, each on its own device)
     });
 }
 
@@ -1333,6 +1321,7 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     else if (!std::strcmp(key, "adaptive")) { m.adaptive = (int)value; for (auto& u : m.fb_unstaged) u = 0; }
     else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;
     else if (!std::strcmp(key, "host_batch_mb")) m.host_batch_mb = (int)value;
+    else if (!std::strcmp(key, "sort_rest_min")) m.sort_rest_min = (int)value;
     else if (!std::strcmp(key, "host_register")) m.host_register = (int)value;   // 1: page-lock the caller's X in place (hipHostRegister) instead of staging it through pinned buffers   // 0: the host ABI uploads X in one piece before computing
     else if (!std::strcmp(key, "k1q_fuse")) m.k1q_fuse = (int)value;           // 0: one K1Q launch per dense-format layer
     else if (!std::strcmp(key, "k1g_min_items")) m.k1g_min_items = (int)value;   // dense X: queries per parent from which a dense-format layer runs the tiled SGEMM K1G (0 = never)
@@ -1367,7 +1356,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
                 use_device(dev);
                 std::unique_ptr<Model> r = m.src_kind == 0 ? load_model_from_disk(m.src_path, m.weight_matrix_type) : load_mmap_model_from_disk(m.src_path);
                 r->device = dev;
-                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->sort_rest = m.sort_rest; r->prune_mid = m.prune_mid; r->qsort = m.qsort; r->qsort_min_parents = m.qsort_min_parents; r->qsort_min_rows = m.qsort_min_rows; r->presence = m.presence; r->adaptive = m.adaptive; r->host_pipeline = m.host_pipeline; r->host_batch_mb = m.host_batch_mb; r->host_register = m.host_register;
+                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->sort_rest = m.sort_rest; r->sort_rest_min = m.sort_rest_min; r->prune_mid = m.prune_mid; r->qsort = m.qsort; r->qsort_min_parents = m.qsort_min_parents; r->qsort_min_rows = m.qsort_min_rows; r->presence = m.presence; r->adaptive = m.adaptive; r->host_pipeline = m.host_pipeline; r->host_batch_mb = m.host_batch_mb; r->host_register = m.host_register;
                 r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers;
                 r->overlap_min_rows = m.overlap_min_rows; r->prune = m.prune;
                 r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;
@@ -1457,13 +1446,15 @@ struct TfidfHandle {
     mutable std::mutex stream_mu;
     mutable hipStream_t stream = nullptr;
     mutable int stream_device = -1;
+    // call with the staging lock (stage.mu) HELD and keep it until the stream has been synchronised: a caller that switched devices
+    // replaces the stream, which must not happen under another thread's transfer
     hipStream_t stream_on(int device) const {
         std::lock_guard<std::mutex> g(stream_mu);
-        if (stream && stream_device != device) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (stream && stream_device != device) { (void)hipSetDevice(stream_device); (void)hipStreamDestroy(stream); stream = nullptr; (void)hipSetDevice(device); }
         if (!stream) { XRL_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); stream_device = device; }
         return stream;
     }
-    ~TfidfHandle() { if (stream) (void)hipStreamDestroy(stream); }
+    ~TfidfHandle() { if (stream) { (void)hipSetDevice(stream_device); (void)hipStreamDestroy(stream); } }
 };
 
 // texts -> term counts (host threads, into pinned staging) -> device -> weighting + normalisation (K5): a query handle that owns its three arrays
@@ -1473,6 +1464,7 @@ std::unique_ptr<Queries> tfidf_to_device(const TfidfHandle& H, const char* const
     const uint32_t nb = (uint32_t)V.base.size(), rows = (uint32_t)nr_doc;
     use_device(device);
     std::lock_guard<std::mutex> stage_lock(H.stage.mu);          // held until the stream has consumed the staging buffer (the synchronize below)
+    if (!s) s = H.stream_on(device);                             // the handle's pooled stream, taken under the staging lock
     std::vector<uint64_t> seg_ptr;
     uint32_t* h_col = nullptr; float* h_cnt = nullptr; uint64_t nnz = 0;
     V.count_corpus(corpus, doc_lens, nr_doc, threads, seg_ptr, [&](uint64_t n, uint32_t*& c, float*& v) {
@@ -1545,8 +1537,8 @@ void c_tfidf_predict(void* ptr, void* corpus_ptr, const size_t* doc_lens, size_t
         require_gpu();
         const TfidfHandle& H = *static_cast<TfidfHandle*>(ptr);
         use_device(g_device);
-        hipStream_t s = H.stream_on(g_device);        // (tfidf_to_device holds the handle's staging lock from its first use of the stream to its synchronize)
-        std::unique_ptr<Queries> q = tfidf_to_device(H, static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, g_device, s);
+        // (stream = nullptr: tfidf_to_device takes the handle's pooled stream under its staging lock and holds the lock until it has synchronised)
+        std::unique_ptr<Queries> q = tfidf_to_device(H, static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, g_device, nullptr);
         uint32_t* indices = nullptr; uint64_t* indptr = nullptr; float* data = nullptr;
         pred_alloc(false, q->dev.rows, q->dev.cols, q->nnz, &indices, &indptr, &data);
         if (!indptr || (q->nnz && (!indices || !data))) fail("allocator returned null");

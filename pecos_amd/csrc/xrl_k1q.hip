@@ -68,7 +68,7 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     v.dense_x = X.dense != 0; v.multi = n > 1; v.bias_first = bias_first;
     for (int l = 0; l < n; ++l) {
         v.pres = v.pres || a.layer[l].pres != nullptr;
-        v.big = v.big || ((uint64_t)Ls[l]->w_rows + 1) * Ls[l]->d_ld * 4ull >= (1ull << 32);
+        v.big = v.big || ((uint64_t)Ls[l]->w_rows + 1) * Ls[l]->d_ld * 4ull >= 0xFFFFFFF0ull;   // (0xFFFFFFF0 is the lane offset that switches a lane off: it must stay outside the resource)
     }
     switch (k1q_kernel_bucket(nsmax)) {
     case 1: if (ppc) k1q_launch_n1p1(a, grid, s, v); else k1q_launch_n1p0(a, grid, s, v); break;

@@ -52,6 +52,8 @@ Model::~Model() {
     replicas.clear();                       // each replica releases its objects with ITS device current
     (void)hipSetDevice(device);
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    if (host_lanes.done[1] && host_lanes.done[1] != ws_done) (void)hipEventDestroy(host_lanes.done[1]);   // (done[0] aliases ws_done)
+    if (host_lanes.join) (void)hipEventDestroy(host_lanes.join);
     if (aux_stream) (void)hipStreamDestroy(aux_stream);
     if (ws_done) (void)hipEventDestroy(ws_done);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);

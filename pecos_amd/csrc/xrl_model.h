@@ -165,6 +165,9 @@ struct Model {
     int host_batch_mb = 12;                 // host ABI, CSR input: megabytes of (column id, value) pairs per compute batch
     int host_pipeline = 1;                  // host ABI: cut large X into row batches whose upload overlaps the previous batch's kernels
     std::vector<hipEvent_t> events;         // cross-stream ordering (timing disabled), reused across predicts
+    // host ABI, two compute lanes (xrl_abi.cpp host_compute): lane 0 uses ws_done / ws_stream above; lane 1 keeps its own "scratch in use
+    // until" event between calls, and one join event orders the lanes.  Owned by the handle: ~Model destroys them on the handle's device.
+    struct HostLanes { hipEvent_t done[2] = {nullptr, nullptr}; hipStream_t strm[2] = {nullptr, nullptr}; hipEvent_t join = nullptr; } host_lanes;
     std::mutex mu;                          // one predict at a time per handle
     std::unique_ptr<Workspace> ws;
     // options
@@ -197,6 +200,7 @@ struct Model {
                                             // segment only when the layer's presence word says it holds a weight; 2 = every layer that has presence words; 0 = never
     int prune_mid = 1;                      // bound-pruned tile-format layers with >= 16 beam parents: a middle stage (slots 1..4) between the first parent and "everything else"
     int sort_rest = 1;                      // bound-pruned tile-format layers: the second phase's compacted items are tile-sorted before K1 runs on them (0: query order)
+    int sort_rest_min = 32768;              // ... only when the previous predicts' later stages held at least this many items (pruning feedback's count; 0 = always)
     int qsort = 1;                          // K1Q, sparse X: the last layer of a run of dense-format layers runs on queries SORTED by the best parent of their beam,
                                             // every XCD on a contiguous range of them (xrl_predict.cpp), when it has >= qsort_min_parents parents and the batch >= qsort_min_rows rows
     int qsort_min_parents = 64, qsort_min_rows = 131072;

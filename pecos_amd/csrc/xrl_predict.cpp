@@ -377,7 +377,14 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S,
                                                                    J, (uint32_t)L.cand_bound(J), lw.prune_done.as<uint32_t>(), nullptr, lw.x_ok.as<uint32_t>()); });
                 if (o.stats_out) XRL_HIP(hipMemsetAsync(lw.items_sorted.p, 0xFF, slots_b * k0_item_bytes(), S));   // the stats pass walks the whole list: unused slots read as "no tile"
-                const bool srt = sorts_rest(l);
+                bool srt = sorts_rest(l);
+                // ... unless the previous predicts left (almost) nothing for the later stages: four tiny launches of the sort then cost more than
+                // the locality buys (a 61 250-row shard of Amazon-670K: 0.99 -> 0.93 ms per step, profiles/r05_k1q/README.md).  The count is the one the
+                // pruning feedback already samples (the last stage's K1 launch writes it to a host-visible word); results never depend on it.
+                if (srt && P.fb_host && l < (size_t)Model::kFbLayers && m.sort_rest_min > 0) {
+                    const uint32_t seen = static_cast<volatile uint32_t*>(m.fb_host)[2 * Model::kFbLayers + l];
+                    if (seen != 0xFFFFFFFFu && seen < (uint32_t)m.sort_rest_min) srt = false;
+                }
                 if (P.fb_host && l < (size_t)Model::kFbLayers) m.fb_tile_slots[l] = (uint64_t)nrows * (beam_in[l] - stage_end[n_stage - 2]) * L.max_tiles_per_parent;
                 for (int st = 1; st < n_stage; ++st) {
                     const uint32_t r0 = stage_end[st - 1], r1 = stage_end[st];

@@ -5,6 +5,9 @@
 #   tests           python -m pytest tests -m gpu
 #   smoke           __graft_entry__.smoke()
 #   bench[:ARGS]    python bench.py ARGS            (ARGS with ',' for spaces; output bench_<n>.json / .err)
+#   probe[:ARGS]    python scripts/host_abi_probe.py ARGS   (fresh process; per-call times + the library's stage timing lines)
+#   ab:ROWS@CONFIG@STEPS@SET|SET|...   scripts/ab.py on the first ROWS rows (0 = all) of CONFIG: option sets (k=v+k=v, "" = defaults) timed in one process,
+#                   outputs compared bit for bit with the first set's; XRL_SO=<variant .so> selects a library build
 #   pmc[:ARGS]      two rocprofv3 --pmc passes (FETCH_SIZE + SQ counters | WRITE_SIZE + L2 hit / miss / requests) + a --kernel-trace --stats pass over
 #                   `bench.py --steps 4 --warmup 6 --no-cpu-baseline --no-host-abi --no-stats ARGS` (last 4 steps counted), reduced to per-kernel CSVs and one pmc_traffic entry
 ulimit -c 0
@@ -24,6 +27,11 @@ try:
     d=json.load(open('$O/bench_$n.json')); print({k:d.get(k) for k in ('value','ms_per_step','value_host_abi','parity')}); print(d['roofline'].get('per_kernel_ms_per_step'))
 except Exception as e: print('no json', e)
 " ;;
+    probe) n=$((n+1)); timeout 600 python scripts/host_abi_probe.py $args > $O/probe_$n.json 2> $O/probe_$n.err; grep -E "probe|xrl host" $O/probe_$n.err | cut -c1-400; cat $O/probe_$n.json ;;
+    ab) n=$((n+1)); IFS='@' read -r ab_rows ab_cfg ab_steps ab_sets <<< "${st#*:}"
+        IFS='|' read -ra ab_list <<< "$ab_sets"; ab_args=(); for x in "${ab_list[@]}"; do ab_args+=("$(echo "$x" | tr '+' ',')"); done
+        [ ${#ab_args[@]} -eq 0 ] && ab_args=("")
+        echo "== ab rows=$ab_rows $ab_cfg so=${XRL_SO:-default}"; AB_ROWS=$ab_rows PECOS_XRL_AMD_SO=${XRL_SO:+$R/pecos_amd/lib/$XRL_SO} timeout 600 python scripts/ab.py $ab_cfg 1.0 $ab_steps "${ab_args[@]}" > $O/ab_$n.log 2>&1; grep -E "ms/step|Error|error" $O/ab_$n.log | cut -c1-600 ;;
     pmc) # pmc:BENCHARG,BENCHARG,...   two counter passes (TCC + TCP + SQ blocks have separate slots) + one --kernel-trace --stats pass; writes
          # pmc_<n>_{fetch,write,l2,sq}.csv, kernel_stats_<n>.csv and the pmc_traffic entry pmc_entry_<n>.json (scripts/pmc_traffic.py)
          n=$((n+1)); cd /tmp && export TMPDIR=/tmp XRL_STEP_MARKER=1

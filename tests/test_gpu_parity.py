@@ -552,6 +552,17 @@ def test_full_size_vs_reference(name, XLM, clib, oracle_mod, tmp_path):
     for dl in (1, 2, 0):
         clib.set_option(m.model.model_chain, "dense_layers", dl)
         assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{name} full size, dense_layers={dl}")
+    clib.set_option(m.model.model_chain, "dense_layers", 1)
+    if name == "wiki10-31k":
+        # host ABI with >= 3 row batches (75 MB of CSR, 4 MB first batch) while predict_device's OWN two-lane split is on (the two
+        # schemes used to share scratch lanes and the auxiliary stream without an ordering between them); repeated, the race was timing-dependent
+        h = m.model.model_chain
+        clib.set_option(h, "host_batch_mb", 4)
+        for omr in (2, 0):
+            clib.set_option(h, "overlap_min_rows", omr)
+            for rep in range(3):
+                assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{name} full size, host batches + overlap_min_rows={omr}, call {rep}")
+        clib.set_option(h, "host_batch_mb", 12)
 
 
 def test_hash_chunked_sparse_queries_bit_exact(manifest, XLM, clib, oracle_mod, tmp_path):
@@ -734,6 +745,28 @@ def test_headline_config_full_size_all_rows_vs_reference(workload, XLM, clib, or
     names = {r["name"] for r in clib.profile_get(h)}
     clib.profile_enable(h, False)
     assert "k1q_fused_0_3" in names and "k1_sparse" in names, names
+    # ---- the launch shape bench.py TIMES (VERDICT r5 missing #3): X resident in HBM, ONE xrl_predict_device_rows call over all 490 000
+    #      rows with default options -- which is what reaches the sorted launch (qsort_min_rows = 131 072): levels 0-2 fused, queries
+    #      counting-sorted by the best beam parent, level 3 as its own single-layer launch on the permutation -- every row against the reference
+    import torch
+    from pecos_amd.distributed import rows_to_csr
+    k = clib.effective_topk(h, 10)
+    q = clib.queries_upload(h, X)
+    N = X.shape[0]
+    dev = torch.device("cuda", 0)
+    t_idx = torch.zeros((N, k), dtype=torch.int32, device=dev); t_val = torch.zeros((N, k), dtype=torch.float32, device=dev)
+    t_cnt = torch.zeros((N,), dtype=torch.int32, device=dev)
+    for rep in range(7):   # repeats: the pruning feedback switches layers to their unstaged (presence-word) instantiations on the hard model
+        t_idx.fill_(-1); t_val.fill_(float("nan")); t_cnt.fill_(-1)
+        clib.profile_enable(h, True); clib.profile_reset(h)
+        clib.predict_device_rows(h, q, 10, None, 10, t_idx.data_ptr(), t_val.data_ptr(), t_cnt.data_ptr(), k, 0, N, sync=True)
+        names = {r["name"] for r in clib.profile_get(h)}
+        clib.profile_enable(h, False)
+        assert {"k1q_fused_0_2", "k1_sort_queries", "k1q_dense"} <= names and "k1q_fused_0_3" not in names, names
+        got = rows_to_csr(t_idx.cpu().numpy().view(np.uint32), t_val.cpu().numpy(), t_cnt.cpu().numpy().view(np.uint32), m.nr_pred_cols)
+        assert_same_topk(got, want, exact_scores=True, what=f"{workload} full size, device-resident X, one 490000-row call (sorted launch), predict #{rep}")
+    clib.queries_free(q)
+    del t_idx, t_val, t_cnt
     clib.set_option(h, "dense_layers", 0)
     assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"{workload} full size, tile format everywhere")
     clib.set_option(h, "dense_layers", 1)
