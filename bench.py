@@ -335,6 +335,7 @@ def main():
         if world == 1 and not args.no_host_abi and not args.include_upload:
             view = ScipyCsrF32.init_from(Xs) if sparse else ScipyDrmF32.init_from(Xs)
             times = []
+            first_call = None
             for it in range(1 + max(1, args.host_steps)):
                 alloc = ScipyCompressedSparseAllocator()
                 t0 = time.perf_counter()
@@ -342,10 +343,15 @@ def main():
                 t1 = time.perf_counter() - t0
                 if it:
                     times.append(t1)
+                else:
+                    first_call = t1
             med = float(np.median(times))
             out["value_host_abi"] = round(n_total / med, 1)
             out["host_abi"] = dict(entry="c_xlinear_predict_csr_f32" if sparse else "c_xlinear_predict_drm_f32", ms_per_call=round(med * 1e3, 3),
-                                   calls=len(times), includes="H2D of X from pageable host memory (pinned staging, row batches pipelined with compute), "
+                                   calls=len(times), ms_calls=[round(t * 1e3, 2) for t in times],
+                                   first_call_ms=round(first_call * 1e3, 2), first_call_note="this process's first host-ABI call (untimed warm-up call of the loop): the device-"
+                                   "resident loop has run before it, so kernels are loaded; X's device arrays and the pinned result buffers are allocated inside it. "
+                                   "A fresh process's first call: profiles/r06_host_abi.md", includes="H2D of X from pageable host memory (pinned staging, row batches pipelined with compute), "
                                    "kernels, D2H, allocator callback, host CSR assembly", x_bytes=int(Xs.nnz * 8 + (rows + 1) * 8) if sparse else int(Xs.size * 4),
                                    ratio_to_device_resident=round(n_total / med / value, 3))
             log(f"host ABI: {med * 1e3:.2f} ms per call = {n_total / med / 1e6:.2f} M q/s ({n_total / med / value:.2f} x device-resident)")
@@ -389,6 +395,10 @@ def main():
                 out["extra"]["text_to_labels"] = text_to_labels(clib, model, folder, Xs, beam, args.topk, args.text_docs, log)
             except Exception as e:   # never let an extra line break the bench
                 log(f"extra.text_to_labels skipped: {e!r}")
+            try:
+                out["extra"]["shard8"] = shard8_line(clib, h, q, torch, dev, stream, tstream, beam, args, k, n_total, ms_per_step, log)
+            except Exception as e:
+                log(f"extra.shard8 skipped: {e!r}")
             clib.queries_free(q); q = None
             try:
                 out["extra"]["hard"] = hard_line(args, log)
@@ -596,6 +606,33 @@ def timed_output_parity(folder, Xpar, G, beam, topk, world, rows_per_shard, log)
     return dict(timed_output_identical=bool(same_idx and bit), timed_output_rows=int(n),
                 timed_output_sample=f"first {rows_per_shard} rows of each of the {world} shard(s) = {n} rows, "
                 f"read back from the buffers the timed steps wrote, vs {kind}", timed_output_indices_identical=same_idx, timed_output_scores_bit_identical=bit)
+
+
+def shard8_line(clib, h, q, torch, dev, stream, tstream, beam, args, k, n_total, ms_full, log):
+    """extra.shard8: the one-GPU PROXY of the 8-GPU run (SCALE_rNN needs an 8-GPU node): the step on ONE rank's shard -- the first
+    n_total / 8 rows, device-resident, same entry point and options -- timed like the main loop.  projected_speedup_8 = full-step time /
+    shard-step time: what 8 ranks would reach if the all-gather hides completely under the next step (it is queued on a second
+    stream for that) and RCCL took no CUs.  Not a measurement of 8 GPUs."""
+    rows = n_total // 8
+    idx = torch.zeros((rows, k), dtype=torch.int32, device=dev); val = torch.zeros((rows, k), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((rows,), dtype=torch.int32, device=dev)
+
+    def step():
+        clib.predict_device_rows(h, q, beam, None, args.topk, idx.data_ptr(), val.data_ptr(), cnt.data_ptr(), k, 0, rows, stream=stream, sync=False)
+    with torch.cuda.stream(tstream):
+        for _ in range(max(args.warmup, 8)):      # (the pruning feedback's item counts settle at the shard's size)
+            step()
+        torch.cuda.synchronize()
+        n = max(args.steps, 50)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+    log(f"extra.shard8: {rows} rows in {ms:.3f} ms per step -> projected 8-GPU speed-up {ms_full / ms:.2f}x (one-GPU proxy)")
+    return dict(rows=rows, ms_per_step=round(ms, 4), steps=n, projected_speedup_8=round(ms_full / ms, 2),
+                note="one-GPU proxy of the strong-scaling run: one rank's shard (n_total / 8 rows) on this GPU; assumes the all-gather of step s hides under "
+                     "step s+1 and RCCL takes no CUs; NOT an 8-GPU measurement")
 
 
 def hard_line(args, log):

@@ -2,9 +2,10 @@
 # One gpurun call = one invocation of this script on the GPU box:  scripts/gpu_round.sh <tag> <stage> [<stage> ...]
 # Everything is written under gpurun_out/<tag>/ (merged back by gpurun); summaries worth keeping are copied to profiles/ by hand.
 # Stages:
-#   tests           python -m pytest tests -m gpu
+#   tests[:ARGS]    python -m pytest -m gpu ARGS   (default: tests; ',' separates arguments, '+' is a space inside one, e.g. tests:tests/test_gpu_fuzz.py,-k,fuzz+or+goldens)
 #   smoke           __graft_entry__.smoke()
 #   bench[:ARGS]    python bench.py ARGS            (ARGS with ',' for spaces; output bench_<n>.json / .err)
+#   so[:NAME]       the following stages load pecos_amd/lib/NAME (a kernel-tuning variant built by scripts/build_variant.sh) instead of libxrl_amd.so; empty = back to the default
 #   probe[:ARGS]    python scripts/host_abi_probe.py ARGS   (fresh process; per-call times + the library's stage timing lines)
 #   ab:ROWS@CONFIG@STEPS@SET|SET|...   scripts/ab.py on the first ROWS rows (0 = all) of CONFIG: option sets (k=v+k=v, "" = defaults) timed in one process,
 #                   outputs compared bit for bit with the first set's; XRL_SO=<variant .so> selects a library build
@@ -18,7 +19,9 @@ n=0
 for st in "$@"; do
   name=${st%%:*}; args=""; [ "$st" != "$name" ] && args=$(echo "${st#*:}" | tr ',' ' ')
   case $name in
-    tests) timeout ${XRL_TESTS_TIMEOUT:-1500} python -m pytest tests -m gpu -q -x $args 2>&1 | tail -15 > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
+    tests) targs=(); if [ "$st" != "$name" ]; then IFS=',' read -ra tl <<< "${st#*:}"; for x in "${tl[@]}"; do targs+=("${x//+/ }"); done; fi   # (',' separates arguments, '+' stands for a space inside one: -k,fuzz+or+goldens)
+           [ ${#targs[@]} -eq 0 ] && targs=(tests)
+           timeout ${XRL_TESTS_TIMEOUT:-1500} python -m pytest -m gpu -q -x "${targs[@]}" 2>&1 | tail -15 > $O/pytest_gpu.log; cat $O/pytest_gpu.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log ;;
     bench) n=$((n+1)); echo "== bench $args"; timeout ${XRL_BENCH_TIMEOUT:-600} python bench.py $args > $O/bench_$n.json 2> $O/bench_$n.err; echo "$args" > $O/bench_$n.args
            grep -E "per-launch|host ABI|xrl host|cpu reference|Error|error" $O/bench_$n.err | cut -c1-1500; python -c "
@@ -27,11 +30,12 @@ try:
     d=json.load(open('$O/bench_$n.json')); print({k:d.get(k) for k in ('value','ms_per_step','value_host_abi','parity')}); print(d['roofline'].get('per_kernel_ms_per_step'))
 except Exception as e: print('no json', e)
 " ;;
+    so) if [ -n "$args" ]; then export PECOS_XRL_AMD_SO=$R/pecos_amd/lib/$args; else unset PECOS_XRL_AMD_SO; fi; echo "== library: ${PECOS_XRL_AMD_SO:-default}" ;;
     probe) n=$((n+1)); timeout 600 python scripts/host_abi_probe.py $args > $O/probe_$n.json 2> $O/probe_$n.err; grep -E "probe|xrl host" $O/probe_$n.err | cut -c1-400; cat $O/probe_$n.json ;;
     ab) n=$((n+1)); IFS='@' read -r ab_rows ab_cfg ab_steps ab_sets <<< "${st#*:}"
         IFS='|' read -ra ab_list <<< "$ab_sets"; ab_args=(); for x in "${ab_list[@]}"; do ab_args+=("$(echo "$x" | tr '+' ',')"); done
         [ ${#ab_args[@]} -eq 0 ] && ab_args=("")
-        echo "== ab rows=$ab_rows $ab_cfg so=${XRL_SO:-default}"; AB_ROWS=$ab_rows PECOS_XRL_AMD_SO=${XRL_SO:+$R/pecos_amd/lib/$XRL_SO} timeout 600 python scripts/ab.py $ab_cfg 1.0 $ab_steps "${ab_args[@]}" > $O/ab_$n.log 2>&1; grep -E "ms/step|Error|error" $O/ab_$n.log | cut -c1-600 ;;
+        echo "== ab rows=$ab_rows $ab_cfg"; AB_ROWS=$ab_rows timeout 600 python scripts/ab.py $ab_cfg 1.0 $ab_steps "${ab_args[@]}" > $O/ab_$n.log 2>&1; grep -E "ms/step|Error|error" $O/ab_$n.log | cut -c1-600 ;;
     pmc) # pmc:BENCHARG,BENCHARG,...   two counter passes (TCC + TCP + SQ blocks have separate slots) + one --kernel-trace --stats pass; writes
          # pmc_<n>_{fetch,write,l2,sq}.csv, kernel_stats_<n>.csv and the pmc_traffic entry pmc_entry_<n>.json (scripts/pmc_traffic.py)
          n=$((n+1)); cd /tmp && export TMPDIR=/tmp XRL_STEP_MARKER=1
