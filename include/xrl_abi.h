@@ -328,6 +328,10 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *                         ties by position), so the result is unchanged bit for bit; NaN parent scores and "noop" disable it per
  *                         query / layer; 0: every candidate of every beam parent is scored (what the reference evaluates)
  *   "overlap_min_rows"    split predicts of at least this many rows into two batches on two streams (0 = never)
+ *   "reserve_rows"        sizes the host ABI's result buffers (pinned host + device, rows x the model's default top-k) for calls of up to this many rows NOW
+ *                         instead of inside the first large call.  (Everything that does not depend on X -- copy threads, streams, the pinned upload
+ *                         ring, kernel code objects, both scratch lanes for 65 536-row batches -- is created when a model is loaded from a folder;
+ *                         the environment variable XRL_WARM=0 turns that off.)
  *   "host_batch_mb"       12 (default): CSR input of the pipelined host ABI is computed in batches that grow x1.6 from a third of this
  *                         many megabytes of (column id, value) pairs up to three times it (measured on Amazon-670K: 12 -> 10.4 ms per
  *                         call, 24 -> 12.1, 36 -> 13.0)

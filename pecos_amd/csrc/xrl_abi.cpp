@@ -326,8 +326,15 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     auto elem_at = [&](uint32_t r) -> uint64_t { return is_csr ? Xs->row_ptr[r] : (uint64_t)r * Xd->cols; };
     uint64_t max_elems = 0;
     for (uint32_t b = 0; b < n_batch; ++b) max_elems = std::max(max_elems, elem_at(rb[b + 1]) - elem_at(rb[b]));
+    double t_fine = now_ms();
+    auto fine = [&](const char* what) {   // (diagnostics, XRL_HOST_TIMING=1: which step of the preparation took long)
+        if (host_timing() && now_ms() - t_fine > 1.0) std::fprintf(stderr, "[xrl host]   prep: %s took %.2f ms\n", what, now_ms() - t_fine);
+        t_fine = now_ms();
+    };
+    fine("batch planning");
     if (is_csr) {
         ws.x_ptr.upload_raw(Xs->row_ptr, ((size_t)rows + 1) * 8);
+        fine("row-pointer upload (synchronous pageable copy)");
         ws.x_idx.reserve(elems * 4); ws.x_val.reserve(elems * 4);
         X.row_ptr = ws.x_ptr.as<uint64_t>(); X.col_idx = ws.x_idx.as<uint32_t>(); X.val = ws.x_val.as<float>();
         X.rows = rows; X.cols = Xs->cols; X.dense = 0; X.nnz = elems;
@@ -338,12 +345,16 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     }
     for (uint32_t b = 0; b < n_batch; ++b) o.reserve_rows = std::max(o.reserve_rows, rb[b + 1] - rb[b]);
     const uint64_t chunk_elems = (32ull << 20) / (is_csr ? 8u : 4u);      // elements per staged upload chunk
+    fine("device arrays of X");
     for (int s2 = 0; s2 < kStageSlots; ++s2) ws.stage[s2].reserve(std::min(max_elems, chunk_elems) * (is_csr ? 8u : 4u));
+    fine("pinned staging ring");
     if (!m.copy_stream) XRL_HIP(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
     hipEvent_t up[kStageSlots];
     for (auto& e : up) XRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    fine("copy stream + events");
     const uint32_t k = effective_topk(m, o.only_topk);
     reserve_outputs(m, rows, k);
+    fine("result buffers (device + pinned host)");
     // option host_register: page-lock the caller's arrays in place for the duration of the call and let the copy engine read them
     // directly (no staging memcpy); falls back to staging when the registration fails
     bool reg_idx = false, reg_val = false;
@@ -422,8 +433,11 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
                     m.ws_done = hl->done[L]; m.ws_stream = hl->strm[L];
                 }
                 try {
+                    const double t_pd = now_ms();
                     predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, S, false,
                                    rb[b], rb[b + 1] - rb[b]);
+                    if (host_timing() && now_ms() - t_pd > 0.5)      // (diagnostics: a launch sequence that blocked -- an allocation, a code-object load)
+                        std::fprintf(stderr, "[xrl host]   batch %u/%u (%u rows, lane %d): enqueue took %.2f ms\n", b, n_batch, rb[b + 1] - rb[b], L, now_ms() - t_pd);
                 } catch (...) {
                     if (two) { hl->done[L] = m.ws_done; hl->strm[L] = m.ws_stream; if (L) std::swap(ws.lane[0], ws.lane[1]); m.ws_done = hl->done[0]; m.ws_stream = hl->strm[0]; }
                     throw;
@@ -858,6 +872,43 @@ int xrl_set_device(int device) {
     return rc;
 }
 
+
+// Everything the host ABI needs that does not depend on the caller's X is created when a model is LOADED from a folder, not inside the first
+// predict (a user's first call cost 42-66 ms, 25 of them allocations, 15 more the first launches): the copy-thread pool,
+// the copy / auxiliary / D2H streams, the three pinned staging buffers of the upload ring, the code objects of the kernels the default
+// policy runs, and BOTH scratch lanes sized for the row batches the pipeline cuts (a 36 MB batch of Amazon-shape rows is ~60 k queries).
+// One tiny predict per lane does the last two.  XRL_WARM=0 skips it (tests that load hundreds of throw-away models may want to).
+constexpr uint32_t kWarmRows = 65536;
+static void warm_handle(Model& m) {
+    static const bool off = [] { const char* e = std::getenv("XRL_WARM"); return e && e[0] == '0'; }();
+    if (off || m.layers.empty()) return;
+    use_device(m.device);
+    if (!m.ws) m.ws = std::make_unique<Workspace>();
+    Workspace& ws = *m.ws;
+    (void)CopyPool::get();
+    if (!m.copy_stream) XRL_HIP(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
+    if (!m.aux_stream) XRL_HIP(hipStreamCreateWithFlags(&m.aux_stream, hipStreamNonBlocking));
+    if (!m.d2h_stream) XRL_HIP(hipStreamCreateWithFlags(&m.d2h_stream, hipStreamNonBlocking));
+    for (int s2 = 0; s2 < kStageSlots; ++s2) ws.stage[s2].reserve((size_t)32 << 20);
+    // 256 one-feature queries through the default policy, once per scratch lane
+    const uint32_t R = 256, D = std::max<uint32_t>(1, m.nr_features);
+    std::vector<uint64_t> ptr(R + 1); std::vector<uint32_t> idx(R); std::vector<float> val(R, 1.0f);
+    for (uint32_t r = 0; r <= R; ++r) ptr[r] = r;
+    for (uint32_t r = 0; r < R; ++r) idx[r] = (uint32_t)(((uint64_t)r * 2654435761ull) % D);
+    ScipyCsrF32 Xh{}; Xh.rows = R; Xh.cols = m.nr_features; Xh.row_ptr = ptr.data(); Xh.col_idx = idx.data(); Xh.val = val.data();
+    QueriesDev X{};
+    upload_csr(&Xh, ws.x_ptr, ws.x_idx, ws.x_val, X);
+    PredictOpts o; o.reserve_rows = kWarmRows;
+    const uint32_t k = effective_topk(m, 0);
+    reserve_outputs(m, R, k);
+    for (int L = 0; L < 2 && !m.csc_route; ++L) {   // (the CSC route builds its device copy of W on first use: not here)
+        if (L) std::swap(ws.lane[0], ws.lane[1]);
+        try { predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, true); }
+        catch (...) { if (L) std::swap(ws.lane[0], ws.lane[1]); throw; }
+        if (L) std::swap(ws.lane[0], ws.lane[1]);
+    }
+}
+
 void* c_xlinear_load_model_from_disk_ext(const char* model_path, int weight_matrix_type) {
     void* out = nullptr;
     guarded([&] {
@@ -866,6 +917,7 @@ void* c_xlinear_load_model_from_disk_ext(const char* model_path, int weight_matr
         use_device(g_device);
         auto m = load_model_from_disk(model_path, weight_matrix_type);
         m->device = g_device; m->src_path = model_path; m->src_kind = 0;
+        warm_handle(*m);
         out = m.release();
     });
     return out;
@@ -884,6 +936,7 @@ void* c_xlinear_load_mmap_model_from_disk(const char* model_path, const bool laz
         use_device(g_device);
         auto m = load_mmap_model_from_disk(model_path);
         m->device = g_device; m->src_path = model_path; m->src_kind = 1;
+        warm_handle(*m);
         out = m.release();
     });
     return out;
@@ -1322,6 +1375,15 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     else if (!std::strcmp(key, "host_pipeline")) m.host_pipeline = (int)value;
     else if (!std::strcmp(key, "host_batch_mb")) m.host_batch_mb = (int)value;
     else if (!std::strcmp(key, "sort_rest_min")) m.sort_rest_min = (int)value;
+    else if (!std::strcmp(key, "reserve_rows")) {
+        // a serving process that knows its largest batch sizes the result buffers of the host ABI once, at start-up (pinned host memory: rows x
+        // the model's default top-k x 8 bytes, + the device side), instead of inside its first large call
+        if (value < 0 || value > 0x7FFFFFFF) fail("reserve_rows: expected 0 .. 2^31-1");
+        std::lock_guard<std::mutex> g(m.mu);
+        use_device(m.device);
+        if (!m.ws) m.ws = std::make_unique<Workspace>();
+        reserve_outputs(m, (uint32_t)value, effective_topk(m, 0));
+    }
     else if (!std::strcmp(key, "host_register")) m.host_register = (int)value;   // 1: page-lock the caller's X in place (hipHostRegister) instead of staging it through pinned buffers   // 0: the host ABI uploads X in one piece before computing
     else if (!std::strcmp(key, "k1q_fuse")) m.k1q_fuse = (int)value;           // 0: one K1Q launch per dense-format layer
     else if (!std::strcmp(key, "k1g_min_items")) m.k1g_min_items = (int)value;   // dense X: queries per parent from which a dense-format layer runs the tiled SGEMM K1G (0 = never)
