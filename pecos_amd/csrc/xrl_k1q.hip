@@ -28,14 +28,17 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     if (n <= 0 || n > kK1QMaxLayers) fail("k1q: bad layer count");
     if (n > 1) for (int l = 0; l < n; ++l) if (k1q_regs(*Ls[l], Ps[l].beam_in, Ps[l].k, true) > 3) fail("k1q: only layers of <= 3 candidate registers can share a launch");
     if (Ps[0].nrows == 0) return;
-    K1QArgs a;
+    K1QArgs a{};
     uint32_t nsmax = 1; int ppc = 0;
     for (int l = 0; l < n; ++l) {
         const LayerDev& L = *Ls[l]; const LayerPlan& P = Ps[l];
         const uint32_t ns = k1q_regs(L, P.beam_in, P.k, true);      // capacity check only; whether sparse X SHOULD use the format is the caller's policy
         if (ns == 0) fail("k1q: layer not eligible");
         K1QLayer& y = a.layer[l];
-        y.wd = L.wd; y.d_ld = L.d_ld; y.pres = (!X.dense && !P.tune.ablate && (P.tune.pres_mode == 2 || (P.tune.pres_mode == 1 && !P.prune))) ? L.pres : nullptr; y.pres_words = L.pres_words;   // presence words: layers that run unstaged
+        y.wd = L.wd; y.d_ld = L.d_ld;
+        // presence words: layers that run unstaged (or every layer that has them: presence = 2); the masks need dense tiles of >= 16 columns (<= 4 beam slots per candidate register)
+        y.pres = (!X.dense && !P.tune.ablate && L.d_gp_log2 >= 4 && (P.tune.pres_mode == 2 || (P.tune.pres_mode == 1 && !P.prune))) ? L.pres : nullptr;
+        y.pres_words = L.pres_words;
         y.d_ptile = L.d_ptile; y.d_tcol = L.d_tcol; y.bias_prod = L.bias_prod; y.perm_inv = L.perm_inv;
         y.d_gp_log2 = L.d_gp_log2; y.d_max_tiles = L.d_max_tiles; y.n_parents = L.n_parents; y.w_rows = L.w_rows;
         y.beam_in = P.beam_in; y.k = P.k; y.ns = k1q_bucket(ns);

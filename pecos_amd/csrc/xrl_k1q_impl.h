@@ -111,6 +111,45 @@ template <int NS> struct K1QCfg {
     static constexpr int U = NS <= 1 ? XRL_K1Q_U1 : NS <= 2 ? XRL_K1Q_U2 : NS <= 3 ? XRL_K1Q_U3 : NS <= 12 ? 4 : 2;
 };
 
+
+// PRESENCE MASKS (round 6).  Layers that run UNSTAGED on sparse X ask the layer's presence words before requesting weight segments (a third to
+// a half of the (feature, parent) segments of such layers are empty).  Round 4 / 5 asked per batch, lane = candidate: a presence load, a wait,
+// then the weight load -- two dependent round trips per batch of 8 features.  Now the question is asked once per 64-feature CHUNK with the
+// lanes turned around: lane = chunk feature, and for each of the <= 4 beam slots of each candidate register (dense tiles of >= 16 columns) ONE
+// load returns the presence word of (this lane's feature, the slot's tile) -- 4 independent loads per register, all lanes in flight together.
+// Result: one bit per (register, slot) in a per-lane mask; inside the batch loop a feature's mask is one v_readlane and a lane whose slot holds
+// no weight at the feature switches its weight load off (offset outside the resource: 0.0, no memory request).  A batch is ONE round trip.
+// A function of its own (noinline): the unstaged kernels have no scalar registers to spare, and the 4 NR tile ids + offsets + shifts are
+// allocated in the callee's frame instead of being spilled around the hot loop.
+//   pres_rs: the layer's presence array as one buffer resource (pres_all bytes); fvo: this lane's feature x bytes per presence row; t0..t2: per lane,
+//   the dense tile of the lane's candidate in registers RB, RB+1, RB+2 (slot q's tile sits in lane q << gl); Q = 64 >> gl slots per register
+#ifndef XRL_PM_INLINE
+#define XRL_PM_INLINE 0
+#endif
+#if XRL_PM_INLINE
+__device__ __forceinline__
+#else
+__device__ __attribute__((noinline))
+#endif
+uint32_t k1q_presence_mask(__amdgpu_buffer_rsrc_t pres_rs, uint32_t pres_all, uint32_t fvo, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t gl, int nr) {
+    const uint32_t Q = 64u >> gl;
+    uint32_t pm = 0u;
+    for (int r = 0; r < nr; ++r) {
+        const uint32_t tiles = r == 0 ? t0 : r == 1 ? t1 : t2;
+        uint32_t pw[4], tq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tq[q] = (uint32_t)__builtin_amdgcn_readlane((int)tiles, (int)(((uint32_t)q << gl) & 63u));
+            // (slots a register does not have -- 32-column tiles: 2 per register -- address outside the resource: no request, bit 0;
+            //  gfx950 treats voffset + soffset >= num_records as out of range: scripts/buffer_range_probe.hip)
+            pw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pres_rs, (int)fvo, (int)((uint32_t)q < Q ? (tq[q] >> 5) * 4u : pres_all), 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pm |= ((pw[q] >> (tq[q] & 31u)) & 1u) << (r * 4 + q);
+    }
+    return pm;
+}
+
 // One layer for one query (one wavefront): beam in s_bidx / s_bval[0..cnt) -> beam out in the same arrays; returns the new count.
 // BIASF: the accumulators start at the bias product (dense X; sparse X under HASH_CHUNKED, inference.hpp:716-722) instead of receiving it
 // last -- a compile-time switch: as a run-time one it cost the widest kernel 8 VGPRs and a wavefront per SIMD
@@ -161,7 +200,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     const uint32_t w_rows = Ly.w_rows;
     // presence words: dense tile of a lane's byte offset = woff >> (gl + 2); its word's byte offset in the presence row = (tile >> 5) * 4
     const uint32_t* __restrict__ pres = Ly.pres;
-    const uint32_t pres_bytes = Ly.pres_words * 4u, dt_shift = gl + 2u, pw_shift = gl + 2u + 5u - 2u;
+    const uint32_t pres_bytes = Ly.pres_words * 4u, dt_shift = gl + 2u;
     const __amdgpu_buffer_rsrc_t pres_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(PRES && pres ? pres : wd), 0, (int)(PRES && pres ? (w_rows + 1u) * pres_bytes : 0u), 0x00020000);
     uint32_t xmx = 0u, xn = 0u;                                        // pruning guard: largest |x| bits this lane has seen, features of the query
 
@@ -176,30 +215,21 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
     auto pass = [&](auto rb_tag, auto re_tag) {
         constexpr int RB = decltype(rb_tag)::value, RE = decltype(re_tag)::value, NR = RE - RB;
         constexpr int UU = K1QCfg<NR>::U;
-        auto body_f = [&](auto exact_tag, auto&& getf, auto&& getx) {   // getf(u) / getx(u): feature id and value of the batch's u-th feature
+        // presence masks (k1q_presence_mask): one bit per (register of this pass, beam slot), per lane = feature of the current chunk
+        const bool pmask_ok = PRES && pres != nullptr && NR <= 3;
+        uint32_t pm = 0u, mybit[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) mybit[r] = 1u << (((uint32_t)r * 4u + ((uint32_t)lane >> gl)) & 31u);
+        auto body_f = [&](auto exact_tag, auto&& getf, auto&& getx, uint32_t tl) {   // getf(u) / getx(u): feature id and value of the batch's u-th feature; tl: its slot in the 64-feature chunk
             constexpr bool EX = decltype(exact_tag)::value;
             uint32_t wb[UU][NR];
-            if (PRES && !EX && pres != nullptr) {
-                // PRESENCE: first the word that says whether this lane's dense tile holds any weight at the feature (one small row per
-                // feature, mostly L2-resident), then the weight load with the lane's offset -- or an offset outside the resource for an
-                // empty tile: such lanes read 0.0 without a memory request.  A 64-byte segment none of whose lanes asks is never fetched.
-                // (the whole presence array is ONE resource -- it is < 2 GiB, xrl_model.cpp -- and the feature's row is the instruction's SCALAR offset.
-                //  Round 5 also tried staging a chunk's presence rows in LDS with buffer_load ... lds, to replace this dependent trip to the L2 by
-                //  an LDS read: slower, 5.9 + 3.8 ms against 4.45 + 3.0 ms on the hard workload -- profiles/r05_k1q_experiments.md)
-#pragma unroll
-                for (int u = 0; u < UU; ++u) {
-                    const uint32_t prow = getf(u) * pres_bytes;
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) wb[u][r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pres_rs, (int)((woff[RB + r] >> pw_shift) & ~3u), (int)prow, 0);
-                }
+            if (PRES && !EX && pmask_ok) {
 #pragma unroll
                 for (int u = 0; u < UU; ++u) {
                     const uint32_t fu = getf(u);
+                    const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)pm, (int)((tl + (uint32_t)u) & 63u));
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const bool present = ((wb[u][r] >> ((woff[RB + r] >> dt_shift) & 31u)) & 1u) != 0u;
-                        wb[u][r] = k1q_load_w<BIGW>(wd, ld, w_rows + 1u, fu, present ? woff[RB + r] : 0xFFFFFFF0u);
-                    }
+                    for (int r = 0; r < NR; ++r) wb[u][r] = k1q_load_w<BIGW>(wd, ld, w_rows + 1u, fu, (sm & mybit[r]) ? woff[RB + r] : 0xFFFFFFF0u);
                 }
             } else {
 #pragma unroll
@@ -221,8 +251,8 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                 }
             }
         };
-        auto body = [&](auto exact_tag, const uint32_t (&fs)[UU], const float (&xs)[UU]) {
-            body_f(exact_tag, [&](int u) { return fs[u]; }, [&](int u) { return xs[u]; });
+        auto body = [&](auto exact_tag, const uint32_t (&fs)[UU], const float (&xs)[UU], uint32_t tl) {
+            body_f(exact_tag, [&](int u) { return fs[u]; }, [&](int u) { return xs[u]; }, tl);
         };
         // the query's (feature, value) pairs: its CSR row (chunk_ops<csr, bin_search>, inference.hpp:769-813: ascending features), or every
         // chunk row except the bias row with x gathered by row id (chunk_ops<drm, bin_search>, :815-839)
@@ -249,6 +279,9 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
             // loop below, which sends such features to the all-missing row like the reference's row lookup finds nothing for them
             const uint32_t ib = (!DENSEX && (uint32_t)lane < nc) ? fsrc[t0 + (uint32_t)lane] : 0u;
             const bool nonfinite = __ballot(vb >= 0x7F800000u || ib > w_rows) != 0ull;
+            if (pmask_ok && !nonfinite)   // (ib <= w_rows here; lanes past the chunk's end hold feature 0: their masks are never applied to a weight that counts)
+                pm = k1q_presence_mask(pres_rs, (w_rows + 1u) * pres_bytes, ib * pres_bytes, woff[RB] >> dt_shift, woff[RB + (NR > 1 ? 1 : 0)] >> dt_shift,
+                                       woff[RB + (NR > 2 ? 2 : 0)] >> dt_shift, gl, NR < 3 ? NR : 3);
             for (uint32_t t = t0; t < t0 + nc; t += (uint32_t)UU) {
                 uint32_t fs[UU]; float xs[UU];
                 if (!nonfinite && t + (uint32_t)UU <= t0 + nc) {             // a full batch: plain uniform loads
@@ -257,11 +290,11 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                         // scalar-load round trip per batch and no SGPR arrays alive across the loads
                         const int tl = (int)(t - t0);
                         body_f(std::false_type{}, [&](int u) { return (uint32_t)__builtin_amdgcn_readlane((int)ib, tl + u); },
-                               [&](int u) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)xraw, tl + u)); });
+                               [&](int u) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)xraw, tl + u)); }, (uint32_t)tl);
                     } else {
 #pragma unroll
                         for (int u = 0; u < UU; ++u) { fs[u] = DENSEX ? t + (uint32_t)u : fsrc[t + (uint32_t)u]; xs[u] = vsrc[t + (uint32_t)u]; }
-                        body(std::false_type{}, fs, xs);
+                        body(std::false_type{}, fs, xs, t - t0);
                     }
                 } else if (!nonfinite && (uint64_t)t + (uint32_t)UU <= room) {  // the row's tail: the loads run on into the next row, the slots past the end are neutralised
 #pragma unroll
@@ -271,7 +304,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                         const float x = vsrc[t + (uint32_t)u];
                         fs[u] = ok ? f : w_rows; xs[u] = ok ? x : 0.0f;
                     }
-                    body(std::false_type{}, fs, xs);
+                    body(std::false_type{}, fs, xs, t - t0);
                 } else {                                                      // non-finite x in the chunk, or the end of the X arrays: clamped loads, exact loop
 #pragma unroll
                     for (int u = 0; u < UU; ++u) {
@@ -281,7 +314,7 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
                         const float x = vsrc[ic];
                         fs[u] = ok ? min(f, w_rows) : w_rows; xs[u] = ok ? x : 0.0f;
                     }
-                    body(std::true_type{}, fs, xs);
+                    body(std::true_type{}, fs, xs, t - t0);
                 }
             }
         }

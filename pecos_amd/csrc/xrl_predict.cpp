@@ -6,6 +6,7 @@
 #include "xrl_predict.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 namespace xrl {
@@ -193,7 +194,15 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         const int ln = (int)(batch % (uint64_t)lanes);
         LaneWs& lw = ws.lane[ln];
         hipStream_t S = lane_stream[ln];
+        static const bool debug_sync = [] { const char* e = std::getenv("XRL_DEBUG_SYNC"); return e && e[0] == '1'; }();
         auto timed = [&](const char* name, uint32_t layer, auto&& fn) {
+            if (debug_sync) {   // XRL_DEBUG_SYNC=1: every launch group is announced and synchronised on its own, a device fault names the kernel family and the layer
+                std::fprintf(stderr, "[xrl debug] %s layer %u rows %llu+%u\n", name, layer, (unsigned long long)row0, nrows); std::fflush(stderr);
+                fn();
+                const hipError_t e = hipStreamSynchronize(S);
+                if (e != hipSuccess) fail(std::string("device fault in ") + name + " (layer " + std::to_string(layer) + ", rows " + std::to_string(row0) + "+" + std::to_string(nrows) + "): " + hipGetErrorString(e));
+                return;
+            }
             if (!m.profiling) { fn(); return; }
             PendingEvent ev; ev.slot = profile_slot(m, name, layer);
             XRL_HIP(hipEventCreate(&ev.a)); XRL_HIP(hipEventCreate(&ev.b));
