@@ -123,30 +123,42 @@ template <int NS> struct K1QCfg {
 // allocated in the callee's frame instead of being spilled around the hot loop.
 //   pres_rs: the layer's presence array as one buffer resource (pres_all bytes); fvo: this lane's feature x bytes per presence row; t0..t2: per lane,
 //   the dense tile of the lane's candidate in registers RB, RB+1, RB+2 (slot q's tile sits in lane q << gl); Q = 64 >> gl slots per register
-#ifndef XRL_PM_INLINE
-#define XRL_PM_INLINE 0
-#endif
-#if XRL_PM_INLINE
-__device__ __forceinline__
-#else
-__device__ __attribute__((noinline))
-#endif
-uint32_t k1q_presence_mask(__amdgpu_buffer_rsrc_t pres_rs, uint32_t pres_all, uint32_t fvo, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t gl, int nr) {
+// Rows of <= 16 presence words (layers of <= 512 dense tiles: Amazon-670K's levels 2 and 3) are fetched WHOLE, one 64-byte row per lane in <= 4
+// 16-byte loads (a lane's four loads share one cache line: 64 line requests per chunk, where one 4-byte load per slot asked for 64 x 12),
+// and turned around through a wavefront-private LDS stage (word-major: conflict-free both ways) so that slot q's word -- the same word index
+// for every lane -- is one ds_read.  Wider rows fall back to one 4-byte load per slot.
+constexpr uint32_t kPresStageWords = 16;
+__device__ __forceinline__ uint32_t k1q_presence_mask(__amdgpu_buffer_rsrc_t pres_rs, uint32_t pres_all, uint32_t pres_words, uint32_t fvo, uint32_t t0, uint32_t t1, uint32_t t2,
+                                                      uint32_t gl, int nr, uint32_t* stage, int lane) {
     const uint32_t Q = 64u >> gl;
     uint32_t pm = 0u;
+    const bool staged_rows = pres_words <= kPresStageWords;
+    if (staged_rows) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((uint32_t)i * 4u < pres_words) {
+                // (a row shorter than the 16 bytes asked for runs on into the next row -- or, at the array's end, out of range: zeros; those words are never selected)
+                const u4 v = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(pres_rs, (int)(fvo + 16u * (uint32_t)i), 0, 0));
+                stage[(4 * i + 0) * 64 + lane] = v.x; stage[(4 * i + 1) * 64 + lane] = v.y; stage[(4 * i + 2) * 64 + lane] = v.z; stage[(4 * i + 3) * 64 + lane] = v.w;
+            }
+        wave_sync_lds();
+    }
     for (int r = 0; r < nr; ++r) {
         const uint32_t tiles = r == 0 ? t0 : r == 1 ? t1 : t2;
         uint32_t pw[4], tq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             tq[q] = (uint32_t)__builtin_amdgcn_readlane((int)tiles, (int)(((uint32_t)q << gl) & 63u));
+            if (staged_rows) pw[q] = stage[(min(tq[q] >> 5, kPresStageWords - 1u)) * 64u + (uint32_t)lane];
             // (slots a register does not have -- 32-column tiles: 2 per register -- address outside the resource: no request, bit 0;
             //  gfx950 treats voffset + soffset >= num_records as out of range: scripts/buffer_range_probe.hip)
-            pw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pres_rs, (int)fvo, (int)((uint32_t)q < Q ? (tq[q] >> 5) * 4u : pres_all), 0);
+            else pw[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pres_rs, (int)fvo, (int)((uint32_t)q < Q ? (tq[q] >> 5) * 4u : pres_all), 0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pm |= ((pw[q] >> (tq[q] & 31u)) & 1u) << (r * 4 + q);
+        for (int q = 0; q < 4; ++q) pm |= ((uint32_t)q < Q ? ((pw[q] >> (tq[q] & 31u)) & 1u) : 0u) << (r * 4 + q);
     }
+    if (staged_rows) wave_sync_lds();                                  // (the stage is rewritten by the next chunk)
     return pm;
 }
 
@@ -157,7 +169,7 @@ uint32_t k1q_presence_mask(__amdgpu_buffer_rsrc_t pres_rs, uint32_t pres_all, ui
 // requested, a third to a half of them empty); the staged default does not pay its registers (4.15 vs 4.49 ms on Amazon-670K)
 template <int NS, int PPC, bool DENSEX, bool BIASF, bool PRES, bool BIGW>
 __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesDev& X, uint64_t xrow, uint32_t cnt_in,
-                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane, float wmax, uint32_t& fbm) {
+                                               uint32_t* s_bidx, float* s_bval, uint2* sc, int lane, float wmax, uint32_t& fbm, uint32_t* pstage) {
     // ---- prolongate: which (parent, dense tile, column) does each of this lane's candidates stand for
     const uint32_t gl = Ly.d_gp_log2, gmask = (1u << gl) - 1u, TT = Ly.d_max_tiles;
     const uint32_t cnt = Ly.implicit_root ? 1u : min(cnt_in, Ly.beam_in);
@@ -280,8 +292,8 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
             const uint32_t ib = (!DENSEX && (uint32_t)lane < nc) ? fsrc[t0 + (uint32_t)lane] : 0u;
             const bool nonfinite = __ballot(vb >= 0x7F800000u || ib > w_rows) != 0ull;
             if (pmask_ok && !nonfinite)   // (ib <= w_rows here; lanes past the chunk's end hold feature 0: their masks are never applied to a weight that counts)
-                pm = k1q_presence_mask(pres_rs, (w_rows + 1u) * pres_bytes, ib * pres_bytes, woff[RB] >> dt_shift, woff[RB + (NR > 1 ? 1 : 0)] >> dt_shift,
-                                       woff[RB + (NR > 2 ? 2 : 0)] >> dt_shift, gl, NR < 3 ? NR : 3);
+                pm = k1q_presence_mask(pres_rs, (w_rows + 1u) * pres_bytes, Ly.pres_words, ib * pres_bytes, woff[RB] >> dt_shift, woff[RB + (NR > 1 ? 1 : 0)] >> dt_shift,
+                                       woff[RB + (NR > 2 ? 2 : 0)] >> dt_shift, gl, NR < 3 ? NR : 3, pstage, lane);
             for (uint32_t t = t0; t < t0 + nc; t += (uint32_t)UU) {
                 uint32_t fs[UU]; float xs[UU];
                 if (!nonfinite && t + (uint32_t)UU <= t0 + nc) {             // a full batch: plain uniform loads
@@ -510,6 +522,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NSMAX
     __shared__ uint2 sc_all[4 * 64];
     __shared__ uint32_t bidx_all[4 * 64];
     __shared__ float bval_all[4 * 64];
+    __shared__ uint32_t pstage_all[PRES ? 4 * kPresStageWords * 64 : 1];   // presence rows of the current chunk, word-major, per wavefront (k1q_presence_mask)
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform: scalar control flow below
     uint32_t q = blockIdx.x * 4u + wave;
@@ -523,6 +536,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NSMAX
     if (q >= a.nrows) return;
     uint2* sc = sc_all + wave * 64u;
     uint32_t* s_bidx = bidx_all + wave * 64u; float* s_bval = bval_all + wave * 64u;
+    uint32_t* pstage = pstage_all + (PRES ? wave * (kPresStageWords * 64u) : 0u);
 
     // incoming beam -> LDS (k <= 64 entries); the implicit root needs none
     uint32_t cnt = 1;
@@ -539,14 +553,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NSMAX
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;
         // every layer runs the body compiled for ITS register count (a narrower layer does not pay for the widest one's loads)
-        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
-        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm);
+        if (ns <= 1) cnt = k1q_layer<1, PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm, pstage);
+        else if (NSMAX >= 2 && ns <= 2) cnt = k1q_layer<(NSMAX >= 2 ? 2 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm, pstage);
+        else if (NSMAX >= 3 && ns <= 3) cnt = k1q_layer<(NSMAX >= 3 ? 3 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm, pstage);
+        else if (NSMAX >= 4 && ns <= 4) cnt = k1q_layer<(NSMAX >= 4 ? 4 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm, pstage);
+        else if (NSMAX >= 6 && ns <= 6) cnt = k1q_layer<(NSMAX >= 6 ? 6 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm, pstage);
+        else if (NSMAX >= 8 && ns <= 8) cnt = k1q_layer<(NSMAX >= 8 ? 8 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm, pstage);
+        else if (NSMAX >= 12 && ns <= 12) cnt = k1q_layer<(NSMAX >= 12 ? 12 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm, pstage);
+        else cnt = k1q_layer<(NSMAX >= 16 ? 16 : 1), PPC, DENSEX, BIASF, PRES, BIGW>(Ly, a.X, xrow, cnt, s_bidx, s_bval, sc, lane, a.prune_wmax, fbm, pstage);
     }
     if ((uint32_t)lane < cnt) {
         const size_t o = (size_t)q * a.out_stride + (uint32_t)lane;
