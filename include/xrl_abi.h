@@ -308,8 +308,8 @@ uint64_t xrl_debug_layout_rows(const uint32_t* rptr, uint32_t nrows, int align, 
  *   "sort_rest"           1 (default): the second phase of a bound-pruned tile-format layer runs on tile-sorted items (counting sort of the
  *                         compacted list by tile: the items of a tile run back to back on one XCD and share its lookup words and entries in
  *                         that XCD's L2); 0: in query order
- *   "sort_rest_min"       32768 (default): ... and only while the later stages of the handle's previous predicts held at least this many items (the
- *                         pruning feedback's count): on small row batches the sort's four launches cost more than they buy; 0: always sort
+ *   "sort_rest_min"       32768 (default): ... and only while the later stages of the handle's previous predicts held at least max(this many, 32 per tile
+ *                         of the layer) items (the pruning feedback's count): below that the sort's four launches cost more than the locality buys; 0: always sort
  *   "qsort"               1 (default): K1Q, sparse X -- the LAST layer of a run of dense-format layers is launched on its own, on queries counting-sorted
  *                         by the best parent of their beam, every XCD taking a contiguous eighth of the sorted order (queries of one region of the
  *                         tree share (feature, parent) segments in that XCD's L2), when the layer has >= "qsort_min_parents" (64) parents and the
