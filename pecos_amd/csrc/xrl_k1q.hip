@@ -15,9 +15,9 @@ uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k, bool dense_x)
     return ns <= 16 ? (uint32_t)std::max<uint64_t>(1, ns) : 0u;
 }
 
-static bool k1q_fuse01_enabled() {   // XRL_K1Q_FUSE01=0: levels 0 and 1 take separate feature walks (A/B, tests)
+static int k1q_fuse01_enabled() {   // XRL_K1Q_FUSE01=0: levels 0 and 1 take separate feature walks; 1: one walk, a load per level; default 2: one walk, ONE load (merged rows) (A/B, tests)
     const char* e = std::getenv("XRL_K1Q_FUSE01");
-    return !(e && e[0] == '0');
+    return (e && e[0] == '0') ? 0 : (e && e[0] == '1') ? 1 : 2;
 }
 static uint32_t k1q_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 2 ? 2 : ns <= 3 ? 3 : ns <= 4 ? 4 : ns <= 6 ? 6 : ns <= 8 ? 8 : ns <= 12 ? 12 : 16; }
 static uint32_t k1q_kernel_bucket(uint32_t ns) { return ns <= 1 ? 1 : ns <= 3 ? 3 : ns <= 6 ? 6 : 16; }   // kernels are compiled for these maxima
@@ -53,7 +53,10 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
     if (n >= 2 && !X.dense && Ps[0].implicit_root && Ps[0].first_layer && Ls[0]->n_parents == 1 && Ls[0]->d_max_tiles == 1 && Ps[0].tune.ablate == 0) {
         const uint32_t K0 = Ls[0]->n_children;
         const uint64_t c1 = ((uint64_t)K0 * Ls[1]->d_max_tiles) << Ls[1]->d_gp_log2;
-        if (K0 >= 1 && K0 <= 64 && K0 <= Ps[0].k && Ps[1].beam_in >= K0 && c1 <= 64 && Ls[0]->w_rows == Ls[1]->w_rows && a.layer[0].ns == 1 && a.layer[1].ns == 1 && Ps[1].k <= 64) a.fuse01 = k1q_fuse01_enabled() ? 1 : 0;
+        if (K0 >= 1 && K0 <= 64 && K0 <= Ps[0].k && Ps[1].beam_in >= K0 && c1 <= 64 && Ls[0]->w_rows == Ls[1]->w_rows && a.layer[0].ns == 1 && a.layer[1].ns == 1 && Ps[1].k <= 64) a.fuse01 = k1q_fuse01_enabled();
+        // one load per feature for both levels when the model carries their merged matrix (finalize_model) and the candidate layout is the one it was built for
+        if (a.fuse01 == 2 && !(Ls[0]->wd01 && Ls[0]->wd01_c1 == c1 && c1 + K0 <= 64)) a.fuse01 = 1;
+        a.wd01 = Ls[0]->wd01; a.wd01_c1 = Ls[0]->wd01_c1;
     }
     a.p_idx = prev.idx; a.p_val = prev.val; a.p_cnt = prev.cnt; a.p_stride = prev.stride;
     a.out_idx = out_idx; a.out_val = out_val; a.out_cnt = out_cnt; a.out_stride = out_stride;
@@ -127,6 +130,22 @@ densify_kernel(const uint64_t* __restrict__ col_ptr, const uint32_t* __restrict_
     const uint64_t e0 = col_ptr[oc], e1 = col_ptr[oc + 1];
     // (an explicit -0.0 would read as "no entry": stored as +0.0 -- x * (+-0.0) leaves an accumulator unchanged either way)
     for (uint64_t e = e0 + (threadIdx.x & 63u); e < e1; e += 64u) { const uint32_t b = __float_as_uint(val[e]); wd[(uint64_t)row_idx[e] * ld + off] = b == kMissing ? 0u : b; }
+}
+
+// levels 0 and 1 side by side: out[row][c] = wd1[row][c] (c < c1), out[row][c1 + j] = wd0[row][j] (j < k0), kMissing elsewhere; 64 columns per row
+__global__ void __launch_bounds__(256)
+merge01_kernel(const uint32_t* __restrict__ wd0, uint64_t ld0, uint32_t k0, const uint32_t* __restrict__ wd1, uint64_t ld1, uint32_t c1, uint32_t rows, uint32_t* __restrict__ out) {
+    const uint32_t f = blockIdx.x * 4u + (threadIdx.x >> 6), c = threadIdx.x & 63u;
+    if (f >= rows) return;
+    uint32_t v = kMissing;
+    if (c < c1) v = wd1[(uint64_t)f * ld1 + c];
+    else if (c - c1 < k0) v = wd0[(uint64_t)f * ld0 + (c - c1)];
+    out[(uint64_t)f * 64u + c] = v;
+}
+void launch_merge01(const uint32_t* wd0, uint64_t ld0, uint32_t k0, const uint32_t* wd1, uint64_t ld1, uint32_t c1, uint32_t rows, uint32_t* out, hipStream_t s) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(merge01_kernel, dim3((rows + 3u) / 4u), dim3(256), 0, s, wd0, ld0, k0, wd1, ld1, c1, rows, out);
+    XRL_LAUNCH_CHECK();
 }
 
 void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,

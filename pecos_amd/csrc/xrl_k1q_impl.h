@@ -62,7 +62,8 @@ constexpr int kK1QMaxLayers = 8;
 struct K1QArgs {
     K1QLayer layer[kK1QMaxLayers];
     int n_layers;                     // consecutive dense-format layers run back to back by the same wavefront: the beam stays in LDS
-    int fuse01;                       // layers 0 and 1 share one walk over the query's features (k1q_layer01)
+    int fuse01;                       // layers 0 and 1 share one walk over the query's features: 1 = k1q_layer01 (a load per level), 2 = k1q_layer01m (merged rows: one load)
+    const uint32_t* wd01; uint32_t wd01_c1;   // LayerDev::wd01 of the root layer
     QueriesDev X;
     const uint32_t* p_idx; const float* p_val; const uint32_t* p_cnt; uint32_t p_stride;
     uint32_t* out_idx; float* out_val; uint32_t* out_cnt; uint32_t out_stride;
@@ -509,6 +510,110 @@ __device__ __forceinline__ uint32_t k1q_layer01(const K1QLayer& L0, const K1QLay
     return kk;
 }
 
+
+// The same with ONE load per feature: the root layer carries both levels' dense rows side by side (LayerDev::wd01: 64 columns per feature,
+// level 1's row at its own offsets in [0, c1), level 0's K0 columns behind it), lanes [0, c1) hold the level-1 candidates and lanes
+// [c1, c1 + K0) the level-0 columns -- one accumulator, one transform pass when the two levels share their post-processor.  Half the loads,
+// multiplies and adds of k1q_layer01, one fp64 transform instead of two.
+template <int PPC, bool BIASF>
+__device__ __forceinline__ uint32_t k1q_layer01m(const K1QLayer& L0, const K1QLayer& L1, const uint32_t* __restrict__ wd01, uint32_t c1, const QueriesDev& X, uint64_t xrow,
+                                                  uint32_t* s_bidx, float* s_bval, uint2* sc, int lane) {
+    constexpr int UU = 16;
+    const uint32_t K0 = L0.d_tcol[1] - L0.d_tcol[0];
+    // ---- level 0: lane c1 + c <-> child c of the root
+    const uint32_t l0 = (uint32_t)lane - c1;
+    const bool v0 = l0 < K0;
+    const uint32_t child0 = v0 ? L0.d_tcol[0] + l0 : 0u;
+    const uint32_t orig0 = v0 ? (L0.perm_inv ? L0.perm_inv[child0] : child0) : 0xFFFFFFFFu;
+    // ---- level 1: candidate u = lane < c1 of the parents taken in COLUMN order (virtual beam slot j = level-0 column j)
+    const uint32_t gl = L1.d_gp_log2, gmask = (1u << gl) - 1u, TT = L1.d_max_tiles;
+    const uint32_t slot = (uint32_t)lane >> gl, col = (uint32_t)lane & gmask;
+    const uint32_t j = TT == 1u ? slot : slot / TT, tt = TT == 1u ? 0u : slot - j * TT;
+    bool v1 = (uint32_t)lane < c1 && j < K0;
+    uint32_t parent = (uint32_t)__shfl((int)orig0, (int)(c1 + (v1 ? j : 0u)), 64);
+    v1 = v1 && parent < L1.n_parents;
+    if (!v1) parent = 0;
+    const uint32_t dt = L1.d_ptile[parent] + tt;
+    v1 = v1 && dt < L1.d_ptile[parent + 1];
+    const uint32_t dtc = v1 ? dt : 0u;
+    const uint32_t cb = L1.d_tcol[dtc], ce = L1.d_tcol[dtc + 1];
+    v1 = v1 && col < ce - cb;
+    const uint32_t child1 = v1 ? cb + col : 0u;
+    // this lane's column of the merged row; lanes that hold neither a level-1 candidate nor a level-0 column address outside the resource (no request)
+    const uint32_t woff = v1 ? ((dtc << gl) + col) * 4u : v0 ? (c1 + l0) * 4u : 0xFFFFFFF0u;
+    const float bp1 = (v1 && L1.has_bias) ? L1.bias_prod[child1] : 0.0f, bp0 = (v0 && L0.has_bias) ? L0.bias_prod[child0] : 0.0f;
+    const float bp = v1 ? bp1 : bp0;
+    float acc = BIASF ? bp : 0.0f;
+
+    const uint32_t wr = L0.w_rows;                                      // == L1.w_rows
+    const uint64_t xb = X.row_ptr[xrow];
+    const uint32_t xl = (uint32_t)(X.row_ptr[xrow + 1] - xb);
+    const uint32_t* __restrict__ xi = X.col_idx + xb;
+    const float* __restrict__ xv = X.val + xb;
+    // One 64-feature chunk at a time in the lanes (lane t holds feature t0 + t); a batch takes its UU (feature id, value) pairs by v_readlane at
+    // the point of use -- no scalar loads, no register arrays -- and slots past the row's end name the all-missing row with x = 0, so the last
+    // batch needs no path of its own.  A chunk with a non-finite x or an id beyond the layers' rows runs the exact loop (skips cells on the marker).
+    auto body = [&](auto exact_tag, uint32_t ib, uint32_t xr, uint32_t tl) {
+        constexpr bool EX = decltype(exact_tag)::value;
+        uint32_t w[UU];
+#pragma unroll
+        for (int u = 0; u < UU; ++u) w[u] = k1q_load_w<false>(wd01, 256u, wr + 1u, (uint32_t)__builtin_amdgcn_readlane((int)ib, (int)(tl + (uint32_t)u)), woff);
+#pragma unroll
+        for (int u = 0; u < UU; ++u) {
+            const float x = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)xr, (int)(tl + (uint32_t)u)));
+            const float sm = __fadd_rn(acc, __fmul_rn(x, __uint_as_float(w[u])));
+            acc = (EX && w[u] == kMissing) ? acc : sm;
+        }
+    };
+    for (uint32_t t0 = 0; t0 < xl; t0 += 64u) {
+        const uint32_t nc = min(64u, xl - t0);
+        const uint32_t xr = (uint32_t)lane < nc ? __float_as_uint(xv[t0 + (uint32_t)lane]) : 0u;
+        const uint32_t ir = (uint32_t)lane < nc ? xi[t0 + (uint32_t)lane] : wr;
+        const bool nonfinite = __ballot((xr & 0x7FFFFFFFu) >= 0x7F800000u || ir > wr) != 0ull;
+        const uint32_t ib = min(ir, wr);                                  // (features beyond the layers' rows: the all-missing row, like the reference's lookup finds nothing)
+        for (uint32_t tl = 0; tl < nc; tl += (uint32_t)UU) {
+            if (!nonfinite) body(std::false_type{}, ib, xr, tl);
+            else body(std::true_type{}, ib, xr, tl);
+        }
+    }
+    // ---- bias last, transform (one pass when both levels share the post-processor)
+    if (!BIASF) acc = __fadd_rn(acc, bp);      // (bp is +0.0 where the level has no bias or the column no bias entry: leaves the accumulator as it is, like the `if` of k1q_layer01 -- accumulators are never -0.0)
+    float sv;
+    if (L0.pp_kind == L1.pp_kind && L0.pp_p == L1.pp_p) sv = pp_transform<PPC>(L1.pp_kind, L1.pp_p, acc);
+    else { const float a1 = pp_transform<PPC>(L1.pp_kind, L1.pp_p, acc), a0 = pp_transform<PPC>(L0.pp_kind, L0.pp_p, acc); sv = v1 ? a1 : a0; }
+    // ---- level 0 (first layer: no combine): rank of every node in (value desc, position asc) order, on lanes [c1, c1 + K0)
+    const uint32_t k0key = v0 ? score_key(sv) : 0u;
+    uint32_t rank0 = 0;
+    for (uint32_t c = 0; c < K0; ++c) {
+        const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)k0key, (int)(c1 + c));
+        rank0 += (kc > k0key || (kc == k0key && c < l0)) ? 1u : 0u;
+    }
+    // ---- level 1: combine with the parent's score; candidate position = (rank of the parent, tile, column)
+    const uint32_t jsrc = c1 + (j < K0 ? j : 0u);
+    const float psv = __shfl(sv, (int)jsrc, 64);
+    float s1v = sv;
+    if (!L1.first_layer) s1v = pp_combine(L1.pp_kind, sv, psv);
+    const uint32_t prank = (uint32_t)__shfl((int)rank0, (int)jsrc, 64);
+    const uint32_t position = (((prank * TT) + tt) << gl) + col;       // < c1 <= 64: one candidate register
+    sc[lane] = make_uint2(0u, 0xFFFFFFFFu);
+    wave_sync_lds();
+    if (v1) sc[position] = make_uint2(__float_as_uint(s1v), child1);
+    wave_sync_lds();
+    const uint2 mine = sc[lane];
+    wave_sync_lds();
+    uint32_t key[1], sbits[1], payload[1];
+    sbits[0] = mine.x; payload[0] = mine.y;
+    key[0] = mine.y != 0xFFFFFFFFu ? score_key(__uint_as_float(mine.x)) : 0u;
+    uint32_t rank, sb, ch;
+    const uint32_t kk = wave_topk<1>(key, sbits, payload, L1.k, sc, lane, rank, sb, ch);
+    if ((uint32_t)lane < kk) {
+        s_bidx[rank] = L1.perm_inv ? L1.perm_inv[ch] : ch;
+        s_bval[rank] = __uint_as_float(sb);
+    }
+    wave_sync_lds();
+    return kk;
+}
+
 // MULTI = false: exactly one layer (layer[0]); the layer loop and its run-time descriptor indexing cost ~20 VGPRs, which the
 // single-layer launches (wide layers, k1q_fuse = 0) do not pay.
 // The fused kernel of narrow layers is compiled for 7 wavefronts per SIMD (72 VGPRs instead of the 74 the compiler settles on,
@@ -548,7 +653,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NSMAX
     const uint64_t xrow = (uint64_t)a.row0 + q;
     uint32_t fbm = 0u;                                                 // pruning feedback: bit l = layer l ran staged, bit 16 + l = its second pass was needed
     int l_first = 0;
-    if (MULTI && !DENSEX && a.fuse01) { cnt = k1q_layer01<PPC, BIASF, BIGW>(a.layer[0], a.layer[1], a.X, xrow, s_bidx, s_bval, sc, lane); l_first = 2; }
+    if (MULTI && !DENSEX && a.fuse01 == 2) { cnt = k1q_layer01m<PPC, BIASF>(a.layer[0], a.layer[1], a.wd01, a.wd01_c1, a.X, xrow, s_bidx, s_bval, sc, lane); l_first = 2; }
+    else if (MULTI && !DENSEX && a.fuse01) { cnt = k1q_layer01<PPC, BIASF, BIGW>(a.layer[0], a.layer[1], a.X, xrow, s_bidx, s_bval, sc, lane); l_first = 2; }
     for (int l = l_first; l < (MULTI ? a.n_layers : 1); ++l) {
         const K1QLayer& Ly = a.layer[l];
         const uint32_t ns = Ly.ns;

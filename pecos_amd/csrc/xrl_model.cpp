@@ -578,6 +578,22 @@ void finalize_model(Model& m) {
                  ") does not match the previous layer's label count (" + std::to_string(prev_out) + ")");
     }
     if (!m.stream) XRL_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+    // levels 0 and 1 in one 64-column dense matrix (LayerDev::wd01): K1Q's fused walk of the two levels then issues ONE load per feature
+    if (m.layers.size() >= 2) {
+        Layer& L0 = *m.layers[0]; const Layer& L1 = *m.layers[1];
+        const LayerDev& d0 = L0.dev; const LayerDev& d1 = L1.dev;
+        const char* e = std::getenv("XRL_K1Q_MERGE01");
+        if (!(e && e[0] == '0') && d0.wd && d1.wd && d0.n_parents == 1 && d0.d_max_tiles == 1 && d0.w_rows == d1.w_rows && d1.n_parents == d0.n_children) {
+            const uint64_t K0 = d0.n_children, c1 = (K0 * d1.d_max_tiles) << d1.d_gp_log2;
+            if (K0 >= 1 && c1 + K0 <= 64 && c1 <= d1.d_ld && K0 <= d0.d_ld) {
+                m.d_wd01.reserve(((size_t)d0.w_rows + 1) * 64 * 4);
+                launch_merge01(d0.wd, d0.d_ld, (uint32_t)K0, d1.wd, d1.d_ld, (uint32_t)c1, d0.w_rows + 1, m.d_wd01.as<uint32_t>(), nullptr);
+                XRL_HIP(hipStreamSynchronize(nullptr));
+                L0.dev.wd01 = m.d_wd01.as<uint32_t>(); L0.dev.wd01_c1 = (uint32_t)c1;
+                L0.device_bytes += m.d_wd01.cap;
+            }
+        }
+    }
 }
 
 std::unique_ptr<Model> load_model_from_disk(const std::string& path, int weight_matrix_type) {

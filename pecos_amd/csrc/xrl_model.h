@@ -92,6 +92,10 @@ struct LayerDev {
                                  //   kernel runs on the number of fabric requests (profiles/r04_hard_config.md)
     int d_full;                  // every (feature, kept child) cell of the dense matrix holds a weight (no kMissing): K1G's 2-op inner loop
     const uint32_t* tile_parent; // [n_tiles] parent of every tile-format tile (K1G walks tile-sorted items)
+    // ROOT layer only (finalize_model): levels 0 and 1 in ONE dense matrix of 64 columns per feature row -- columns [0, wd01_c1) are level 1's dense row
+    // (same offsets as in its own matrix), columns [wd01_c1, wd01_c1 + K0) level 0's -- so that K1Q's fused walk of the two levels issues one
+    // load per feature; nullptr when the two levels do not fit 64 columns
+    const uint32_t* wd01; uint32_t wd01_c1;
 };
 
 struct Layer {
@@ -191,6 +195,7 @@ struct Model {
                                             //   per layer (copied from fb_dev by the first wavefront of the next K1Q launch), [2*kFbLayers, 3*kFbLayers) the
                                             //   second stage's item count of tile-format layers (written by its K1 launch)
     DevBuf fb_dev;                          // K1Q's counters (device atomics)
+    DevBuf d_wd01;                          // levels 0 + 1 merged dense rows (LayerDev::wd01 of the root layer)
     uint32_t fb_seen[kFbLayers] = {0}, fb_second[kFbLayers] = {0};   // K1Q counters at the last decision
     uint64_t fb_tile_slots[kFbLayers] = {0};                          // second-stage slots the item count of a tile-format layer refers to
     uint32_t fb_unstaged_calls[kFbLayers] = {0};                      // predicts in a row a layer has run unstaged (re-probed every kFbReprobe)
@@ -238,6 +243,7 @@ void compile_mmap_model(const std::string& npz_path, const std::string& mmap_pat
 void ensure_device_csc(Layer& L);
 // xrl_k1q.hip: memset wd to kMissing and scatter the CSC columns src_col[c] to padded column dst_off[c]
 // xrl_k1q.hip: presence words of a dense-format layer (LayerDev::pres) from its matrix
+void launch_merge01(const uint32_t* wd0, uint64_t ld0, uint32_t k0, const uint32_t* wd1, uint64_t ld1, uint32_t c1, uint32_t rows, uint32_t* out, hipStream_t s);
 void launch_presence(const uint32_t* wd, uint64_t ld, uint32_t rows, uint32_t gp_log2, uint32_t n_tiles, uint32_t pres_words, uint32_t* pres, hipStream_t s);
 void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,
                     const uint32_t* dst_off, uint32_t n_children, uint32_t w_rows, uint64_t ld, uint32_t* wd, hipStream_t s);   // upload W as CSC (original column ids) if not there yet

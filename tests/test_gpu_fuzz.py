@@ -109,7 +109,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         qs = int(rng.choice([0, 1, 1]))
         clib.set_option(m.model.model_chain, "qsort", qs)
         clib.set_option(m.model.model_chain, "qsort_min_rows", 1); clib.set_option(m.model.model_chain, "qsort_min_parents", 2)
-        os.environ["XRL_K1Q_FUSE01"] = str(int(rng.choice([0, 1, 1])))                          # levels 0 + 1 in one feature walk (K1Q) / separately
+        os.environ["XRL_K1Q_FUSE01"] = str(int(rng.choice([0, 1, 2])))                          # levels 0 + 1 separately / in one feature walk, a load per level / one load (merged rows)
         clib.set_option(m.model.model_chain, "prune", int(rng.choice([0, 1, 1])))                  # exact bound pruning on / off: same bits
         # one or two row batches in flight (two streams), whole or ragged batches
         clib.set_option(m.model.model_chain, "overlap_min_rows", int(rng.choice([0, 2])))

@@ -122,7 +122,9 @@ def test_scaled_configs_vs_oracle(name, scale, XLM, clib, oracle_mod, tmp_path):
     for kw in (dict(beam_size=cfg["beam"], only_topk=10), dict(beam_size=64, only_topk=64, post_processor="log-l3-hinge"), dict(beam_size=2, only_topk=5, post_processor="sigmoid")):
         os.environ["XRL_K1Q_FUSE01"] = "0"
         a0 = m.predict(X, **kw)
-        os.environ.pop("XRL_K1Q_FUSE01")
+        os.environ["XRL_K1Q_FUSE01"] = "1"                       # one walk, a load per level
+        assert_same_topk(m.predict(X, **kw), a0, exact_scores=True, what=f"{name} levels 0+1 fused (two loads) vs separate {kw}")
+        os.environ.pop("XRL_K1Q_FUSE01")                         # default: one walk, ONE load per feature (merged rows) where the model carries them
         assert_same_topk(m.predict(X, **kw), a0, exact_scores=True, what=f"{name} levels 0+1 fused vs separate {kw}")
         assert_same_topk(a0, ref.predict(X, **kw), exact_scores=EXACT_PP(kw.get("post_processor")), what=f"{name} separate walks vs reference {kw}")
     # exact bound pruning off / on (default on): the same bits on every kernel family, and the profile shows both phases of a pruned layer
