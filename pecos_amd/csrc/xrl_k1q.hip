@@ -44,6 +44,7 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
         y.beam_in = P.beam_in; y.k = P.k; y.ns = k1q_bucket(ns);
         y.has_bias = L.has_bias; y.pp_kind = P.pp.kind; y.pp_p = P.pp.p; y.first_layer = P.first_layer; y.implicit_root = P.implicit_root; y.bias_first = P.bias_first; y.prune = P.prune;
         y.layer_id = (P.layer >= 0 && P.layer < 16) ? P.layer : 0;
+        y.regular = L.d_regular;
         nsmax = std::max(nsmax, y.ns); ppc |= pp_class(P.pp);
     }
     a.n_layers = n; a.X = X;

@@ -56,6 +56,7 @@ struct K1QLayer {
     int prune;                        // exact bound pruning: score the first candidate register before requesting the others' weights
     int bias_first;                   // sparse X, HASH_CHUNKED arithmetic (inference.hpp:705-735): bias before the features, like dense X
     int layer_id;                     // index in the chain: the layer's slot in the pruning feedback counters
+    int regular;                      // LayerDev::d_regular: dense tile = parent, first child = parent << d_gp_log2 (no d_ptile / d_tcol lookups)
 };
 constexpr int kK1QMaxLayers = 8;
 
@@ -186,11 +187,16 @@ __device__ __forceinline__ uint32_t k1q_layer(const K1QLayer& Ly, const QueriesD
         if (!Ly.implicit_root) { parent = s_bidx[v ? j : 0u]; pscore = s_bval[v ? j : 0u]; }
         v = v && parent < Ly.n_parents;
         if (!v) parent = 0;
-        const uint32_t dt = Ly.d_ptile[parent] + tt;
-        v = v && dt < Ly.d_ptile[parent + 1];
-        const uint32_t dtc = v ? dt : 0u;
-        const uint32_t cb = Ly.d_tcol[dtc], ce = Ly.d_tcol[dtc + 1];
-        v = v && col < ce - cb;
+        uint32_t dtc, cb;
+        if (Ly.regular) { dtc = parent; cb = parent << gl; }            // one full tile per parent: nothing to look up (and no dependent round trips before the first weight load)
+        else {
+            const uint32_t dt = Ly.d_ptile[parent] + tt;
+            v = v && dt < Ly.d_ptile[parent + 1];
+            dtc = v ? dt : 0u;
+            cb = Ly.d_tcol[dtc];
+            const uint32_t ce = Ly.d_tcol[dtc + 1];
+            v = v && col < ce - cb;
+        }
         woff[r] = v ? ((dtc << gl) + col) * 4u : 0u;                   // BYTE offset inside a feature row (d_ld < 2^30)
         child[r] = v ? cb + col : 0u;
         ps[r] = pscore; valid[r] = v;
@@ -533,11 +539,16 @@ __device__ __forceinline__ uint32_t k1q_layer01m(const K1QLayer& L0, const K1QLa
     uint32_t parent = (uint32_t)__shfl((int)orig0, (int)(c1 + (v1 ? j : 0u)), 64);
     v1 = v1 && parent < L1.n_parents;
     if (!v1) parent = 0;
-    const uint32_t dt = L1.d_ptile[parent] + tt;
-    v1 = v1 && dt < L1.d_ptile[parent + 1];
-    const uint32_t dtc = v1 ? dt : 0u;
-    const uint32_t cb = L1.d_tcol[dtc], ce = L1.d_tcol[dtc + 1];
-    v1 = v1 && col < ce - cb;
+    uint32_t dtc, cb;
+    if (L1.regular) { dtc = parent; cb = parent << gl; }
+    else {
+        const uint32_t dt = L1.d_ptile[parent] + tt;
+        v1 = v1 && dt < L1.d_ptile[parent + 1];
+        dtc = v1 ? dt : 0u;
+        cb = L1.d_tcol[dtc];
+        const uint32_t ce = L1.d_tcol[dtc + 1];
+        v1 = v1 && col < ce - cb;
+    }
     const uint32_t child1 = v1 ? cb + col : 0u;
     // this lane's column of the merged row; lanes that hold neither a level-1 candidate nor a level-0 column address outside the resource (no request)
     const uint32_t woff = v1 ? ((dtc << gl) + col) * 4u : v0 ? (c1 + l0) * 4u : 0xFFFFFFF0u;

@@ -546,6 +546,13 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
         d.d_sparse_ok = (wp <= 32 || per_segment >= 1.0) ? 1 : 0;
     }
     d.pres = pres_words ? L->d_pres.as<uint32_t>() : nullptr; d.pres_words = pres_words;
+    d.d_regular = 0;
+    if (L->dense_bytes && d_max_tiles == 1 && d_ptile.size() == (size_t)P + 1 && d_tcol.size() >= (size_t)P + 1) {
+        bool reg = true;
+        for (uint32_t p2 = 0; reg && p2 <= P; ++p2) reg = d_ptile[p2] == p2 && (p2 == P || d_tcol[p2] == (p2 << d_gp_log2));
+        reg = reg && (uint64_t)c_nnz == ((uint64_t)P << d_gp_log2);
+        d.d_regular = reg ? 1 : 0;
+    }
     d.d_full = d_full ? 1 : 0; d.tile_parent = L->dense_bytes ? L->d_tile_parent.as<uint32_t>() : nullptr;
     return L;
 }

@@ -96,6 +96,8 @@ struct LayerDev {
     // (same offsets as in its own matrix), columns [wd01_c1, wd01_c1 + K0) level 0's -- so that K1Q's fused walk of the two levels issues one
     // load per feature; nullptr when the two levels do not fit 64 columns
     const uint32_t* wd01; uint32_t wd01_c1;
+    int d_regular;               // every parent owns exactly ONE dense tile and every tile is full (2^d_gp_log2 children): dense tile = parent, first child = parent << d_gp_log2
+                                 // -- K1Q's prolongation then needs neither d_ptile nor d_tcol (two dependent loads per candidate register); balanced trees are like this
 };
 
 struct Layer {
