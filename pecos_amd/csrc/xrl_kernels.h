@@ -23,7 +23,7 @@ struct BeamDev {
     uint32_t stride;
 };
 
-struct K1Tune { int wpb = 1, lds_pad = 0, ablate = 0, k1g_variant = 0, pres_mode = 1; };   // per-model tuning / debug knobs (xrl_set_option k1_wpb, k1_lds_pad, k1_ablate, k1g_variant)
+struct K1Tune { int wpb = 1, lds_pad = 0, ablate = 0, k1g_variant = 0, pres_mode = 1, tile_rows = 1; };   // per-model tuning / debug knobs (xrl_set_option k1_wpb, k1_lds_pad, k1_ablate, k1g_variant)
 
 struct LayerPlan {
     uint32_t row0, nrows;       // query rows [row0, row0+nrows) of the query matrix
@@ -106,6 +106,9 @@ void launch_tfidf_weight(const uint64_t* row_ptr, const uint32_t* col_idx, const
                          int binary, int sublinear_tf, int norm_p, float* out, hipStream_t s,
                          uint32_t seg_stride = 1, uint32_t seg_off = 0, uint32_t* err = nullptr);   // rows = segments of row_ptr; *err = 1 on a column id >= cols
 int k1_auto_group(const LayerDev& L, const Layer& host, int dense);
+// K1T (xrl_k1t.hip): K1 on the densely held tile rows (LayerDev::wt), accumulators in registers; launch_k1 routes to it when k1t_serves
+bool k1t_serves(const LayerDev& L, const QueriesDev& X);
+void launch_k1t(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, const uint32_t* n_items, float* cand, hipStream_t s);
 // K1Q (xrl_k1q.hip): a whole layer -- prolongate, chunk products against the DENSE row format, post-processor,
 // combine, top-k, child re-ordering -- in one query-stationary kernel: previous beam in, next beam out.
 uint32_t k1q_regs(const LayerDev& L, uint32_t beam_in, uint32_t k, bool dense_x);   // 0: the layer / beam / k cannot (or should not) be served by K1Q

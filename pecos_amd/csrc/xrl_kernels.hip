@@ -694,6 +694,10 @@ int k1_auto_group(const LayerDev& L, const Layer& host, int dense) {
 void launch_k1(const LayerDev& L, const LayerPlan& P, const QueriesDev& X, const void* items, const uint32_t* n_items,
                float* cand, int group, hipStream_t s) {
     if (P.nrows == 0) return;
+    // K1T (densely held tile rows, accumulators in registers): measured faster on items in QUERY order (a bound-pruned layer's first stage: Amazon-670K
+    // 1.010 -> 0.959 ms, Wiki10-31K 0.334 -> 0.286 ms) and slower on tile-sorted lists (Amazon-670K-hard 7.29 -> 8.48 ms: both kernels run at the L1-miss
+    // request ceiling of ~80 G requests/s and a 384-byte dense row is 6 requests against ~4 for its entry list) -- tile_rows 1 = query-order launches only, 2 = all
+    if ((P.tune.tile_rows >= 2 || (P.tune.tile_rows == 1 && !n_items)) && P.tune.ablate == 0 && k1t_serves(L, X)) { launch_k1t(L, P, X, items, n_items, cand, s); return; }
     K1Args a;
     a.L = L; a.X = X; a.items = static_cast<const ItemDesc*>(items); a.n_items = n_items; a.cand = cand;
     a.n_slots = (uint64_t)P.nrows * P.beam_in * L.max_tiles_per_parent;

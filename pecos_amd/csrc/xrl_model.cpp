@@ -554,6 +554,41 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
         d.d_regular = reg ? 1 : 0;
     }
     d.d_full = d_full ? 1 : 0; d.tile_parent = L->dense_bytes ? L->d_tile_parent.as<uint32_t>() : nullptr;
+    // ---- TILE ROWS held densely (K1T, xrl_k1t.hip): built on the device from the tile format just uploaded.  Needs one cell per (row, column)
+    //      (no duplicate row ids inside a weight column), a rank-bitmap lookup (the slots it returns index the rows) and room:
+    //      (rows + tiles) x stride x 4 bytes, at most a quarter of the free HBM / XRL_TILE_ROWS_MAX_MB (default 64 GiB).  XRL_TILE_ROWS=0 disables it.
+    d.wt = nullptr; d.wt_base = nullptr; d.wt_stride = 0; d.wt_bytes = 0;
+    {
+        const char* te = std::getenv("XRL_TILE_ROWS");
+        bool want = !(te && te[0] == '0') && !structure_only && !use_bucket && T > 0 && nnz > 0 && L->max_tile_cols <= kMaxTileCols;
+        for (uint32_t c = 0; want && c < W.cols; ++c)
+            for (uint64_t e = W.col_ptr[c] + 1; e < W.col_ptr[c + 1]; ++e)
+                if (W.row_idx[e] <= W.row_idx[e - 1]) { want = false; break; }
+        int g = 0, nr = 0;
+        k1t_shape(L->max_tile_cols, g, nr);
+        const uint64_t stride = (uint64_t)g * nr;
+        const uint64_t floats = (total_rows + T) * stride;
+        if (want) {
+            uint64_t cap_b = 64ull << 30;
+            if (const char* mb = std::getenv("XRL_TILE_ROWS_MAX_MB")) cap_b = std::strtoull(mb, nullptr, 10) << 20;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_b = std::min<uint64_t>(cap_b, free_b / 4);
+            uint32_t max_rows = 0;
+            for (uint32_t t = 0; t < T; ++t) max_rows = std::max(max_rows, tiles[t].nrows);
+            if (nr > 4 || floats * 4 > cap_b || ((uint64_t)max_rows + 1) * stride * 4 >= (1ull << 32)) want = false;   // (a row's byte offset inside its tile is 32 bits)
+        }
+        if (want) {
+            std::vector<uint64_t> base(T);
+            for (uint32_t t = 0; t < T; ++t) base[t] = (tiles[t].rowptr_base + t) * stride;
+            L->d_wt_base.upload(base);
+            L->d_wt.reserve(floats * 4 + 64);
+            d.wt_base = L->d_wt_base.as<uint64_t>(); d.wt_stride = (uint32_t)stride;
+            launch_tile_rows(d, floats + 16, L->d_wt.as<uint32_t>(), nullptr);
+            XRL_HIP(hipStreamSynchronize(nullptr));
+            d.wt = L->d_wt.as<float>(); d.wt_bytes = floats * 4 + 64;
+            L->device_bytes += L->d_wt.cap + L->d_wt_base.cap;
+        }
+    }
     return L;
 }
 

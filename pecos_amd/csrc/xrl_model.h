@@ -96,6 +96,10 @@ struct LayerDev {
     // (same offsets as in its own matrix), columns [wd01_c1, wd01_c1 + K0) level 0's -- so that K1Q's fused walk of the two levels issues one
     // load per feature; nullptr when the two levels do not fit 64 columns
     const uint32_t* wd01; uint32_t wd01_c1;
+    // TILE ROWS held densely (K1T, xrl_k1t.hip), nullptr when not built: tile t's rows (every feature with a weight in the tile, ascending: the
+    // slots the rank-bitmaps return) are wt_stride floats each, column c of the tile at position c, kMissing where W has no entry, followed by
+    // one all-missing pad row; they start at float index wt_base[t].  wt_stride = G * NR of k1t_shape(max_tile_cols).
+    const float* wt; const uint64_t* wt_base; uint32_t wt_stride; uint64_t wt_bytes;
     int d_regular;               // every parent owns exactly ONE dense tile and every tile is full (2^d_gp_log2 children): dense tile = parent, first child = parent << d_gp_log2
                                  // -- K1Q's prolongation then needs neither d_ptile nor d_tcol (two dependent loads per candidate register); balanced trees are like this
 };
@@ -123,6 +127,7 @@ struct Layer {
     DevBuf d_tiles, d_ptile, d_chunk_col, d_bitmap, d_row_ptr, d_row_idx, d_entries, d_perm_inv, d_chunk_alg, d_bias_prod;
     DevBuf d_bucket, d_bitmap64;
     DevBuf d_wd, d_dptile, d_dtcol, d_tile_parent, d_pres;   // dense row format (see LayerDev::wd)
+    DevBuf d_wt, d_wt_base;                                   // tile rows held densely (see LayerDev::wt)
     uint64_t dense_bytes = 0;
     uint32_t bk_shift = 0, bk_n = 0, bk_levels = 0;
     LayerDev dev{};
@@ -185,6 +190,7 @@ struct Model {
                                             // K0/K2 run under the other half's K1; 0 = never (measured on Amazon-670K: 25.9 vs 25.5 ms, no gain)
     int prune = 1;                          // exact bound pruning (xrl_predict.cpp): 1 = a layer first scores the children of the best beam parent(s) only and
                                             // skips the rest for every query whose k-th best already reaches the next parent's score; 0 = score every candidate
+    int tile_rows = 1;                      // tile-format layers that carry densely held tile rows (LayerDev::wt), sparse X: 1 = launches on items in query order run K1T (xrl_k1t.hip), 2 = every launch, 0 = always the entry-list kernel K1
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
     int k1q_fuse = 3;                       // consecutive dense-format layers of <= this many candidate registers (1..3) share one K1Q launch (the beam stays in LDS); 0: one launch per layer
@@ -202,6 +208,7 @@ struct Model {
     uint64_t fb_tile_slots[kFbLayers] = {0};                          // second-stage slots the item count of a tile-format layer refers to
     uint32_t fb_unstaged_calls[kFbLayers] = {0};                      // predicts in a row a layer has run unstaged (re-probed every kFbReprobe)
     uint8_t fb_unstaged[kFbLayers] = {0};
+    uint8_t fb_probing[kFbLayers] = {0};                              // an unstaged layer was staged ONCE (the probe) and its outcome has not arrived yet: it keeps running unstaged meanwhile
     int adaptive = 1;                       // 0: always stage (xrl_set_option "adaptive")
     int presence = 1;                       // K1Q, sparse X: 1 = layers that run UNSTAGED (prune off, or switched by the pruning feedback) request a (feature, parent) weight
                                             // segment only when the layer's presence word says it holds a weight; 2 = every layer that has presence words; 0 = never
@@ -245,6 +252,8 @@ void compile_mmap_model(const std::string& npz_path, const std::string& mmap_pat
 void ensure_device_csc(Layer& L);
 // xrl_k1q.hip: memset wd to kMissing and scatter the CSC columns src_col[c] to padded column dst_off[c]
 // xrl_k1q.hip: presence words of a dense-format layer (LayerDev::pres) from its matrix
+void k1t_shape(uint32_t max_tile_cols, int& g, int& nr);   // lanes per item / columns per lane of K1T for a layer's widest tile
+void launch_tile_rows(const LayerDev& L, uint64_t total_floats, uint32_t* wt, hipStream_t s);   // fills LayerDev::wt from the tile format on the device (xrl_k1t.hip)
 void launch_merge01(const uint32_t* wd0, uint64_t ld0, uint32_t k0, const uint32_t* wd1, uint64_t ld1, uint32_t c1, uint32_t rows, uint32_t* out, hipStream_t s);
 void launch_presence(const uint32_t* wd, uint64_t ld, uint32_t rows, uint32_t gp_log2, uint32_t n_tiles, uint32_t pres_words, uint32_t* pres, hipStream_t s);
 void launch_densify(const uint64_t* col_ptr, const uint32_t* row_idx, const float* val, const uint32_t* src_col,

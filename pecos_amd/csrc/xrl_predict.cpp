@@ -154,7 +154,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
     for (size_t l = 0; l < T; ++l) prune_wmax = std::max(prune_wmax, m.layers[l]->w_absmax);
     if (!(prune_wmax <= 3.0e38f)) prune_wmax = INFINITY;
     // ---- pruning feedback (Model::fb_*): which layers run UNSTAGED this time because their first stage settled (almost) no query the last times
-    bool unst[Model::kFbLayers] = {false};
+    bool unst[Model::kFbLayers] = {false}, probe_now[Model::kFbLayers] = {false};
     if (m.prune && m.adaptive) {
         constexpr uint32_t kFbReprobe = 32;                             // an unstaged layer is staged again every so many predicts: the data may have changed
         constexpr uint32_t kPending = 0xFFFFFFFFu;
@@ -168,23 +168,35 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
         for (size_t l = 0; l < T && l < (size_t)Model::kFbLayers; ++l) {
             if (!o.stats_out) {
                 if (m.fb_unstaged[l]) {
-                    if (++m.fb_unstaged_calls[l] >= kFbReprobe) {            // stage it once more and look again
-                        m.fb_unstaged[l] = 0; m.fb_unstaged_calls[l] = 0;
-                        m.fb_seen[l] = fh[2 * l]; m.fb_second[l] = fh[2 * l + 1]; fh[2 * Model::kFbLayers + l] = kPending; m.fb_tile_slots[l] = 0;
+                    // An unstaged layer is PROBED every kFbReprobe predicts: that one predict stages it, the following ones keep running
+                    // unstaged until the probe's counters arrive (a caller that queues predicts without synchronising is many predicts
+                    // ahead of the device: waiting for the outcome in the staged state would run all of them staged).
+                    bool decided = false, stage_again = false;
+                    if (m.fb_probing[l]) {
+                        const uint32_t seen = fh[2 * l], sec = fh[2 * l + 1], dseen = seen - m.fb_seen[l], dsec = sec - m.fb_second[l];
+                        const uint32_t cnt = fh[2 * Model::kFbLayers + l];
+                        if (dseen >= 256u) { decided = true; stage_again = !((double)dsec > 0.7 * (double)dseen); m.fb_seen[l] = seen; m.fb_second[l] = sec; }
+                        else if (cnt != kPending && m.fb_tile_slots[l] > 0) { decided = true; stage_again = !((double)cnt > 0.6 * (double)m.fb_tile_slots[l]); }
+                        if (decided) { m.fb_probing[l] = 0; m.fb_unstaged_calls[l] = 0; if (stage_again) m.fb_unstaged[l] = 0; }
+                    }
+                    if (m.fb_unstaged[l] && ++m.fb_unstaged_calls[l] >= kFbReprobe) {    // (an undecided probe -- a batch too small to sample 256 queries -- is repeated)
+                        m.fb_unstaged_calls[l] = 0; m.fb_probing[l] = 1; probe_now[l] = true;
+                        if (!decided) { m.fb_seen[l] = fh[2 * l]; m.fb_second[l] = fh[2 * l + 1]; }
+                        fh[2 * Model::kFbLayers + l] = kPending; m.fb_tile_slots[l] = 0;
                     }
                 } else {
                     // query-stationary layers: of the sampled queries that ran staged, how many needed the second pass
                     const uint32_t seen = fh[2 * l], sec = fh[2 * l + 1], dseen = seen - m.fb_seen[l], dsec = sec - m.fb_second[l];
                     if (dseen >= 256u) {
-                        if ((double)dsec > 0.7 * (double)dseen) { m.fb_unstaged[l] = 1; m.fb_unstaged_calls[l] = 0; }
+                        if ((double)dsec > 0.7 * (double)dseen) { m.fb_unstaged[l] = 1; m.fb_unstaged_calls[l] = 0; m.fb_probing[l] = 0; }
                         m.fb_seen[l] = seen; m.fb_second[l] = sec;
                     }
                     // tile-format layers: the item count of the last stage against the slots it was sized for
                     const uint32_t cnt = fh[2 * Model::kFbLayers + l];
-                    if (cnt != kPending && m.fb_tile_slots[l] > 0 && (double)cnt > 0.6 * (double)m.fb_tile_slots[l]) { m.fb_unstaged[l] = 1; m.fb_unstaged_calls[l] = 0; }
+                    if (cnt != kPending && m.fb_tile_slots[l] > 0 && (double)cnt > 0.6 * (double)m.fb_tile_slots[l]) { m.fb_unstaged[l] = 1; m.fb_unstaged_calls[l] = 0; m.fb_probing[l] = 0; }
                 }
             }
-            unst[l] = m.fb_unstaged[l] != 0;
+            unst[l] = m.fb_unstaged[l] != 0 && !probe_now[l];
         }
     }
 
@@ -226,7 +238,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             P.layer = (int)l;
             P.row0 = (uint32_t)row0; P.nrows = nrows; P.beam_in = beam_in[l]; P.k = k[l];
             P.cand_stride = cstride[l]; P.pp = pp[l];
-            P.tune.wpb = m.k1_wpb; P.tune.lds_pad = m.k1_lds_pad; P.tune.ablate = m.k1_ablate; P.tune.k1g_variant = m.k1g_variant; P.tune.pres_mode = m.presence;
+            P.tune.wpb = m.k1_wpb; P.tune.lds_pad = m.k1_lds_pad; P.tune.ablate = m.k1_ablate; P.tune.k1g_variant = m.k1g_variant; P.tune.pres_mode = m.presence; P.tune.tile_rows = m.tile_rows;
             P.first_layer = (l == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;   // no_prev_pred
             P.implicit_root = (l == 0 && !has_init) ? 1 : 0;
             P.bias_first = (m.weight_matrix_type == 1 && !X.dense) ? 1 : 0;
@@ -430,8 +442,9 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             const uint64_t n_slots = (uint64_t)nrows * beam_in[l] * L.max_tiles_per_parent;
             if (mode != 0) timed("k1_sort_items", (uint32_t)l, [&] { launch_sort_items(L.dev, n_slots, lw.items.p, lw.items_sorted.p, lw.sort_hist.as<uint32_t>(), lw.sort_start.as<uint32_t>(), S); });
             if (lanes == 2 && k1_done) XRL_HIP(hipStreamWaitEvent(S, k1_done, 0));   // K1 launches take turns across the lanes
+            LayerPlan PU = P; PU.fb_host = nullptr;   // (an unstaged pass's item count is not a feedback sample: a probe's outcome may be pending)
             timed(X.dense ? "k1_dense" : "k1_sparse", (uint32_t)l, [&] {
-                    launch_k1(L.dev, P, X, mode == 1 ? lw.items_sorted.p : lw.items.p, mode == 1 ? lw.sort_start.as<uint32_t>() + L.n_tiles : nullptr,
+                    launch_k1(L.dev, PU, X, mode == 1 ? lw.items_sorted.p : lw.items.p, mode == 1 ? lw.sort_start.as<uint32_t>() + L.n_tiles : nullptr,
                               lw.cand.as<float>(), g, S); });
             if (lanes == 2) { k1_done = next_event(); XRL_HIP(hipEventRecord(k1_done, S)); }
             timed("k2_topk", (uint32_t)l, [&] { launch_k2_topk(L.dev, P, prev, lw.cand_off.as<uint32_t>(), lw.ncand.as<uint32_t>(), lw.cand.as<float>(), oi, ov, oc, os, S); });

@@ -17,7 +17,7 @@ from pecos_amd import XLinearModel, clib  # noqa: E402
 name, scale, steps = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
 sets = sys.argv[4:] or [""]
 rows_limit = int(os.environ.get("AB_ROWS", "0"))
-DEFAULTS = dict(sort_rest_min=32768, qsort=1, qsort_min_parents=64, qsort_min_rows=131072, prune=1, adaptive=1, presence=1, sort_rest=1, prune_mid=1, k1q_fuse=3, dense_layers=1, k1_group=0, sort_min_tiles=0)
+DEFAULTS = dict(tile_rows=1, sort_rest_min=32768, qsort=1, qsort_min_parents=64, qsort_min_rows=131072, prune=1, adaptive=1, presence=1, sort_rest=1, prune_mid=1, k1q_fuse=3, dense_layers=1, k1_group=0, sort_min_tiles=0)
 folder = f"/tmp/xrl_bench/{name}_{scale}"
 if not os.path.exists(folder + "/.done"):
     t0 = time.time()
