@@ -1387,6 +1387,7 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     }
     else if (!std::strcmp(key, "host_register")) m.host_register = (int)value;   // 1: page-lock the caller's X in place (hipHostRegister) instead of staging it through pinned buffers   // 0: the host ABI uploads X in one piece before computing
     else if (!std::strcmp(key, "k1q_fuse")) m.k1q_fuse = (int)value;           // 0: one K1Q launch per dense-format layer
+    else if (!std::strcmp(key, "k1g_first")) m.k1g_first = (int)value;
     else if (!std::strcmp(key, "k1g_min_items")) m.k1g_min_items = (int)value;   // dense X: queries per parent from which a dense-format layer runs the tiled SGEMM K1G (0 = never)
     else if (!std::strcmp(key, "dense_layers")) m.dense_layers = (int)value;   // 0: never run the fused dense-format kernel K1Q
     else if (!std::strcmp(key, "overlap_min_rows")) m.overlap_min_rows = (int)value;
@@ -1420,7 +1421,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
                 std::unique_ptr<Model> r = m.src_kind == 0 ? load_model_from_disk(m.src_path, m.weight_matrix_type) : load_mmap_model_from_disk(m.src_path);
                 r->device = dev;
                 r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->sort_rest = m.sort_rest; r->sort_rest_min = m.sort_rest_min; r->prune_mid = m.prune_mid; r->tile_rows = m.tile_rows; r->qsort = m.qsort; r->qsort_min_parents = m.qsort_min_parents; r->qsort_min_rows = m.qsort_min_rows; r->presence = m.presence; r->adaptive = m.adaptive; r->host_pipeline = m.host_pipeline; r->host_batch_mb = m.host_batch_mb; r->host_register = m.host_register;
-                r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->dense_layers = m.dense_layers;
+                r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->k1g_first = m.k1g_first; r->dense_layers = m.dense_layers;
                 r->overlap_min_rows = m.overlap_min_rows; r->prune = m.prune;
                 r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;
                 m.replicas.push_back(std::move(r));

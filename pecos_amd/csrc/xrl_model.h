@@ -194,6 +194,7 @@ struct Model {
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)
     int k1q_fuse = 3;                       // consecutive dense-format layers of <= this many candidate registers (1..3) share one K1Q launch (the beam stays in LDS); 0: one launch per layer
+    int k1g_first = 0;                      // K1G layers under bound pruning: beam parents scored in the first stage (0 = about one candidate register, 64 / children per parent)
     int k1g_min_items = 16;                 // dense X: run a dense-format layer as the tiled SGEMM K1G once a parent serves this many queries on average (0 = never)
     // ---- pruning feedback (xrl_predict.cpp): what the bound pruning of the PREVIOUS predicts of this handle achieved, per layer, so that a
     // model on which the first stage settles almost nothing (scores that do not saturate, routing spread over the tree) stops paying for

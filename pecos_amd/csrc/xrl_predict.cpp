@@ -22,7 +22,8 @@ size_t profile_slot(Model& m, const char* name, uint32_t layer) {
 
 // dense-X SGEMM layers, bound pruning: beam slots whose children fill about one candidate register (64) are scored first -- never all of
 // them (the second stage must keep at least one slot)
-static uint32_t k1g_first_slots(const Layer& L, uint32_t beam_in) {
+static uint32_t k1g_first_slots(const Layer& L, uint32_t beam_in, int forced = 0) {
+    if (forced > 0) return (uint32_t)std::max<int64_t>(1, std::min<int64_t>(beam_in > 1 ? (int64_t)beam_in - 1 : 1, forced));
     return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(beam_in > 1 ? beam_in - 1 : 1, 64 / std::max<uint64_t>(1, L.cand_bound(1))));
 }
 
@@ -273,7 +274,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 //      then a second, tile-sorted GEMM over the remaining slots of the queries whose top-k is not final yet.  J covers about
                 //      one candidate register (64 candidates), like K1Q's first stage.
                 if (m.prune && !P.implicit_root && !P.first_layer && P.pp.kind != PP_NOOP && beam_in[l] > 1 && k2_wave_path(P)) {
-                    const uint32_t J = k1g_first_slots(L, beam_in[l]);
+                    const uint32_t J = k1g_first_slots(L, beam_in[l], m.k1g_first);
                     const uint64_t slots_a = (uint64_t)nrows * J * L.max_tiles_per_parent, slots_b = (uint64_t)nrows * (beam_in[l] - J) * L.max_tiles_per_parent;
                     lw.prune_done.reserve((size_t)nb * 4); lw.prune_cnt.reserve(256);
                     LayerPlan PA = P; PA.beam_in = J;
@@ -371,7 +372,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
                 // that the work it counts is the work the timed kernels evaluate (K1G: J parents first; K1Q: the parents of candidate
                 // register 0 first, nothing skipped when the whole beam fits one register)
                 const bool dense_x = X.dense != 0 || m.dense_layers >= 2;
-                if (mode == 3) J = k1g_first_slots(L, beam_in[l]);      // (the SAME staging the timed K1G path uses: ADVICE r3)
+                if (mode == 3) J = k1g_first_slots(L, beam_in[l], m.k1g_first);      // (the SAME staging the timed K1G path uses: ADVICE r3)
                 else if (m.dense_layers && k1q_regs(L.dev, beam_in[l], k[l], dense_x) != 0) {
                     if (k1q_regs(L.dev, beam_in[l], k[l], dense_x) <= 1) pruned = false;
                     else J = std::max<uint32_t>(1, (64u >> L.dev.d_gp_log2) / std::max<uint32_t>(1, L.dev.d_max_tiles));

@@ -17,16 +17,24 @@ from pecos_amd import XLinearModel, clib  # noqa: E402
 name, scale, steps = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
 sets = sys.argv[4:] or [""]
 rows_limit = int(os.environ.get("AB_ROWS", "0"))
-DEFAULTS = dict(tile_rows=1, sort_rest_min=32768, qsort=1, qsort_min_parents=64, qsort_min_rows=131072, prune=1, adaptive=1, presence=1, sort_rest=1, prune_mid=1, k1q_fuse=3, dense_layers=1, k1_group=0, sort_min_tiles=0)
+DEFAULTS = dict(tile_rows=1, k1g_first=0, k1g_variant=0, sort_rest_min=32768, qsort=1, qsort_min_parents=64, qsort_min_rows=131072, prune=1, adaptive=1, presence=1, sort_rest=1, prune_mid=1, k1q_fuse=3, dense_layers=1, k1_group=0, sort_min_tiles=0)
 folder = f"/tmp/xrl_bench/{name}_{scale}"
 if not os.path.exists(folder + "/.done"):
     t0 = time.time()
     ks, X, cfg = xrl_synth.make_config(name, folder, scale=scale)
-    smat.save_npz(folder + "/X.npz", X, compressed=False); json.dump({"ks": ks, "cfg": cfg}, open(folder + "/meta.json", "w")); open(folder + "/.done", "w").write("ok")
+    if smat.issparse(X):
+        smat.save_npz(folder + "/X.npz", X, compressed=False)
+    else:
+        np.save(folder + "/X.npy", X)
+    json.dump({"ks": ks, "cfg": cfg}, open(folder + "/meta.json", "w")); open(folder + "/.done", "w").write("ok")
     print(f"generated {name} in {time.time() - t0:.0f} s", flush=True)
-X = smat.load_npz(folder + "/X.npz").tocsr().astype(np.float32); X.sort_indices()
-if rows_limit:
-    X = X[:rows_limit]
+if os.path.exists(folder + "/X.npy"):      # dense queries (dense-768)
+    X = np.load(folder + "/X.npy", mmap_mode="r")
+    X = np.ascontiguousarray(X[:rows_limit] if rows_limit else X, dtype=np.float32)
+else:
+    X = smat.load_npz(folder + "/X.npz").tocsr().astype(np.float32); X.sort_indices()
+    if rows_limit:
+        X = X[:rows_limit]
 cfg = xrl_synth.CONFIGS[name]
 m = XLinearModel.load(folder); h = m.model.model_chain
 q = clib.queries_upload(h, X)

@@ -35,7 +35,8 @@ except Exception as e: print('no json', e)
     ab) n=$((n+1)); IFS='@' read -r ab_rows ab_cfg ab_steps ab_sets <<< "${st#*:}"
         IFS='|' read -ra ab_list <<< "$ab_sets"; ab_args=(); for x in "${ab_list[@]}"; do ab_args+=("$(echo "$x" | tr '+' ',')"); done
         [ ${#ab_args[@]} -eq 0 ] && ab_args=("")
-        echo "== ab rows=$ab_rows $ab_cfg"; AB_ROWS=$ab_rows timeout 600 python scripts/ab.py $ab_cfg 1.0 $ab_steps "${ab_args[@]}" > $O/ab_$n.log 2>&1; grep -E "ms/step|Error|error" $O/ab_$n.log | cut -c1-600 ;;
+        ab_scale=1.0; case $ab_cfg in *:*) ab_scale=${ab_cfg#*:}; ab_cfg=${ab_cfg%%:*} ;; esac   # CONFIG:SCALE
+        echo "== ab rows=$ab_rows $ab_cfg x$ab_scale"; AB_ROWS=$ab_rows timeout 900 python scripts/ab.py $ab_cfg $ab_scale $ab_steps "${ab_args[@]}" > $O/ab_$n.log 2>&1; grep -E "ms/step|Error|error" $O/ab_$n.log | cut -c1-600 ;;
     pmc) # pmc:BENCHARG,BENCHARG,...   two counter passes (TCC + TCP + SQ blocks have separate slots) + one --kernel-trace --stats pass; writes
          # pmc_<n>_{fetch,write,l2,sq}.csv, kernel_stats_<n>.csv and the pmc_traffic entry pmc_entry_<n>.json (scripts/pmc_traffic.py)
          n=$((n+1)); cd /tmp && export TMPDIR=/tmp XRL_STEP_MARKER=1
