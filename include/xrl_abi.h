@@ -215,6 +215,8 @@ void* xrl_queries_tfidf_device(void* model, uint32_t rows, uint32_t cols, const 
 void* c_tfidf_load(const char* model_dir);
 void c_tfidf_destruct(void* ptr);
 void c_tfidf_predict(void* ptr, void* corpus_ptr /* const char** */, const size_t* doc_lens, size_t nr_doc, int threads, py_sparse_allocator_t pred_alloc);
+/* libpecos.cpp:413-425: one document per line of a text file (buffer_size only sizes the reference's read chunks: ignored) */
+void c_tfidf_predict_from_file(void* ptr, void* corpus_fname_ptr /* const char* */, size_t fname_len, size_t buffer_size, int threads, py_sparse_allocator_t pred_alloc);
 uint32_t xrl_tfidf_nr_features(void* ptr);
 void* xrl_tfidf_predict_device(void* vectorizer, void* model, void* corpus_ptr /* const char** */, const size_t* doc_lens, size_t nr_doc, int threads);
 void xrl_tfidf_counts(void* ptr, void* corpus_ptr /* const char** */, const size_t* doc_lens, size_t nr_doc, int threads, py_sparse_allocator_t alloc);

@@ -224,6 +224,7 @@ class corelib(object):
             "c_tfidf_load": (c_void_p, [c_char_p]),
             "c_tfidf_destruct": (None, [c_void_p]),
             "c_tfidf_predict": (None, [c_void_p, c_void_p, POINTER(c_uint64), c_uint64, c_int, ScipyCompressedSparseAllocator.CFUNCTYPE]),
+            "c_tfidf_predict_from_file": (None, [c_void_p, c_void_p, c_uint64, c_uint64, c_int, ScipyCompressedSparseAllocator.CFUNCTYPE]),
             "xrl_tfidf_counts": (None, [c_void_p, c_void_p, POINTER(c_uint64), c_uint64, c_int, ScipyCompressedSparseAllocator.CFUNCTYPE]),
             "xrl_tfidf_nr_features": (c_uint32, [c_void_p]),
             "xrl_tfidf_predict_device": (c_void_p, [c_void_p, c_void_p, c_void_p, POINTER(c_uint64), c_uint64, c_int]),
@@ -519,10 +520,14 @@ class corelib(object):
         return arr, lens, nr_doc
 
     def tfidf_predict(self, model, corpus, buffer_size=0, threads=-1):
-        """Vectorize a list of strings (the reference's in-memory path; predict-from-file stays the reference's)."""
-        if isinstance(corpus, str):
-            raise NotImplementedError("predict from a corpus FILE is not offered by pecos_amd: read the lines and pass a list")
+        """Vectorize a list of strings, or -- corpus given as a path -- the lines of a text file (pecos/core/base.py:1820-1863)."""
         pred_alloc = ScipyCompressedSparseAllocator()
+        if isinstance(corpus, str):
+            assert os.path.isfile(corpus), "Cannot predict from {}!".format(corpus)
+            corpus_utf8 = corpus.encode("utf-8")
+            self.clib_float32.c_tfidf_predict_from_file(c_void_p(model), ctypes.cast(c_char_p(corpus_utf8), c_void_p), len(corpus_utf8), buffer_size, threads, pred_alloc.cfunc)
+            self._check()
+            return pred_alloc.get()
         arr, lens, nr_doc = self._corpus_arrays(corpus)
         self.clib_float32.c_tfidf_predict(c_void_p(model), arr, lens.ctypes.data_as(POINTER(c_uint64)), nr_doc, threads, pred_alloc.cfunc)
         self._check()

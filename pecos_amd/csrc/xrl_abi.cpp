@@ -3,7 +3,9 @@
 #include "../../include/xrl_abi.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <functional>
@@ -1593,31 +1595,123 @@ uint32_t xrl_tfidf_nr_features(void* ptr) {
     return v;
 }
 
+// documents -> weighted CSR on the device -> the caller's arrays through ONE allocator call (shared by c_tfidf_predict and c_tfidf_predict_from_file)
+// The weighting half on the HOST, for calls of a handful of documents (the reference serves nr_doc == 1 with a direct host call, libpecos.cpp:437-439:
+// microseconds -- a device round trip costs a hundred times that).  tfidf.hpp:798-822 operation by operation in fp32, like the kernel
+// (csrc/xrl_features.hip): sequential norm in ascending feature order, separate multiply and add (-ffp-contract=off), glibc's logf (the reference's own).
+static void tfidf_weight_host(const uint64_t* row_ptr, const uint32_t* col, float* val, const float* idf, uint32_t rows, uint32_t cols, bool binary,
+                              bool sublinear, int norm_p, uint32_t seg_stride, uint32_t seg_off) {
+    if (norm_p != 1 && norm_p != 2) fail("tfidf: invalid normalize option, norm_p: [ 1| 2]");
+    for (uint32_t r = 0; r < rows; ++r) {
+        const uint64_t b = row_ptr[(uint64_t)r * seg_stride + seg_off], e = row_ptr[(uint64_t)r * seg_stride + seg_off + 1];
+        float denom = 0.0f;
+        for (uint64_t t = b; t < e; ++t) {
+            float v = binary ? 1.0f : val[t];
+            if (sublinear) v = (float)((double)std::log(v) + 1.0);
+            if (idf) {
+                if (col[t] >= cols) fail("tfidf: a feature id outside the model's feature range");
+                v = v * idf[col[t]];
+            }
+            val[t] = v;
+            const float term = norm_p == 1 ? std::fabs(v) : v * v;
+            denom = denom + term;
+        }
+        if (std::fabs(denom) < FLT_EPSILON) denom = 1.0f;
+        else if (norm_p == 2) denom = std::sqrt(denom);
+        for (uint64_t t = b; t < e; ++t) val[t] = val[t] / denom;
+    }
+}
+
+constexpr size_t kTfidfHostDocs = 4;   // c_tfidf_predict calls of at most this many documents are weighted on the host
+
+static void tfidf_predict_small_on_host(const TfidfHandle& H, const char* const* corpus, const size_t* doc_lens, size_t nr_doc, py_sparse_allocator_t pred_alloc) {
+    const TfidfVectorizer& V = H.v;
+    const uint32_t nb = (uint32_t)V.base.size(), rows = (uint32_t)nr_doc;
+    std::vector<uint64_t> seg_ptr;
+    std::vector<uint32_t> h_col; std::vector<float> h_val;
+    V.count_corpus(corpus, doc_lens, nr_doc, 1, seg_ptr, [&](uint64_t n, uint32_t*& c, float*& v) { h_col.resize(n + 1); h_val.resize(n + 1); c = h_col.data(); v = h_val.data(); });
+    const uint64_t nnz = seg_ptr.empty() ? 0 : seg_ptr.back();
+    for (uint32_t b = 0; b < nb; ++b) {
+        const TfidfBase& B = V.base[b];
+        tfidf_weight_host(seg_ptr.data(), h_col.data(), h_val.data(), B.use_idf ? H.idf_all.data() : nullptr, rows, V.nr_features, B.binary, B.sublinear_tf, B.norm_p, nb, b);
+    }
+    std::vector<uint64_t> row_ptr((size_t)rows + 1);
+    for (size_t r = 0; r <= rows; ++r) row_ptr[r] = seg_ptr[r * nb];
+    if (nb > 1 || V.norm_p != V.base[0].norm_p)
+        tfidf_weight_host(row_ptr.data(), h_col.data(), h_val.data(), nullptr, rows, V.nr_features, false, false, V.norm_p, 1, 0);
+    uint32_t* indices = nullptr; uint64_t* indptr = nullptr; float* data = nullptr;
+    pred_alloc(false, rows, V.nr_features, nnz, &indices, &indptr, &data);
+    if (!indptr || (nnz && (!indices || !data))) fail("allocator returned null");
+    std::memcpy(indptr, row_ptr.data(), ((size_t)rows + 1) * 8);
+    if (nnz) { std::memcpy(indices, h_col.data(), (size_t)nnz * 4); std::memcpy(data, h_val.data(), (size_t)nnz * 4); }
+}
+
+static void tfidf_predict_to_host(const TfidfHandle& H, const char* const* corpus, const size_t* doc_lens, size_t nr_doc, int threads, py_sparse_allocator_t pred_alloc) {
+    const char* hs = std::getenv("XRL_TFIDF_HOST_DOCS");                     // XRL_TFIDF_HOST_DOCS=0: always the device (tests; read per call)
+    if (!(hs && hs[0] == '0') && nr_doc <= kTfidfHostDocs) { tfidf_predict_small_on_host(H, corpus, doc_lens, nr_doc, pred_alloc); return; }
+    use_device(g_device);
+    // (stream = nullptr: tfidf_to_device takes the handle's pooled stream under its staging lock and holds the lock until it has synchronised)
+    std::unique_ptr<Queries> q = tfidf_to_device(H, corpus, doc_lens, nr_doc, threads, g_device, nullptr);
+    uint32_t* indices = nullptr; uint64_t* indptr = nullptr; float* data = nullptr;
+    pred_alloc(false, q->dev.rows, q->dev.cols, q->nnz, &indices, &indptr, &data);
+    if (!indptr || (q->nnz && (!indices || !data))) fail("allocator returned null");
+    XRL_HIP(hipMemcpy(indptr, q->dev.row_ptr, ((size_t)q->dev.rows + 1) * 8, hipMemcpyDeviceToHost));
+    if (q->nnz) {
+        // D2H into the pinned staging buffer (link speed), then host threads spread it over the allocator's fresh arrays: their first touch
+        // in parallel, instead of the runtime's single-threaded pageable path
+        std::lock_guard<std::mutex> stage_lock(H.stage.mu);
+        const size_t nb4 = (size_t)q->nnz * 4;
+        char* st = static_cast<char*>(H.stage.need(2 * nb4));
+        XRL_HIP(hipMemcpy(st, q->dev.col_idx, nb4, hipMemcpyDeviceToHost));
+        XRL_HIP(hipMemcpy(st + nb4, q->dev.val, nb4, hipMemcpyDeviceToHost));
+        parallel_copy(indices, st, nb4, threads);
+        parallel_copy(data, st + nb4, nb4, threads);
+    }
+}
+
 void c_tfidf_predict(void* ptr, void* corpus_ptr, const size_t* doc_lens, size_t nr_doc, int threads, py_sparse_allocator_t pred_alloc) {
     guarded([&] {
         if (!ptr || !pred_alloc) fail("c_tfidf_predict: null argument");
         if (nr_doc == 0) fail("Invalid nr_doc 0");                         // libpecos.cpp:442-444
         if (!corpus_ptr || !doc_lens) fail("c_tfidf_predict: null corpus");
         require_gpu();
-        const TfidfHandle& H = *static_cast<TfidfHandle*>(ptr);
-        use_device(g_device);
-        // (stream = nullptr: tfidf_to_device takes the handle's pooled stream under its staging lock and holds the lock until it has synchronised)
-        std::unique_ptr<Queries> q = tfidf_to_device(H, static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, g_device, nullptr);
-        uint32_t* indices = nullptr; uint64_t* indptr = nullptr; float* data = nullptr;
-        pred_alloc(false, q->dev.rows, q->dev.cols, q->nnz, &indices, &indptr, &data);
-        if (!indptr || (q->nnz && (!indices || !data))) fail("allocator returned null");
-        XRL_HIP(hipMemcpy(indptr, q->dev.row_ptr, ((size_t)q->dev.rows + 1) * 8, hipMemcpyDeviceToHost));
-        if (q->nnz) {
-            // D2H into the pinned staging buffer (link speed), then host threads spread it over the allocator's fresh arrays: their first touch
-            // in parallel, instead of the runtime's single-threaded pageable path
-            std::lock_guard<std::mutex> stage_lock(H.stage.mu);
-            const size_t nb4 = (size_t)q->nnz * 4;
-            char* st = static_cast<char*>(H.stage.need(2 * nb4));
-            XRL_HIP(hipMemcpy(st, q->dev.col_idx, nb4, hipMemcpyDeviceToHost));
-            XRL_HIP(hipMemcpy(st + nb4, q->dev.val, nb4, hipMemcpyDeviceToHost));
-            parallel_copy(indices, st, nb4, threads);
-            parallel_copy(data, st + nb4, nb4, threads);
+        tfidf_predict_to_host(*static_cast<TfidfHandle*>(ptr), static_cast<const char* const*>(corpus_ptr), doc_lens, nr_doc, threads, pred_alloc);
+    });
+}
+
+// c_tfidf_predict_from_file (libpecos.cpp:413-425 -> Vectorizer::predict_from_file, tfidf.hpp:1041-1120, 1365-1389): one document per LINE of the
+// file.  The reference cuts the file into chunks at newlines (file_util.hpp:180-200) and every chunk into lines (append_lines_to_string_view,
+// tfidf.hpp:279-294): every '\n' ends a document (empty lines are documents), and a last line WITHOUT a newline is a document too -- with the
+// terminating NUL that load_file_block appends counted into its length (tfidf.hpp:290-293 takes `end - start` after the loop has walked over it),
+// which is reproduced here.  buffer_size only sizes the reference's read chunks: the file is read whole.
+void c_tfidf_predict_from_file(void* ptr, void* corpus_fname_ptr, size_t fname_len, size_t buffer_size, int threads, py_sparse_allocator_t pred_alloc) {
+    (void)buffer_size;
+    guarded([&] {
+        if (!ptr || !pred_alloc || !corpus_fname_ptr) fail("c_tfidf_predict_from_file: null argument");
+        require_gpu();
+        const std::string fname(static_cast<const char*>(corpus_fname_ptr), fname_len);
+        std::FILE* fp = std::fopen(fname.c_str(), "rb");
+        if (!fp) fail("c_tfidf_predict_from_file: can't read " + fname);
+        std::vector<char> buf;
+        {
+            std::fseek(fp, 0, SEEK_END);
+            const long sz = std::ftell(fp);
+            std::fseek(fp, 0, SEEK_SET);
+            if (sz < 0) { std::fclose(fp); fail("c_tfidf_predict_from_file: can't size " + fname); }
+            buf.resize((size_t)sz + 1);
+            const size_t got = sz ? std::fread(buf.data(), 1, (size_t)sz, fp) : 0;
+            std::fclose(fp);
+            if (got != (size_t)sz) fail("c_tfidf_predict_from_file: error reading " + fname);
+            buf[(size_t)sz] = '\0';
         }
+        const size_t n = buf.size() - 1;
+        std::vector<const char*> docs; std::vector<size_t> lens;
+        size_t start = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (buf[i] == '\n') { docs.push_back(buf.data() + start); lens.push_back(i - start); start = i + 1; }
+        if (start < n) { docs.push_back(buf.data() + start); lens.push_back(n + 1 - start); }   // (the NUL is part of the reference's last document)
+        if (docs.empty()) fail("c_tfidf_predict_from_file: " + fname + " holds no document");
+        tfidf_predict_to_host(*static_cast<TfidfHandle*>(ptr), docs.data(), lens.data(), docs.size(), threads, pred_alloc);
     });
 }
 

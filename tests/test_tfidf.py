@@ -424,10 +424,69 @@ def test_c_tfidf_predict_vs_reference_goldens(name, manifest):
         assert np.allclose(P.data, X.data, rtol=3e-7, atol=0)
     else:
         assert np.array_equal(P.data.view(np.uint32), X.data.astype(np.float32).view(np.uint32)), name
-    one = vec.predict([corpus[1]], threads=1)        # nr_doc == 1
-    assert np.array_equal(one.indices, X.indices[X.indptr[1]: X.indptr[2]])
+    # calls of <= 4 documents are weighted on the HOST (the reference's nr_doc == 1 path is a host call too, libpecos.cpp:437-439); XRL_TFIDF_HOST_DOCS=0 sends
+    # them to the device: both must give the golden rows (host: glibc's logf like the reference -> bit-identical also with sublinear_tf)
+    for nd in (1, 3, 4):
+        for env in (None, "0"):
+            if env is None:
+                os.environ.pop("XRL_TFIDF_HOST_DOCS", None)
+            else:
+                os.environ["XRL_TFIDF_HOST_DOCS"] = env
+            try:
+                few = vec.predict(corpus[1: 1 + nd], threads=1)
+            finally:
+                os.environ.pop("XRL_TFIDF_HOST_DOCS", None)
+            lo, hi = X.indptr[1], X.indptr[1 + nd]
+            assert few.shape == (nd, X.shape[1]) and np.array_equal(few.indptr, X.indptr[1: 2 + nd] - lo) and np.array_equal(few.indices, X.indices[lo:hi]), (name, nd, env)
+            if sub and env == "0":
+                assert np.allclose(few.data, X.data[lo:hi], rtol=3e-7, atol=0)
+            else:
+                assert np.array_equal(few.data.view(np.uint32), X.data[lo:hi].astype(np.float32).view(np.uint32)), (name, nd, env)
     with pytest.raises(RuntimeError):
         vec.predict([])                              # Invalid nr_doc 0 (libpecos.cpp:442-444)
+
+
+def _file_cases():
+    d = os.path.join(GOLDEN, "tfidf_files")
+    return sorted(f[:-4] for f in os.listdir(d) if f.endswith(".txt")) if os.path.isdir(d) else []
+
+
+def _file_docs(raw):
+    """The documents the reference's reader makes of a file (tfidf.hpp:279-294): every newline ends one, a last line without a newline keeps the NUL its buffer ends with."""
+    docs, start = [], 0
+    for i, b in enumerate(raw):
+        if b == 10:
+            docs.append(raw[start:i]); start = i + 1
+    if start < len(raw):
+        docs.append(raw[start:] + b"\0")
+    return docs
+
+
+@pytest.mark.parametrize("case", _file_cases())
+def test_file_reader_documents_have_the_reference_pattern(case):
+    # host only: the term-count pattern of the documents cut from the file == the pattern of the reference's predict_from_file output
+    from pecos_amd import clib
+    name = case.split("__")[0]
+    raw = open(os.path.join(GOLDEN, "tfidf_files", case + ".txt"), "rb").read()
+    z = np.load(os.path.join(GOLDEN, "tfidf_files", case + ".npz"))
+    h = clib.tfidf_load(os.path.join(GOLDEN, "tfidf_models", name, "model"))
+    try:
+        C = clib.tfidf_counts(h, _file_docs(raw))
+    finally:
+        clib.tfidf_destruct(h)
+    assert C.shape == tuple(z["shape"]) and np.array_equal(C.indptr, z["indptr"]) and np.array_equal(C.indices, z["indices"]), case
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _file_cases())
+def test_c_tfidf_predict_from_file_vs_reference_goldens(case):
+    # libpecos.cpp:413-425 through the drop-in entry point: one document per line, blank lines are documents, a last line without a newline
+    from pecos_amd.features import Tfidf
+    name = case.split("__")[0]
+    z = np.load(os.path.join(GOLDEN, "tfidf_files", case + ".npz"))
+    P = Tfidf.load(os.path.join(GOLDEN, "tfidf_models", name, "model")).predict(os.path.join(GOLDEN, "tfidf_files", case + ".txt"))
+    assert P.shape == tuple(z["shape"]) and np.array_equal(P.indptr, z["indptr"]) and np.array_equal(P.indices, z["indices"]), case
+    assert np.array_equal(P.data.view(np.uint32), z["data"].astype(np.float32).view(np.uint32)), case
 
 
 @pytest.mark.gpu
