@@ -1370,6 +1370,7 @@ static void set_option_one(Model& m, const char* key, int64_t value) {
     else if (!std::strcmp(key, "sort_rest")) m.sort_rest = (int)value;
     else if (!std::strcmp(key, "prune_mid")) m.prune_mid = (int)value;
     else if (!std::strcmp(key, "tile_rows")) m.tile_rows = (int)value;
+    else if (!std::strcmp(key, "k2_big_min_k")) m.k2_big_min_k = (int)value;
     else if (!std::strcmp(key, "qsort")) m.qsort = (int)value;                         // 0: K1Q never runs a layer on sorted queries
     else if (!std::strcmp(key, "qsort_min_parents")) m.qsort_min_parents = (int)value;
     else if (!std::strcmp(key, "qsort_min_rows")) m.qsort_min_rows = (int)value;
@@ -1422,7 +1423,7 @@ int xrl_set_option(void* model, const char* key, int64_t value) {
                 use_device(dev);
                 std::unique_ptr<Model> r = m.src_kind == 0 ? load_model_from_disk(m.src_path, m.weight_matrix_type) : load_mmap_model_from_disk(m.src_path);
                 r->device = dev;
-                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->sort_rest = m.sort_rest; r->sort_rest_min = m.sort_rest_min; r->prune_mid = m.prune_mid; r->tile_rows = m.tile_rows; r->qsort = m.qsort; r->qsort_min_parents = m.qsort_min_parents; r->qsort_min_rows = m.qsort_min_rows; r->presence = m.presence; r->adaptive = m.adaptive; r->host_pipeline = m.host_pipeline; r->host_batch_mb = m.host_batch_mb; r->host_register = m.host_register;
+                r->k1_group = m.k1_group; r->max_batch_rows = m.max_batch_rows; r->sort_min_tiles = m.sort_min_tiles; r->sort_rest = m.sort_rest; r->sort_rest_min = m.sort_rest_min; r->prune_mid = m.prune_mid; r->tile_rows = m.tile_rows; r->k2_big_min_k = m.k2_big_min_k; r->qsort = m.qsort; r->qsort_min_parents = m.qsort_min_parents; r->qsort_min_rows = m.qsort_min_rows; r->presence = m.presence; r->adaptive = m.adaptive; r->host_pipeline = m.host_pipeline; r->host_batch_mb = m.host_batch_mb; r->host_register = m.host_register;
                 r->k1q_fuse = m.k1q_fuse; r->k1g_min_items = m.k1g_min_items; r->k1g_first = m.k1g_first; r->dense_layers = m.dense_layers;
                 r->overlap_min_rows = m.overlap_min_rows; r->prune = m.prune;
                 r->k1g_variant = m.k1g_variant; r->k1_wpb = m.k1_wpb; r->k1_lds_pad = m.k1_lds_pad; r->k1_ablate = m.k1_ablate;

@@ -23,7 +23,7 @@ struct BeamDev {
     uint32_t stride;
 };
 
-struct K1Tune { int wpb = 1, lds_pad = 0, ablate = 0, k1g_variant = 0, pres_mode = 1, tile_rows = 1; };   // per-model tuning / debug knobs (xrl_set_option k1_wpb, k1_lds_pad, k1_ablate, k1g_variant)
+struct K1Tune { int wpb = 1, lds_pad = 0, ablate = 0, k1g_variant = 0, pres_mode = 1, tile_rows = 1, k2_big_min_k = 0; };   // per-model tuning / debug knobs (xrl_set_option k1_wpb, k1_lds_pad, k1_ablate, k1g_variant)
 
 struct LayerPlan {
     uint32_t row0, nrows;       // query rows [row0, row0+nrows) of the query matrix
@@ -118,5 +118,8 @@ void launch_k1q(const LayerDev* const* Ls, const LayerPlan* Ps, int n, const Que
                 const uint32_t* qperm = nullptr /* launch slot -> query (launch_sort_queries); every XCD then takes a contiguous range of slots */);
                 // prune_wmax / out_xok: the bound-pruning guard (prune_guard_ok, xrl_device.h); out_xok[q] receives every query's flag
 size_t k2_max_k();
+// xrl_topk_big.hip: top-k sizes beyond k2_max_k() -- one segmented radix sort over the batch's candidate rows (no cap, like the reference's sorted_csr)
+void launch_k2_topk_big(const LayerDev& L, const LayerPlan& P, BeamDev prev, const uint32_t* cand_off, const uint32_t* ncand, const float* cand,
+                        uint32_t* out_idx, float* out_val, uint32_t* out_cnt, uint32_t out_stride, hipStream_t s);
 
 }  // namespace xrl

@@ -952,6 +952,11 @@ void launch_k2_topk(const LayerDev& L, const LayerPlan& P, BeamDev prev, const u
     a.nrows = P.nrows; a.beam_in = P.beam_in; a.cand_stride = P.cand_stride; a.k = P.k; a.out_stride = out_stride;
     a.implicit_root = P.implicit_root;
     if (P.k == 0) fail("k2: only_topk / beam_size resolved to 0");
+    // beyond the LDS kernel's reach (or forced, tests: k2_big_min_k): the segmented sort of xrl_topk_big.hip
+    if (!rank_limit && !done && !skip_done && (P.k > k2_max_k() || (P.tune.k2_big_min_k > 0 && P.k >= (uint32_t)P.tune.k2_big_min_k))) {
+        launch_k2_topk_big(L, P, prev, cand_off, ncand, cand, out_idx, out_val, out_cnt, out_stride, s);
+        return;
+    }
     if (k2_wave_path(P)) {
         // (a rank-limited selection looks at the first slots' candidates only: registers for that many)
         const uint32_t ns = ((rank_limit ? std::min(P.cand_stride, std::max(1u, limited_cands)) : P.cand_stride) + 63u) / 64u;

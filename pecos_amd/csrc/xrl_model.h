@@ -190,6 +190,7 @@ struct Model {
                                             // K0/K2 run under the other half's K1; 0 = never (measured on Amazon-670K: 25.9 vs 25.5 ms, no gain)
     int prune = 1;                          // exact bound pruning (xrl_predict.cpp): 1 = a layer first scores the children of the best beam parent(s) only and
                                             // skips the rest for every query whose k-th best already reaches the next parent's score; 0 = score every candidate
+    int k2_big_min_k = 0;                   // > 0: top-k sizes from this value on take the segmented-sort K2 (xrl_topk_big.hip) that otherwise serves k > 20 480 (tests)
     int tile_rows = 1;                      // tile-format layers that carry densely held tile rows (LayerDev::wt), sparse X: 1 = launches on items in query order run K1T (xrl_k1t.hip), 2 = every launch, 0 = always the entry-list kernel K1
     int dense_layers = 1;                   // 1 = layers that carry the dense row format run the fused query-stationary kernel K1Q (0: K0 -> K1 -> K2 everywhere)
     bool csc_route = false;                 // weight_matrix_type == CSC: every layer runs the reference's CSC arithmetic (K0 -> K1C -> K2)

@@ -239,7 +239,7 @@ void predict_device(Model& m, const QueriesDev& X, const PredictOpts& o, uint32_
             P.layer = (int)l;
             P.row0 = (uint32_t)row0; P.nrows = nrows; P.beam_in = beam_in[l]; P.k = k[l];
             P.cand_stride = cstride[l]; P.pp = pp[l];
-            P.tune.wpb = m.k1_wpb; P.tune.lds_pad = m.k1_lds_pad; P.tune.ablate = m.k1_ablate; P.tune.k1g_variant = m.k1g_variant; P.tune.pres_mode = m.presence; P.tune.tile_rows = m.tile_rows;
+            P.tune.wpb = m.k1_wpb; P.tune.lds_pad = m.k1_lds_pad; P.tune.ablate = m.k1_ablate; P.tune.k1g_variant = m.k1g_variant; P.tune.pres_mode = m.presence; P.tune.tile_rows = m.tile_rows; P.tune.k2_big_min_k = m.k2_big_min_k;
             P.first_layer = (l == 0 && (!has_init || o.no_prev_pred)) ? 1 : 0;   // no_prev_pred
             P.implicit_root = (l == 0 && !has_init) ? 1 : 0;
             P.bias_first = (m.weight_matrix_type == 1 && !X.dense) ? 1 : 0;

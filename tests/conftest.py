@@ -59,3 +59,24 @@ def assert_same_topk(a, b, rel=1e-5, exact_scores=False, what=""):
         err = np.abs(a.data - b.data)
         tol = rel * np.abs(b.data) + 1e-37
         assert np.all(err <= tol), f"{what}: max rel err {np.max(err / np.maximum(np.abs(b.data), 1e-30))}"
+
+
+def assert_topk_close(a, b, rel=1e-5, what="", atol=1e-37):
+    """Where the two sides may legitimately round differently (a summation ORDER the reference itself leaves to a hash table): same row lengths, every
+    label both sides return scores within `rel`, the i-th scores agree within `rel`, and a label only one side returns sits within `rel` of that
+    side's last (k-th) score -- i.e. the lists differ at most by swaps of near-ties."""
+    assert a.shape == b.shape and np.array_equal(a.indptr, b.indptr), f"{what}: shapes / row lengths differ"
+    for r in range(a.shape[0]):
+        lo, hi = a.indptr[r], a.indptr[r + 1]
+        if hi == lo:
+            continue
+        ia, va, ib, vb = a.indices[lo:hi], a.data[lo:hi], b.indices[lo:hi], b.data[lo:hi]
+        tol = rel * np.maximum(np.abs(va), np.abs(vb)) + atol
+        assert np.all(np.abs(va - vb) <= tol), f"{what}: row {r}: i-th scores differ by more than {rel} (+ {atol})"
+        da, db = dict(zip(ia.tolist(), va.tolist())), dict(zip(ib.tolist(), vb.tolist()))
+        for lab in set(da) | set(db):
+            if lab in da and lab in db:
+                assert abs(da[lab] - db[lab]) <= rel * max(abs(da[lab]), abs(db[lab])) + atol, f"{what}: row {r} label {lab}"
+            else:
+                v, last = (da[lab], va[-1]) if lab in da else (db[lab], vb[-1])
+                assert abs(v - last) <= 4 * (rel * max(abs(v), abs(last)) + atol), f"{what}: row {r}: label {lab} is not a near-tie of the k-th score"

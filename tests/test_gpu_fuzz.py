@@ -105,6 +105,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
         clib.set_option(m.model.model_chain, "k1_group", int(rng.choice([0, 0, 1, 4, 16, 64])))
         clib.set_option(m.model.model_chain, "presence", int(rng.choice([0, 1, 2, 2])))           # K1Q presence words: never / unstaged layers / always
         clib.set_option(m.model.model_chain, "sort_min_tiles", int(rng.choice([0, 1, 1])))       # tile-format layers: items in natural order / tile-sorted
+        clib.set_option(m.model.model_chain, "k2_big_min_k", int(rng.choice([0, 0, 1, 40])))      # the segmented-sort K2 that serves k > 20 480, forced on small k
         clib.set_option(m.model.model_chain, "tile_rows", (2, 0, 1, 2)[trial])                    # tile-format layers, sparse X: K1T (densely held tile rows) in every launch / never / query-order launches
         # K1Q's sorted launch (queries counting-sorted by the best parent of their beam, XCD-contiguous): forced on these small batches / off
         qs = int(rng.choice([0, 1, 1]))
@@ -126,6 +127,7 @@ def test_fuzz(seed, tmp_path, oracle_mod):
     clib.set_option(m.model.model_chain, "dense_layers", 1)
     clib.set_option(m.model.model_chain, "sort_min_tiles", 0)
     clib.set_option(m.model.model_chain, "tile_rows", 1)
+    clib.set_option(m.model.model_chain, "k2_big_min_k", 0)
     clib.set_option(m.model.model_chain, "presence", 1)
     clib.set_option(m.model.model_chain, "prune", 1)
     os.environ.pop("XRL_K1Q_FUSE01", None)

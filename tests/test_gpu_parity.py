@@ -599,6 +599,34 @@ def test_hash_chunked_sparse_queries_bit_exact(manifest, XLM, clib, oracle_mod, 
                 assert_same_topk(m.predict(X, **kw), want, exact_scores=True, what=f"HASH_CHUNKED vs live reference {kw} dense_layers={dl}")
             other = ref_bs.predict(X, **kw)
             assert not np.array_equal(other.data.view(np.uint32), want.data.view(np.uint32))     # the two layouts do differ in the last bits
+        # DENSE queries under HASH_CHUNKED: the reference sums a chunk's rows in the iteration order of its robin-hood hash table
+        # (chunk_ops<drm, hash>, inference.hpp:737-768) -- not reproduced: this library sums in ascending feature order (the BINARY_SEARCH_CHUNKED
+        # arithmetic).  The two orders differ by a few ulps of the ACCUMULATOR (margins ~1: <= 5e-7 absolute); an additive
+        # post-processor turns that into the same ABSOLUTE error of a score that may itself be small (log-l1-hinge: 1 - margin cancels: 2.4e-5
+        # relative observed on scores of -0.02), a multiplicative one keeps it relative.  What must hold: the same labels up to swaps of
+        # near-ties, scores within 1e-5 relative + 2e-6 absolute.
+        from conftest import assert_topk_close
+        Xd = np.ascontiguousarray(X[:400].toarray())
+        for kw in (dict(beam_size=10, only_topk=10), dict(beam_size=4, only_topk=20, post_processor="log-l1-hinge")):
+            want = ref.predict(Xd, **kw)
+            for dl in (1, 0):
+                clib.set_option(m.model.model_chain, "dense_layers", dl)
+                assert_topk_close(m.predict(Xd, **kw), want, rel=1e-5, atol=2e-6, what=f"HASH_CHUNKED dense X vs live reference {kw} dense_layers={dl}")
+        clib.set_option(m.model.model_chain, "dense_layers", 1)
+
+
+def test_topk_beyond_the_lds_limit(XLM, clib, oracle_mod, tmp_path):
+    # only_topk / beam_size > 20 480 (what a workgroup's LDS can rank): the reference's sorted_csr has no cap (inference.hpp:1223-1298); here the
+    # segmented-sort K2 (csrc/xrl_topk_big.hip) takes over.  A flat model of 30 000 labels, only_topk 25 000; and a two-layer one with beam 21 000.
+    import xrl_synth
+    for shape, kw in (([30000], dict(only_topk=25000)), ([24000, 26000], dict(beam_size=21000, only_topk=22000))):
+        folder = str(tmp_path / f"m{len(shape)}")
+        xrl_synth.make_model(folder, 60, shape[-1], [8] * len(shape), seed=77, shape=shape)
+        X = xrl_synth.make_queries(6, 60, 10, seed=78, relabel_seed=77)
+        m = XLM.load(folder)
+        om = oracle_mod.OracleModel.load(folder)
+        for Xq in (X, np.ascontiguousarray(X.toarray())):
+            assert_same_topk(m.predict(Xq, **kw), om.predict(Xq, **kw), exact_scores=True, what=f"big k {shape} {kw} dense={not smat.issparse(Xq)}")
 
 
 @pytest.mark.parametrize("variant", ["all_saturated", "bias_only", "descending"])
