@@ -538,7 +538,10 @@ def roofline(clib, h, q, Xs, prof, linfo, beam, args, k, rows, world, ms_per_ste
         # instruction mix can reach at best (frac_of_reachable).
         flops = sum(2.0 * st[r["layer"]]["x_cols"] * r["launches"] for r in prof if r["name"] == dom) / max(1, fam[dom]["launches"])
         tf = flops / (avg_ms * 1e-3) / 1e12
-        return dict(bound="mfma", kernel=dom, achieved=round(tf, 2), peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4), frac_of_reachable=round(tf / 78.6, 4),
+        return dict(bound="valu", bound_note="the kernel issues v_pk_mul_f32 + v_pk_add_f32 (no MFMA, no FMA: the reference rounds the product and the sum separately); "
+                    "peak = the fp32 VECTOR rate with FMA, frac_of_reachable = against half of it (what separate multiply + add can reach); measured on-chip bound "
+                    "(vector issue + LDS + barriers: profiles/r06_leaf.md section 5), not HBM",
+                    kernel=dom, achieved=round(tf, 2), peak=157.3, unit="TFLOP/s", frac=round(tf / 157.3, 4), frac_of_reachable=round(tf / 78.6, 4),
                     traffic=traffic, flops_per_launch=flops, avg_launch_ms=round(avg_ms, 4), launches_per_step=launches_per_step,
                     model="2 flops per multiply-add of every (query feature, candidate column) cell; fp32 multiply and add rounded separately (the reference carries no FMA), "
                           "so MFMA (fused) cannot be used and half the fp32 peak is the reachable rate",
