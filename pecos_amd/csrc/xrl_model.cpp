@@ -556,8 +556,8 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
     d.d_full = d_full ? 1 : 0; d.tile_parent = L->dense_bytes ? L->d_tile_parent.as<uint32_t>() : nullptr;
     // ---- TILE ROWS held densely (K1T, xrl_k1t.hip): built on the device from the tile format just uploaded.  Needs one cell per (row, column)
     //      (no duplicate row ids inside a weight column), a rank-bitmap lookup (the slots it returns index the rows) and room:
-    //      (rows + tiles) x stride x 4 bytes, at most a quarter of the free HBM / XRL_TILE_ROWS_MAX_MB (default 8 GiB: a layer whose tiles are mostly
-    //      single-entry rows -- Amazon-670K-hard's leaf: 5 094 rows per 82-column tile, 16 GB dense -- keeps its entry lists only).  XRL_TILE_ROWS=0 disables it.
+    //      (rows + tiles) x stride x 4 bytes, at most a quarter of the free HBM / XRL_TILE_ROWS_MAX_MB (default 64 GiB; Amazon-670K's leaf -- 5 094 rows per
+    //      82-column tile, most of them single-entry -- takes 16 GB: 22 GB of model instead of 6, +0.2 s of load).  XRL_TILE_ROWS=0 disables it.
     d.wt = nullptr; d.wt_base = nullptr; d.wt_stride = 0; d.wt_bytes = 0;
     {
         const char* te = std::getenv("XRL_TILE_ROWS");
@@ -570,7 +570,7 @@ std::unique_ptr<Layer> compile_layer(const HostCsc& W_full, const HostCsc& C, fl
         const uint64_t stride = (uint64_t)g * nr;
         const uint64_t floats = (total_rows + T) * stride;
         if (want) {
-            uint64_t cap_b = 8ull << 30;
+            uint64_t cap_b = 64ull << 30;
             if (const char* mb = std::getenv("XRL_TILE_ROWS_MAX_MB")) cap_b = std::strtoull(mb, nullptr, 10) << 20;
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) cap_b = std::min<uint64_t>(cap_b, free_b / 4);
