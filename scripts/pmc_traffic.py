@@ -17,7 +17,7 @@ import json
 import os
 import sys
 
-FAMILIES = (("k1q_kernel", "k1q_dense"), ("k1_kernel", "k1_sparse"), ("k1g_kernel", "k1g_dense_x"),
+FAMILIES = (("k1q_kernel", "k1q_dense"), ("k1_kernel", "k1_sparse"), ("k1t_kernel", "k1_sparse"), ("k1g_kernel", "k1g_dense_x"),
             ("k2_topk", "k2_topk"), ("k0_prolongate", "k0_prolongate"), ("sort_", "k1_sort_items"))
 
 
