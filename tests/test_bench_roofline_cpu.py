@@ -156,7 +156,7 @@ def test_no_committed_line_of_this_round_claims_the_impossible():
     # every committed bench line of the current round must carry a roofline block that is true -- no fraction of a
     # hardware peak above 1, no dominant kernel priced with 0 bytes, counter-based blocks quoting the counters' sources
     import glob
-    lines = sorted(glob.glob(os.path.join(REPO, "profiles", "r05_bench_*.json")))
+    lines = sorted(glob.glob(os.path.join(REPO, "profiles", "r06_bench_*.json")))
     assert len(lines) >= 6
     for path in lines:
         j = json.loads(open(path).read().strip().splitlines()[-1])
@@ -220,17 +220,17 @@ def test_round4_lines_agree_with_the_rocprof_summaries():
         assert j["value"] / j["cpu_baseline"]["value"] > 10.0                      # north_star's target (>= 10x the reference CPU), both models
 
 
-def test_round5_lines_agree_with_the_rocprof_summaries():
-    # round 5: K1Q runs as TWO launches per step (fused narrow levels, then the sorted launch of the last dense-format level): the line's
+def test_current_lines_agree_with_the_rocprof_summaries():
+    # rounds 5-6: K1Q runs as TWO launches per step (fused narrow levels, then the sorted launch of the last dense-format level): the line's
     # avg_launch_ms of the k1q family = the mean of the two kernels' average durations in the rocprofv3 --kernel-trace --stats summary;
     # `frac` = counter bytes of the family per launch / that time / 8 TB/s.  The default line also carries the extra blocks.
-    for line, stats, kernels in (("r05_bench_amazon670k_n1.json", "r05_bench_amazon670k_kernel_stats.csv",
+    for line, stats, kernels in (("r06_bench_amazon670k_n1.json", "r06_bench_amazon670k_kernel_stats.csv",
                                   ("k1q_kernel<3, 0, false, true, false, false, false>", "k1q_kernel<3, 0, false, false, false, false, true>")),):
         j = _recorded(line)
         r = j["roofline"]
         rows = _kernel_stats(stats)
         avg = sum(float(next(x for x in rows if k in x["Name"])["AverageNs"]) for k in kernels) * 1e-6 / len(kernels)
-        assert r["kernel"].startswith("k1q") and r["basis"].startswith("pmc") and "b1540963f5dfc195" in r["basis"]
+        assert r["kernel"].startswith("k1q") and r["basis"].startswith("pmc") and "fb6d39fa72ddf226" in r["basis"]
         assert len(r["launches_priced"]) == 2 and r["launches_per_step"] == 2.0
         assert abs(avg - r["avg_launch_ms"]) / r["avg_launch_ms"] < 0.03, (avg, r["avg_launch_ms"])
         assert abs(r["achieved"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
@@ -238,17 +238,17 @@ def test_round5_lines_agree_with_the_rocprof_summaries():
         assert abs(j["value"] - 490000 * 1e3 / j["ms_per_step"]) / j["value"] < 1e-3 and j["value"] / j["cpu_baseline"]["value"] > 10.0
         p = j["parity"]
         assert p["timed_output_identical"] and p["scores_bit_identical"] and p["indices_identical"]
-    j = _recorded("r05_bench_amazon670k_n1.json")
+    j = _recorded("r06_bench_amazon670k_n1.json")
     hard, t2l = j["extra"]["hard"], j["extra"]["text_to_labels"]
     assert hard["config"] == "amazon-670k-hard" and hard["parity"]["timed_output_identical"] and 10.0 < hard["ms_per_step"] < 25.0
     assert t2l["labels_identical_to_reference"] and t2l["scores_bit_identical_to_reference"] and t2l["value"] > 10 * t2l["reference"]["value"]
     # the hard workload's own line: the tile-format leaf is now the family with the most GPU time, priced with ITS counters
-    h = _recorded("r05_bench_amazon670k_hard_n1.json")
+    h = _recorded("r06_bench_amazon670k_hard_n1.json")
     assert h["roofline"]["kernel"].startswith("k1_sparse") and h["roofline"]["basis"].startswith("pmc") and h["roofline"]["issue"]["valu_busy_frac"] > 0.6
     # BASELINE.json configs[4] at its stated size has a valid line again
-    d = _recorded("r05_bench_dense768_full_L3M_N1M_n1.json")
-    assert "N=1000000" in d["config"]["workload"] and "L=3000000" in d["config"]["workload"] and d["roofline"]["bound"] == "mfma"
-    assert 0.0 < d["roofline"]["frac"] < 0.5 and d["parity"]["timed_output_identical"] and d["parity"]["scores_bit_identical"]
+    d = _recorded("r06_bench_dense768_full_L3M_N1M_n1.json")
+    assert "N=1000000" in d["config"]["workload"] and "L=3000000" in d["config"]["workload"] and d["roofline"]["bound"] == "valu"
+    assert 0.0 < d["roofline"]["frac"] < 0.5 and d["parity"]["timed_output_identical"] and d["parity"]["timed_output_scores_bit_identical"]
 
 
 def test_counter_sets_recompute_from_the_committed_passes():
@@ -263,7 +263,7 @@ def test_counter_sets_recompute_from_the_committed_passes():
     for key, n in names.items():
         with tempfile.TemporaryDirectory() as d:
             for k in ("fetch", "write", "l2", "sq"):
-                os.symlink(os.path.join(REPO, "profiles", f"r05_pmc_{n}_{k}.csv"), os.path.join(d, f"pmc_{k}.csv"))
+                os.symlink(os.path.join(REPO, "profiles", f"r06_pmc_{n}_{k}.csv"), os.path.join(d, f"pmc_{k}.csv"))
             cfg, scale = key.split("@")
             out = os.path.join(d, "e.json")
             subprocess.check_call([sys.executable, os.path.join(REPO, "scripts", "pmc_traffic.py"), d, out, "1.0", cfg, scale], stdout=subprocess.DEVNULL)
