@@ -13,7 +13,7 @@ import test_kernel_resources as T  # noqa: E402
 HOT = ["k1q_kernel<3, 0, false, true, false, false, false>", "k1q_kernel<3, 0, false, false, false, false, true>", "k1q_kernel<3, 0, false, true, false, true, false>",
        "k1q_kernel<3, 0, false, false, false, true, true>", "k1q_kernel<3, 0, false, true, false, false, true>", "k1q_kernel<1, 0, false, true, false, false, false>",
        "k1q_kernel<6, 0, false, false, false, false, false>", "k1q_kernel<16, 0, false, false, false, false, false>",
-       "k1_kernel<32, 3, 0, false, 2>", "k1_kernel<16, 1, 0, false, 0>", "k1_kernel<32, 1, 0, false, 0>", "k1g_kernel<2, 12, 1, 64, 0>", "k1g_kernel<2, 8, 1, 64, 0>",
+       "k1_kernel<32, 3, 0, false, 2>", "k1t_kernel<32, 3, 0, 2, false>", "k1t_kernel<32, 3, 0, 2, true>", "k1t_kernel<8, 1, 0, 0, true>", "k1_kernel<16, 1, 0, false, 0>", "k1_kernel<32, 1, 0, false, 0>", "k1g_kernel<2, 12, 1, 64, 0>", "k1g_kernel<2, 8, 1, 64, 0>",
        "k2_topk_wave<13>", "k2_topk_wave<2>", "k2_topk_reg", "tfidf_weight_kernel", "sort_scatter_kernel", "k0b_remaining"]
 
 
@@ -34,7 +34,7 @@ def main():
         for k in sorted(notes):
             if fr in nice[k]:
                 v = notes[k]
-                print(f"| `{nice[k].replace('void xrl::', '').split('(')[0]}` | {v['vgpr']} | {waves(v['vgpr'])} | {v['sgpr']} | {v['sgpr_spill']} | {v['vgpr_spill']} | {v['scratch']} | {v['lds']} |")
+                print(f"| `{nice[k].replace('(anonymous namespace)::', '').replace('void xrl::', '').split('(')[0]}` | {v['vgpr']} | {waves(v['vgpr'])} | {v['sgpr']} | {v['sgpr_spill']} | {v['vgpr_spill']} | {v['scratch']} | {v['lds']} |")
 
 
 if __name__ == "__main__":
