@@ -455,13 +455,17 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
                     XRL_HIP(hipEventRecord(hl->join, m.aux_stream));
                     XRL_HIP(hipStreamWaitEvent(m.d2h_stream, hl->join, 0));
                 }
+                const double t_dl = now_ms();
                 download_rows(m, 0, rb[b + 1], k, 0);
+                if (host_timing() && now_ms() - t_dl > 0.5) std::fprintf(stderr, "[xrl host]   download of rows [0, %u): enqueue took %.2f ms\n", rb[b + 1], now_ms() - t_dl);
             } else if (b + 1 == n_batch) {
                 if (two && L) {                                          // the last batch ran on the auxiliary stream: its copies follow on the handle's stream
                     XRL_HIP(hipEventRecord(hl->join, m.aux_stream));
                     XRL_HIP(hipStreamWaitEvent(m.stream, hl->join, 0));
                 }
+                const double t_dl = now_ms();
                 download_rows(m, n_batch > 1 ? rb[b] : 0, rb[b + 1], k, -1);
+                if (host_timing() && now_ms() - t_dl > 0.5) std::fprintf(stderr, "[xrl host]   download of the last batch: enqueue took %.2f ms\n", now_ms() - t_dl);
             }
             g_ht.enqueue += now_ms() - t_ph;
         }
@@ -902,12 +906,36 @@ static void warm_handle(Model& m) {
     upload_csr(&Xh, ws.x_ptr, ws.x_idx, ws.x_val, X);
     PredictOpts o; o.reserve_rows = kWarmRows;
     const uint32_t k = effective_topk(m, 0);
-    reserve_outputs(m, R, k);
+    // result buffers (device + PINNED host: 4-10 ms to allocate inside a first call) for calls of up to 2^19 rows / 2^23 result cells: 64 MiB pinned per handle at most
+    reserve_outputs(m, std::max<uint32_t>(R, (uint32_t)std::min<uint64_t>(1u << 19, (1ull << 23) / std::max<uint32_t>(1u, k))), k);
     for (int L = 0; L < 2 && !m.csc_route; ++L) {   // (the CSC route builds its device copy of W on first use: not here)
         if (L) std::swap(ws.lane[0], ws.lane[1]);
         try { predict_device(m, X, o, ws.out_idx.as<uint32_t>(), ws.out_val.as<float>(), ws.out_cnt.as<uint32_t>(), k, m.stream, true); }
         catch (...) { if (L) std::swap(ws.lane[0], ws.lane[1]); throw; }
         if (L) std::swap(ws.lane[0], ws.lane[1]);
+    }
+    // Every stream's FIRST copy pays for the runtime setting up its copy path (measured: 5.5 ms inside the first call's download on the D2H stream, 5.5 ms
+    // again two calls later when the last row batch first lands on the other compute lane): one 1 MiB copy each way on each stream now, at load.
+    {
+        const size_t nb = std::min<size_t>((size_t)1 << 20, std::min(ws.out_idx.cap, ws.h_idx.cap));
+        if (nb) {
+            for (hipStream_t st : {m.stream, m.aux_stream, m.d2h_stream, m.copy_stream}) {
+                if (!st) continue;
+                XRL_HIP(hipMemcpyAsync(ws.h_idx.p, ws.out_idx.p, nb, hipMemcpyDeviceToHost, st));
+                XRL_HIP(hipMemcpyAsync(ws.out_idx.p, ws.stage[0].p, std::min(nb, ws.stage[0].cap), hipMemcpyHostToDevice, st));
+                XRL_HIP(hipStreamSynchronize(st));
+            }
+        }
+    }
+    // The warm-up queries (one feature each) say nothing about the caller's data: what the pruning feedback learned from them is discarded -- round 6: their
+    // later stages hold almost every item, which marked the leaf "unstaged" and made a fresh handle score all beam parents of every query until the first
+    // re-probe, 32 row batches (~3 host-ABI calls) later.
+    if (m.fb_host) {
+        for (int l = 0; l < Model::kFbLayers; ++l) {
+            m.fb_unstaged[l] = 0; m.fb_probing[l] = 0; m.fb_unstaged_calls[l] = 0; m.fb_tile_slots[l] = 0;
+            m.fb_seen[l] = m.fb_host[2 * l]; m.fb_second[l] = m.fb_host[2 * l + 1];
+            m.fb_host[2 * Model::kFbLayers + l] = 0xFFFFFFFFu;
+        }
     }
 }
 
