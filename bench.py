@@ -623,10 +623,10 @@ def shard8_line(clib, h, q, torch, dev, stream, tstream, beam, args, k, n_total,
     def step():
         clib.predict_device_rows(h, q, beam, None, args.topk, idx.data_ptr(), val.data_ptr(), cnt.data_ptr(), k, 0, rows, stream=stream, sync=False)
     with torch.cuda.stream(tstream):
-        for _ in range(max(args.warmup, 8)):      # (the pruning feedback's item counts settle at the shard's size)
+        for _ in range(max(args.warmup, 30)):     # (the pruning feedback's item counts settle at the shard's size; the clocks are back up after the CPU legs)
             step()
         torch.cuda.synchronize()
-        n = max(args.steps, 50)
+        n = max(args.steps, 200)      # (0.85 ms steps: 50 of them ran 15 % slower than 200 -- the device had idled through the host-ABI and CPU legs)
         t0 = time.perf_counter()
         for _ in range(n):
             step()

@@ -17,6 +17,7 @@ from pecos_amd import XLinearModel, clib  # noqa: E402
 name, scale, steps = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
 sets = sys.argv[4:] or [""]
 rows_limit = int(os.environ.get("AB_ROWS", "0"))
+shard_rows = int(os.environ.get("AB_SHARD_ROWS", "0"))   # > 0: predict only the first AB_SHARD_ROWS rows of the (whole, device-resident) X: bench.py's extra.shard8 shape
 DEFAULTS = dict(tile_rows=1, k1g_first=0, k1g_variant=0, sort_rest_min=32768, qsort=1, qsort_min_parents=64, qsort_min_rows=131072, prune=1, adaptive=1, presence=1, sort_rest=1, prune_mid=1, k1q_fuse=3, dense_layers=1, k1_group=0, sort_min_tiles=0)
 folder = f"/tmp/xrl_bench/{name}_{scale}"
 if not os.path.exists(folder + "/.done"):
@@ -49,6 +50,13 @@ def fetch(t):
     return t.cpu().numpy().view(np.uint32)
 
 
+def run(sync):
+    if shard_rows:
+        clib.predict_device_rows(h, q, cfg["beam"], None, k, di, dv, dc, k, 0, shard_rows, sync=sync)
+    else:
+        clib.predict_device(h, q, cfg["beam"], None, k, di, dv, dc, k, sync=sync)
+
+
 ref = None
 for st in sets:
     for kk, vv in DEFAULTS.items():
@@ -57,12 +65,12 @@ for st in sets:
         if kv:
             clib.set_option(h, kv.split("=")[0], int(kv.split("=")[1]))
     for _ in range(6):
-        clib.predict_device(h, q, cfg["beam"], None, k, di, dv, dc, k, sync=True)
+        run(True)
     clib.profile_reset(h); clib.profile_enable(h, True)
     t0 = time.perf_counter()
     for _ in range(steps - 1):
-        clib.predict_device(h, q, cfg["beam"], None, k, di, dv, dc, k, sync=False)
-    clib.predict_device(h, q, cfg["beam"], None, k, di, dv, dc, k, sync=True)
+        run(False)
+    run(True)
     dt = (time.perf_counter() - t0) / steps
     clib.profile_enable(h, False)
     prof = clib.profile_get(h)
