@@ -335,8 +335,17 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     };
     fine("batch planning");
     if (is_csr) {
-        ws.x_ptr.upload_raw(Xs->row_ptr, ((size_t)rows + 1) * 8);
-        fine("row-pointer upload (synchronous pageable copy)");
+        // the row pointer travels like the rest of X: through pinned staging, first on the copy stream (every row batch waits for a later event of that
+        // stream).  A synchronous hipMemcpy from the caller's pageable array took 14-26 ms in the SECOND call of a process (the runtime pins the region it
+        // sees again), 0.1 ms otherwise.
+        {
+            const size_t pb = ((size_t)rows + 1) * 8;
+            ws.x_ptr.reserve(pb); ws.stage_ptr.reserve(pb);
+            if (!m.copy_stream) XRL_HIP(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
+            parallel_copy(ws.stage_ptr.p, Xs->row_ptr, pb);
+            XRL_HIP(hipMemcpyAsync(ws.x_ptr.p, ws.stage_ptr.p, pb, hipMemcpyHostToDevice, m.copy_stream));
+        }
+        fine("row-pointer upload (pinned staging, copy stream)");
         ws.x_idx.reserve(elems * 4); ws.x_val.reserve(elems * 4);
         X.row_ptr = ws.x_ptr.as<uint64_t>(); X.col_idx = ws.x_idx.as<uint32_t>(); X.val = ws.x_val.as<float>();
         X.rows = rows; X.cols = Xs->cols; X.dense = 0; X.nnz = elems;
@@ -353,6 +362,11 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
     if (!m.copy_stream) XRL_HIP(hipStreamCreateWithFlags(&m.copy_stream, hipStreamNonBlocking));
     hipEvent_t up[kStageSlots];
     for (auto& e : up) XRL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (is_csr) {   // the compute streams start after the row pointer has arrived (matters only when X holds no element: no chunk event would order them)
+        XRL_HIP(hipEventRecord(up[0], m.copy_stream));
+        XRL_HIP(hipStreamWaitEvent(m.stream, up[0], 0));
+        if (m.aux_stream) XRL_HIP(hipStreamWaitEvent(m.aux_stream, up[0], 0));
+    }
     fine("copy stream + events");
     const uint32_t k = effective_topk(m, o.only_topk);
     reserve_outputs(m, rows, k);
@@ -464,7 +478,7 @@ void host_compute(Model& m, const XT* input_x, PredictOpts o, bool is_csr) {
                     XRL_HIP(hipStreamWaitEvent(m.stream, hl->join, 0));
                 }
                 const double t_dl = now_ms();
-                download_rows(m, n_batch > 1 ? rb[b] : 0, rb[b + 1], k, -1);
+                download_rows(m, n_batch > 1 ? rb[b] : 0, rb[b + 1], k, 1);    // (on the D2H stream behind an event, like the rest: queued on the compute stream itself the copies blocked the enqueuing thread for 5-9 ms in a process's first two calls)
                 if (host_timing() && now_ms() - t_dl > 0.5) std::fprintf(stderr, "[xrl host]   download of the last batch: enqueue took %.2f ms\n", now_ms() - t_dl);
             }
             g_ht.enqueue += now_ms() - t_ph;
@@ -896,6 +910,7 @@ static void warm_handle(Model& m) {
     if (!m.aux_stream) XRL_HIP(hipStreamCreateWithFlags(&m.aux_stream, hipStreamNonBlocking));
     if (!m.d2h_stream) XRL_HIP(hipStreamCreateWithFlags(&m.d2h_stream, hipStreamNonBlocking));
     for (int s2 = 0; s2 < kStageSlots; ++s2) ws.stage[s2].reserve((size_t)32 << 20);
+    ws.stage_ptr.reserve((((size_t)1 << 19) + 1) * 8);
     // 256 one-feature queries through the default policy, once per scratch lane
     const uint32_t R = 256, D = std::max<uint32_t>(1, m.nr_features);
     std::vector<uint64_t> ptr(R + 1); std::vector<uint32_t> idx(R); std::vector<float> val(R, 1.0f);

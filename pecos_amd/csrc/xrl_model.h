@@ -156,6 +156,7 @@ struct Workspace {
     DevBuf out_idx, out_val, out_cnt;
     PinnedBuf h_idx, h_val, h_cnt;
     PinnedBuf stage[3];   // pinned staging ring of the pipelined host-ABI upload (kStageSlots, xrl_abi.cpp)
+    PinnedBuf stage_ptr;  // ... and the row pointer's own pinned staging buffer (it travels first, on the copy stream)
     // initial beam for the single-layer API
     DevBuf init_idx, init_val, init_cnt;
 };
