@@ -230,7 +230,7 @@ def test_current_lines_agree_with_the_rocprof_summaries():
         r = j["roofline"]
         rows = _kernel_stats(stats)
         avg = sum(float(next(x for x in rows if k in x["Name"])["AverageNs"]) for k in kernels) * 1e-6 / len(kernels)
-        assert r["kernel"].startswith("k1q") and r["basis"].startswith("pmc") and "fb6d39fa72ddf226" in r["basis"]
+        assert r["kernel"].startswith("k1q") and r["basis"].startswith("pmc") and "480bcc7b9a2a34a9" in r["basis"]
         assert len(r["launches_priced"]) == 2 and r["launches_per_step"] == 2.0
         assert abs(avg - r["avg_launch_ms"]) / r["avg_launch_ms"] < 0.03, (avg, r["avg_launch_ms"])
         assert abs(r["achieved"] - r["traffic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1.0 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-3
